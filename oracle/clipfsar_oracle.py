@@ -1,0 +1,199 @@
+"""TEST INFRASTRUCTURE -- CPU restatement (torch fp32, plain tensor ops) of the
+CLIP-FSAR episodic-inference hot path of the reference, function by function.
+
+This file is the *checker*: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product path
+(``clip-fsar_amd/``) never imports it and has no CPU fallback.
+
+Pinning: every function below is checked in ``tests/test_oracle_golden.py`` against
+golden vectors produced by importing the real reference in the dev container
+(``oracle/make_golden.py`` + ``oracle/ref_harness.py``).  The reference itself has no
+tests / golden vectors for this path, so the pin is "outputs of the
+reference itself run here".
+
+All citations are to /root/reference/models/base/few_shot.py unless stated otherwise.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+# ------------------------------------------------------------------ A3  LayerNorm (:605-611)
+def layer_norm(x, weight, bias, eps: float = 1e-5):
+    """nn.LayerNorm over the last dim, fp32 statistics, biased variance (:605-611)."""
+    mu = x.mean(dim=-1, keepdim=True)
+    xc = x - mu
+    var = (xc * xc).mean(dim=-1, keepdim=True)
+    return xc * torch.rsqrt(var + eps) * weight + bias
+
+
+def quick_gelu(x):
+    """QuickGELU: x * sigmoid(1.702 x) (:614-616)."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def gelu_erf(x):
+    """nn.GELU() default (exact erf form) used by FeedForward (:1647)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+# ------------------------------------------------------------------ A2  patch embed (:672-676)
+def patch_embed(frames, conv_w, cls, pos, patch: int):
+    """conv1 (stride = kernel = patch, no bias) as a GEMM over non-overlapping patches,
+    patches row-major over the grid, patch vector flattened channel-major then dy then dx;
+    then [cls ; patches] + positional embedding (:672-676).  frames [F,3,H,W] -> [F,N,D]."""
+    F_, C, H, W = frames.shape
+    g = H // patch
+    D = conv_w.shape[0]
+    p = frames.reshape(F_, C, g, patch, g, patch).permute(0, 2, 4, 1, 3, 5).reshape(F_, g * g, C * patch * patch)
+    tok = p @ conv_w.reshape(D, -1).t()                                    # [F, g*g, D]
+    x = torch.cat([cls.reshape(1, 1, D).expand(F_, 1, D), tok], dim=1)
+    return x + pos
+
+
+# ------------------------------------------------------------------ A4-A6 residual block (:619-640)
+def resblock(x, sd, pre: str, heads: int):
+    """x [F,N,D].  x += out_proj(MHA(ln_1 x)); x += c_proj(QuickGELU(c_fc(ln_2 x)))  (:637-640).
+    nn.MultiheadAttention semantics (:623,:635): packed in_proj [3D,D]+bias, per-head
+    softmax(q k^T / sqrt(hd)) v, no mask, no dropout."""
+    F_, N, D = x.shape
+    hd = D // heads
+    h = layer_norm(x, sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"])
+    qkv = h @ sd[pre + "attn.in_proj_weight"].t() + sd[pre + "attn.in_proj_bias"]
+    q, k, v = qkv.split(D, dim=-1)
+    q = q.reshape(F_, N, heads, hd).transpose(1, 2)
+    k = k.reshape(F_, N, heads, hd).transpose(1, 2)
+    v = v.reshape(F_, N, heads, hd).transpose(1, 2)
+    att = torch.softmax((q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(hd)), dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(F_, N, D)
+    x = x + o @ sd[pre + "attn.out_proj.weight"].t() + sd[pre + "attn.out_proj.bias"]
+    h = layer_norm(x, sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"])
+    u = quick_gelu(h @ sd[pre + "mlp.c_fc.weight"].t() + sd[pre + "mlp.c_fc.bias"])
+    return x + u @ sd[pre + "mlp.c_proj.weight"].t() + sd[pre + "mlp.c_proj.bias"]
+
+
+# ------------------------------------------------------------------ A1  VisionTransformer.forward (:671-688)
+def vit_forward(frames, sd, arch, prefix: str = "backbone.", chunk: int = 40, taps=None):
+    """frames [F,3,res,res] fp32 -> features [F,E].  ``arch`` = dict(width, layers, heads, patch, ...).
+    ``taps`` (optional dict) receives intermediates for the first chunk (test use)."""
+    outs = []
+    for s in range(0, frames.shape[0], chunk):
+        f = frames[s:s + chunk]
+        x = patch_embed(f, sd[prefix + "conv1.weight"], sd[prefix + "class_embedding"],
+                        sd[prefix + "positional_embedding"], arch["patch"])
+        x = layer_norm(x, sd[prefix + "ln_pre.weight"], sd[prefix + "ln_pre.bias"])        # :677
+        if taps is not None and s == 0:
+            taps["ln_pre"] = x.clone()
+        for i in range(arch["layers"]):                                                      # :679-681
+            x = resblock(x, sd, "%stransformer.resblocks.%d." % (prefix, i), arch["heads"])
+            if taps is not None and s == 0:
+                taps["block%d" % i] = x.clone()
+        c = layer_norm(x[:, 0, :], sd[prefix + "ln_post.weight"], sd[prefix + "ln_post.bias"])  # :683
+        outs.append(c @ sd[prefix + "proj"])                                                 # :685-686
+    return torch.cat(outs, 0)
+
+
+# ------------------------------------------------------------------ A11 Transformer_v1 (:971-999,:1035-1073,:1643-1654)
+def context2_forward(x, sd, heads: int = 8, prefix: str = "context2.", depth: int = 1):
+    """x [B,L,E] used as q=k=v.  Layer 0: ONE shared LayerNorm for q,k,v (:971-977); to_q/k/v
+    without bias, to_out with bias (:1046-1053); scale = dim_head**-0.5 (:1042); residual on q;
+    FeedForward Linear-GELU(erf)-Linear + residual (:994-995).  Layers >= 1 self-attend on the
+    output (:996-999)."""
+    B, L, E = x.shape
+    for d in range(depth):
+        p = "%slayers.%d." % (prefix, d)
+        n = layer_norm(x, sd[p + "0.norm.weight"], sd[p + "0.norm.bias"])
+        inner = sd[p + "0.fn.to_q.weight"].shape[0]
+        hd = inner // heads
+        q = (n @ sd[p + "0.fn.to_q.weight"].t()).reshape(B, L, heads, hd).transpose(1, 2)
+        k = (n @ sd[p + "0.fn.to_k.weight"].t()).reshape(B, L, heads, hd).transpose(1, 2)
+        v = (n @ sd[p + "0.fn.to_v.weight"].t()).reshape(B, L, heads, hd).transpose(1, 2)
+        a = torch.softmax((q @ k.transpose(-1, -2)) * (hd ** -0.5), dim=-1)
+        o = (a @ v).transpose(1, 2).reshape(B, L, inner)
+        y = o @ sd[p + "0.fn.to_out.0.weight"].t() + sd[p + "0.fn.to_out.0.bias"] + x
+        u = gelu_erf(y @ sd[p + "1.net.0.weight"].t() + sd[p + "1.net.0.bias"])
+        x = u @ sd[p + "1.net.3.weight"].t() + sd[p + "1.net.3.bias"] + y
+    return x
+
+
+# ------------------------------------------------------------------ A13 cos_sim (:1115-1124)
+def cos_sim(x, y, epsilon: float = 0.01):
+    """(x y^T) / (|x| |y|^T + eps): eps is ADDED to the product of norms, no clamp."""
+    num = x @ y.transpose(-1, -2)
+    xn = torch.linalg.vector_norm(x, dim=-1, keepdim=True)
+    yn = torch.linalg.vector_norm(y, dim=-1, keepdim=True)
+    return num / (xn @ yn.transpose(-1, -2) + epsilon)
+
+
+# ------------------------------------------------------------------ A14 OTAM_cum_dist_v2 (:2657-2687)
+def otam_cum_dist(dists, lbda: float = 0.5):
+    """dists [Q,C,T,T'] -> [Q,C].  Zero-pad one column each side (:2663); first row is a plain
+    running sum (:2668-2671); remaining rows use the un-stabilised soft-min
+    -lbda*log(sum exp(-c/lbda)) with 3 predecessors in column 1 and in the last column,
+    2 in the middle columns (:2675-2685)."""
+    d = torch.nn.functional.pad(dists, (1, 1), "constant", 0.0)
+    Qn, Cn, R, M = d.shape
+    c = torch.zeros_like(d)
+    for m in range(1, M):
+        c[:, :, 0, m] = d[:, :, 0, m] + c[:, :, 0, m - 1]
+    for l in range(1, R):
+        c[:, :, l, 1] = d[:, :, l, 1] - lbda * torch.log(
+            torch.exp(-c[:, :, l - 1, 0] / lbda) + torch.exp(-c[:, :, l - 1, 1] / lbda)
+            + torch.exp(-c[:, :, l, 0] / lbda))
+        for m in range(2, M - 1):
+            c[:, :, l, m] = d[:, :, l, m] - lbda * torch.log(
+                torch.exp(-c[:, :, l - 1, m - 1] / lbda) + torch.exp(-c[:, :, l, m - 1] / lbda))
+        c[:, :, l, M - 1] = d[:, :, l, M - 1] - lbda * torch.log(
+            torch.exp(-c[:, :, l - 1, M - 2] / lbda) + torch.exp(-c[:, :, l - 1, M - 1] / lbda)
+            + torch.exp(-c[:, :, l, M - 2] / lbda))
+    return c[:, :, -1, -1]
+
+
+# ------------------------------------------------------------------ A12 class means (:1127-1136, :2949-2962)
+def class_means(x, labels):
+    """mean of x[s] over the supports of each class, classes in ascending label order
+    (torch.unique sorts, :2950,:2958)."""
+    uniq = torch.unique(labels)
+    return torch.stack([x[labels == c].mean(dim=0) for c in uniq]), uniq
+
+
+# ------------------------------------------------------------------ A9-A15 head forward, eval default branch (:2932-2990)
+def head_forward(episode, sd, text_train, text_test, arch, frames: int, merge_before: bool = False,
+                 single_direct: bool = False, depth: int = 1, taps=None):
+    """episode: the A0 dict of torch tensors.  Returns {'logits' [Q,way], 'class_logits' [(S+Q),n_train]}."""
+    T = frames
+    sup_lab = episode["support_labels"]
+    feats_s = vit_forward(episode["support_set"], sd, arch)                      # :2761
+    feats_q = vit_forward(episode["target_set"], sd, arch)                       # :2762
+    E = feats_s.shape[-1]
+    Fs = feats_s.reshape(-1, T, E)                                               # :2765
+    Fq = feats_q.reshape(-1, T, E)                                               # :2764
+    # aux class logits -- TRAIN text table even in eval (:2937-2939)
+    cls_in = torch.cat([Fs, Fq], dim=0).mean(dim=1)
+    class_logits = cos_sim(cls_in, text_train) * sd["scale"]
+    ctx = text_test[episode["real_support_labels"].long()].unsqueeze(1)          # :2946
+    Fq2 = context2_forward(Fq, sd, depth=depth)                                  # :2948
+    if merge_before:                                                             # :2949-2954
+        Fs, _ = class_means(Fs, sup_lab)
+        ctx, _ = class_means(ctx, sup_lab)
+    Fs2 = context2_forward(torch.cat([Fs, ctx], dim=1), sd, depth=depth)[:, :T, :]   # :2955-2956
+    if not merge_before:                                                         # :2957-2962
+        Fs2, _ = class_means(Fs2, sup_lab)
+    nq, ns = Fq2.shape[0], Fs2.shape[0]
+    sim = cos_sim(Fq2.reshape(nq * T, E), Fs2.reshape(ns * T, E))                # :2973
+    dists = (1.0 - sim).reshape(nq, T, ns, T).permute(0, 2, 1, 3)                # :2974-2976
+    cum = otam_cum_dist(dists)                                                   # :2979-2982
+    if not single_direct:
+        cum = cum + otam_cum_dist(dists.transpose(-1, -2))
+    # :2986-2988 -- class c <- column c (unique labels are sorted, so this is the identity)
+    logits = -cum
+    if taps is not None:
+        taps.update(feats_s=feats_s, feats_q=feats_q, ctx_q=Fq2, protos=Fs2, dists=dists, cum_dists=cum)
+    return {"logits": logits, "class_logits": class_logits}
+
+
+def top1_correct(logits, target_labels):
+    """metrics.topks_correct(...,(1,)) (reference utils/metrics.py:100-138): count of argmax hits."""
+    return int((logits.argmax(dim=1) == target_labels.long()).sum())

@@ -1,0 +1,176 @@
+"""TEST INFRASTRUCTURE -- dev-container only: generate tests/golden/*.npz by running the REAL
+reference (imported from /root/reference through oracle/ref_harness.py) on inputs produced by
+the repo's deterministic generators (clip-fsar_amd/synth.py).
+
+    python oracle/make_golden.py [--only NAME ...] [--skip-large]
+
+Fixtures hold only *outputs / intermediates* (inputs and weights are regenerated from
+synth.py with the recorded parameters), so they stay small.  The reference's source never
+enters a fixture.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import clip_fsar_amd.synth as synth  # noqa: E402
+import ref_harness as rh  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# name -> parameters.  n_train/n_test follow the K100 config (64 train / 24 test classes,
+# reference configs/projects/CLIPFSAR/kinetics100/CLIPFSAR_K100_1shot_v1.yaml:21,38).
+HEAD_CASES = {
+    # tiny-architecture cases (seconds): every head option the eval default branch reads
+    "t_5w1s_T8": dict(arch="ViT-test/16", way=5, shot=1, q=1, T=8),
+    "t_5w5s_T8_mb": dict(arch="ViT-test/16", way=5, shot=5, q=1, T=8, merge_before=True),
+    "t_5w5s_q2_T8": dict(arch="ViT-test/16", way=5, shot=5, q=2, T=8),
+    "t_5w3s_T16_mb_d2": dict(arch="ViT-test/16", way=5, shot=3, q=1, T=16, merge_before=True, depth=2),
+    "t_5w2s_T4_sd": dict(arch="ViT-test/16", way=5, shot=2, q=1, T=4, single_direct=True),
+    "t197_5w1s_T2": dict(arch="ViT-test197/16", way=5, shot=1, q=1, T=2),
+    "t257_5w1s_T2": dict(arch="ViT-test257/14", way=5, shot=1, q=1, T=2),
+    # BASELINE.json configs at full size
+    "cfg2_B16_5w1s_T8": dict(arch="ViT-B/16", way=5, shot=1, q=1, T=8, large=True),
+    "cfg3_B16_5w5s_T8_mb": dict(arch="ViT-B/16", way=5, shot=5, q=1, T=8, merge_before=True, large=True),
+    "cfg4_L14_5w1s_T16": dict(arch="ViT-L/14", way=5, shot=1, q=1, T=16, large=True),
+}
+N_TRAIN, N_TEST, SEED = 64, 24, 18
+
+
+def run_head_case(name, p):
+    arch = p["arch"]
+    a = synth.ARCHS[arch]
+    depth = p.get("depth", 1)
+    sd = synth.head_state_dict(arch, seed=SEED, depth=depth)
+    tt = synth.text_features(N_TRAIN, a["embed"], "train", SEED)
+    te = synth.text_features(N_TEST, a["embed"], "test", SEED)
+    cfg = rh.make_cfg(arch, way=p["way"], shot=p["shot"], frames=p["T"], n_train=N_TRAIN, n_test=N_TEST,
+                      merge_before=p.get("merge_before", False), depth=p.get("depth"),
+                      single_direct=p.get("single_direct", False))
+    head = rh.build_reference_head(cfg, a, sd, tt, te)
+    fs = rh.import_reference()
+    ep = synth.make_episode(way=p["way"], shot=p["shot"], query_per_class=p["q"], frames=p["T"], res=a["res"],
+                            n_test_classes=N_TEST, episode=0, seed=SEED)
+    taps = {"vit": [], "ctx": []}
+    h1 = head.backbone.register_forward_hook(lambda m, i, o: taps["vit"].append(o.detach().clone()))
+    h2 = head.context2.register_forward_hook(lambda m, i, o: taps["ctx"].append(o.detach().clone()))
+    t0 = time.time()
+    with torch.no_grad():
+        out = head(rh.episode_to_torch(ep))
+    dt = time.time() - t0
+    h1.remove()
+    h2.remove()
+    T = p["T"]
+    feats_s, feats_q = taps["vit"]
+    ctx_q, ctx_s_full = taps["ctx"]            # query call first (:2948), then support (:2955)
+    # recompute the distance stages with the reference's own helpers, following :2956-2982
+    with torch.no_grad():
+        sup = ctx_s_full[:, :T, :]
+        if not p.get("merge_before", False):
+            lab = torch.from_numpy(ep["support_labels"])
+            uniq = torch.unique(lab)
+            sup = torch.stack([torch.mean(torch.index_select(sup, 0, fs.extract_class_indices(lab, c)), dim=0)
+                               for c in uniq])
+        nq, ns = ctx_q.shape[0], sup.shape[0]
+        sim = fs.cos_sim(ctx_q.reshape(nq * T, -1), sup.reshape(ns * T, -1))
+        dists = (1 - sim).reshape(nq, T, ns, T).permute(0, 2, 1, 3).contiguous()
+        cum = fs.OTAM_cum_dist_v2(dists)
+        if not p.get("single_direct", False):
+            cum = cum + fs.OTAM_cum_dist_v2(dists.transpose(-1, -2))
+    assert torch.allclose(-cum, out["logits"], atol=1e-6), "harness recomputation disagrees with the head"
+    meta = dict(p)
+    meta.update(n_train=N_TRAIN, n_test=N_TEST, seed=SEED, episode=0, ref_seconds=round(dt, 2),
+                torch=torch.__version__)
+    np.savez_compressed(
+        os.path.join(GOLD, "head_%s.npz" % name), meta=json.dumps(meta),
+        logits=out["logits"].numpy(), class_logits=out["class_logits"].numpy(),
+        feats_s=feats_s.numpy(), feats_q=feats_q.numpy(), ctx_q=ctx_q.numpy(), protos=sup.numpy(),
+        dists=dists.numpy(), cum_dists=cum.numpy())
+    lg = out["logits"]
+    acc = float((lg.argmax(1).float().numpy() == ep["target_labels"]).mean())
+    print("%-22s ref %.1fs  logits[%.3f..%.3f] spread %.3f acc %.2f" % (
+        name, dt, lg.min(), lg.max(), float(lg.max() - lg.min()), acc), flush=True)
+
+
+def run_vit_taps():
+    """Per-layer intermediates of the reference VisionTransformer on the tiny arch (pins every
+    op's semantics layer by layer)."""
+    arch = "ViT-test/16"
+    a = synth.ARCHS[arch]
+    sd = synth.vit_state_dict(arch, SEED)
+    vit = rh.build_reference_vit(a, sd)
+    ep = synth.make_episode(frames=3, res=a["res"], seed=SEED, episode=1)
+    frames = torch.from_numpy(ep["support_set"][:6].copy())
+    taps = {}
+    hooks = [vit.ln_pre.register_forward_hook(lambda m, i, o: taps.__setitem__("ln_pre", o.detach().clone()))]
+    for li, blk in enumerate(vit.transformer.resblocks):
+        hooks.append(blk.register_forward_hook(
+            lambda m, i, o, li=li: taps.__setitem__("block%d" % li, o.detach().permute(1, 0, 2).clone())))
+    with torch.no_grad():
+        out = vit(frames)
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(GOLD, "vit_taps_tiny.npz"),
+                        meta=json.dumps(dict(arch=arch, seed=SEED, episode=1, frames=3, n=6)),
+                        out=out.numpy(), **{k: v.numpy() for k, v in taps.items()})
+    print("vit_taps_tiny         out std %.3f" % float(out.std()))
+
+
+def run_known_answers():
+    """Known-answer table recomputed from the reference helpers."""
+    fs = rh.import_reference()
+    torch.manual_seed(0)
+    r = torch.rand(2, 3, 4, 4)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(5, 16, generator=g)
+    y = torch.randn(7, 16, generator=g)
+    d8 = torch.rand(3, 2, 8, 8, generator=g) * 2.0
+    d16 = torch.rand(2, 2, 16, 16, generator=g) * 2.0
+    np.savez_compressed(
+        os.path.join(GOLD, "known_answers.npz"),
+        cos_ones=fs.cos_sim(torch.ones(2, 4), torch.ones(3, 4)).numpy(),
+        otam_zeros=fs.OTAM_cum_dist_v2(torch.zeros(1, 1, 8, 8)).numpy(),
+        otam_ones=fs.OTAM_cum_dist_v2(torch.ones(1, 1, 8, 8)).numpy(),
+        otam_1meye=fs.OTAM_cum_dist_v2(1 - torch.eye(8).reshape(1, 1, 8, 8)).numpy(),
+        otam_l01_zeros=fs.OTAM_cum_dist(torch.zeros(1, 1, 8, 8)).numpy(),
+        bidir_in=r.numpy(),
+        bidir_out=(fs.OTAM_cum_dist_v2(r) + fs.OTAM_cum_dist_v2(r.transpose(-1, -2))).numpy(),
+        cos_x=x.numpy(), cos_y=y.numpy(), cos_xy=fs.cos_sim(x, y).numpy(),
+        d8=d8.numpy(), otam_d8=fs.OTAM_cum_dist_v2(d8).numpy(),
+        d16=d16.numpy(), otam_d16=fs.OTAM_cum_dist_v2(d16).numpy(),
+        quickgelu_in=x.numpy(), quickgelu_out=fs.QuickGELU()(x).numpy(),
+        gelu_out=torch.nn.GELU()(x).numpy())
+    print("known_answers         ok")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--skip-large", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count() or 1)
+    if not args.only:
+        run_known_answers()
+        run_vit_taps()
+    for name, p in HEAD_CASES.items():
+        if args.only and name not in args.only:
+            continue
+        if p.get("large") and args.skip_large:
+            continue
+        run_head_case(name, {k: v for k, v in p.items() if k != "large"})
+
+
+if __name__ == "__main__":
+    main()
