@@ -1,0 +1,245 @@
+// A5: scaled-dot-product attention inside nn.MultiheadAttention of the CLIP ViT (few_shot.py:623,633-635):
+// per (frame, head): softmax(q k^T / sqrt(64)) v, no mask, no dropout.  Sequence = 197 (B/16) or 257 (L/14) tokens,
+// head_dim = 64, so K and V of one (frame, head) fit in LDS and the softmax is single-pass.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+// ------------------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel.  One 256-thread workgroup per (head, frame).
+//   LDS:  K tile  [NP keys][64] bf16, 128-byte rows, 16-byte chunks XOR-swizzled with (row>>1)&7
+//         V^T tile [64 d][NP keys] bf16, row stride == 16 (mod 256) bytes -> conflict-free ds_read_b64
+//   Per wave: 16 query rows at a time.  S^T = K . Q^T with v_mfma_f32_16x16x32_bf16 (K rows feed MFMA "A", Q^T feeds
+//   "B"), so lane (q = lane&15, g = lane>>4) holds, for every 16-key tile j, the scores of keys 16j+4g+{0..3} for
+//   ITS query: the softmax reduction over keys is in-lane + two shuffles (xor 16, 32), and the exponentiated
+//   scores are already in the "B" fragment layout of the PV MFMA (O^T = V^T . P^T) because the MFMA k index is
+//   only a summation index: k-slot (g, j<4) <-> key 32kb+4g+j, (g, j>=4) <-> key 32kb+16+4g+(j-4); V^T fragments are
+//   read from LDS with the same key permutation.  No P round trip through LDS, no cross-lane data movement.
+// ------------------------------------------------------------------------------------------------------------
+template <int NKB>   // number of 32-key blocks (7 -> up to 224 keys, 9 -> up to 288 keys)
+__global__ __launch_bounds__(256) void vit_attn_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
+                                                            int ntok, int D, float scale_log2e) {
+    constexpr int NP = NKB * 32;
+    constexpr int NT = NKB * 2;                                    // 16-key tiles
+    constexpr int VT_STRIDE = ((NP * 2 + 255) / 256) * 256 + 16;   // bytes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sVt = smem + NP * 128;
+
+    const int h = blockIdx.x, f = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t ld = (size_t)3 * D;
+    const __bf16* base = qkv + (size_t)f * ntok * ld + h * 64;
+
+    // ---- stage K (swizzled rows) : NP*8 16-byte chunks
+    for (int idx = tid; idx < NP * 8; idx += 256) {
+        const int r = idx >> 3, pc = idx & 7;
+        const int c = pc ^ swz(r);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < ntok) v = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + D + c * 8);
+        *reinterpret_cast<uint4*>(sK + r * 128 + pc * 16) = v;
+    }
+    // ---- stage V^T: thread takes keys (2kp, 2kp+1) x 8 d values, writes 8 packed bf16 pairs
+    for (int idx = tid; idx < (NP / 2) * 8; idx += 256) {
+        const int kp = idx % (NP / 2), dc = idx / (NP / 2);
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+        if (2 * kp < ntok) v0 = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp) * ld + 2 * D + dc * 8);
+        if (2 * kp + 1 < ntok) v1 = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp + 1) * ld + 2 * D + dc * 8);
+        const unsigned a[4] = {v0.x, v0.y, v0.z, v0.w};
+        const unsigned b[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned lo = (a[j] & 0xFFFFu) | (b[j] << 16);          // d = dc*8 + 2j
+            const unsigned hi = (a[j] >> 16) | (b[j] & 0xFFFF0000u);      // d = dc*8 + 2j + 1
+            *reinterpret_cast<unsigned*>(sVt + (dc * 8 + 2 * j) * VT_STRIDE + kp * 4) = lo;
+            *reinterpret_cast<unsigned*>(sVt + (dc * 8 + 2 * j + 1) * VT_STRIDE + kp * 4) = hi;
+        }
+    }
+    __syncthreads();
+
+    const int q16 = lane & 15, g = lane >> 4;
+    const int nqt = (ntok + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        int qrow = qt * 16 + q16;
+        const bool qvalid = qrow < ntok;
+        if (!qvalid) qrow = ntok - 1;
+        // Q fragment ("B" operand): Q[qrow][32ks + 8g .. +8]
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + ks * 32 + g * 8);
+
+        // S^T tiles
+        f32x4 s[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int kr = j * 16 + q16;   // key row this lane reads for the "A" operand
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kr * 128 + (((ks * 4 + g) ^ swz(kr)) << 4));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
+            }
+            s[j] = acc;
+        }
+        // mask padded keys, row max
+        float mx = -1e30f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = j * 16 + g * 4 + r;
+                if (key >= ntok) s[j][r] = -1e30f;
+                mx = fmaxf(mx, s[j][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = exp2f((s[j][r] - mx) * scale_log2e);
+                s[j][r] = pv;
+                sum += pv;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+
+        // O^T = V^T . P^T
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            bf16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (__bf16)s[2 * kb][r];
+                pf[4 + r] = (__bf16)s[2 * kb + 1][r];
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const char* vr = sVt + (dt * 16 + q16) * VT_STRIDE + (kb * 32 + g * 4) * 2;
+                const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vr + 32);
+                const uint4 packed = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, packed), pf, o[dt], 0, 0, 0);
+            }
+        }
+        // O^T[d][q]: lane owns query q16, d = 16dt + 4g + r
+        if (qvalid) {
+            __bf16* orow = out + ((size_t)f * ntok + qrow) * D + h * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (__bf16)(o[dt][r] * inv);
+                *reinterpret_cast<bf16x4*>(orow + dt * 16 + g * 4) = ov;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fp32 VALU kernel (validation mode).  One workgroup per (head, frame); K and V rows in LDS (fp32); one thread per
+// query row with an online softmax (running max / sum, fp32) -- all lanes read the same K/V row (LDS broadcast).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           int ntok, int D, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sK = reinterpret_cast<float*>(smem);
+    float* sV = sK + (size_t)ntok * 64;
+    const int h = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const size_t ld = (size_t)3 * D;
+    const float* base = qkv + (size_t)f * ntok * ld + h * 64;
+    for (int idx = tid; idx < ntok * 16; idx += 256) {
+        const int r = idx >> 4, c = idx & 15;
+        *reinterpret_cast<float4*>(sK + r * 64 + c * 4) = *reinterpret_cast<const float4*>(base + (size_t)r * ld + D + c * 4);
+        *reinterpret_cast<float4*>(sV + r * 64 + c * 4) =
+            *reinterpret_cast<const float4*>(base + (size_t)r * ld + 2 * D + c * 4);
+    }
+    __syncthreads();
+    for (int qrow = tid; qrow < ntok; qrow += 256) {
+        float q[64], o[64];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)qrow * ld + c * 4);
+            q[4 * c] = v.x * scale; q[4 * c + 1] = v.y * scale; q[4 * c + 2] = v.z * scale; q[4 * c + 3] = v.w * scale;
+        }
+#pragma unroll
+        for (int d = 0; d < 64; ++d) o[d] = 0.f;
+        float m = -1e30f, l = 0.f;
+        for (int key = 0; key < ntok; ++key) {
+            const float* kr = sK + key * 64;
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) sc = fmaf(q[d], kr[d], sc);
+            const float mn = fmaxf(m, sc);
+            const float a = expf(m - mn), pv = expf(sc - mn);
+            l = l * a + pv;
+            const float* vr = sV + key * 64;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) o[d] = fmaf(o[d], a, pv * vr[d]);
+            m = mn;
+        }
+        const float inv = 1.0f / l;
+        float* orow = out + ((size_t)f * ntok + qrow) * D + h * 64;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            *reinterpret_cast<float4*>(orow + 4 * c) =
+                make_float4(o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv);
+    }
+}
+
+template <int NKB>
+int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
+    constexpr int NP = NKB * 32;
+    constexpr int VT_STRIDE = ((NP * 2 + 255) / 256) * 256 + 16;
+    constexpr int LDS = NP * 128 + 64 * VT_STRIDE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<NKB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return cfsar_fail("cfsar_vit_attention: set LDS size: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const float scale_log2e = 0.125f * 1.4426950408889634f;
+    hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB>), dim3(heads, F), dim3(256), LDS, s,
+                       static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e);
+    return cfsar_check_launch("cfsar_vit_attention(bf16)");
+}
+
+}  // namespace
+
+extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads,
+                                   cfsar_stream_t stream) {
+    CFSAR_REQUIRE(qkv && out, "cfsar_vit_attention: null pointer");
+    CFSAR_REQUIRE(F > 0 && ntok > 0 && heads > 0 && D == heads * 64, "cfsar_vit_attention: need D == heads*64 (D=%d heads=%d)",
+                  D, heads);
+    CFSAR_REQUIRE(F <= 65535, "cfsar_vit_attention: too many frames per call (%d)", F);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == CFSAR_BF16) {
+        CFSAR_REQUIRE(ntok <= 288, "cfsar_vit_attention: ntok=%d > 288", ntok);
+        if (ntok <= 224) return launch_bf16<7>(qkv, out, F, ntok, D, heads, s);
+        return launch_bf16<9>(qkv, out, F, ntok, D, heads, s);
+    }
+    if (dtype == CFSAR_F32) {
+        const int lds = ntok * 64 * 4 * 2;
+        CFSAR_REQUIRE(lds <= 160 * 1024, "cfsar_vit_attention: ntok=%d too large for the fp32 kernel", ntok);
+        static int attr_lds = 0;
+        if (lds > attr_lds) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attn_f32_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return cfsar_fail("cfsar_vit_attention: set LDS size: %s", hipGetErrorString(e));
+            attr_lds = lds;
+        }
+        hipLaunchKernelGGL(vit_attn_f32_kernel, dim3(heads, F), dim3(256), lds, s, static_cast<const float*>(qkv),
+                           static_cast<float*>(out), ntok, D, 0.125f);
+        return cfsar_check_launch("cfsar_vit_attention(f32)");
+    }
+    return cfsar_fail("cfsar_vit_attention: bad dtype %d", dtype);
+}

@@ -1,0 +1,160 @@
+// Memory-bound row kernels of the ViT tower: patch gather (im2col), class-token rows, LayerNorm.
+#include "common.h"
+
+namespace {
+
+// ---- A2 stage 1: frames [F,3,H,W] f32 -> rows [(f,py,px)] x k_pad, k = c*P*P + dy*P + dx (few_shot.py:659,672-674).
+// One thread moves two horizontally adjacent pixels (8-byte aligned because P is even); consecutive threads walk k,
+// so stores are fully coalesced and loads come in P*4-byte runs.
+template <typename TO>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ frames, TO* __restrict__ out, int F,
+                                                     int H, int W, int P, int k_pad, long long total_pairs) {
+    const int gw = W / P, gh = H / P;
+    const int kp2 = k_pad >> 1;
+    const int kreal = 3 * P * P;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_pairs;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long row = idx / kp2;
+        const int k = (int)(idx - row * kp2) * 2;
+        float2 v = make_float2(0.f, 0.f);
+        if (k < kreal) {
+            const int px = (int)(row % gw);
+            const long long t = row / gw;
+            const int py = (int)(t % gh);
+            const long long f = t / gh;
+            const int c = k / (P * P);
+            const int rem = k - c * P * P;
+            const int dy = rem / P, dx = rem - dy * P;
+            const float* src = frames + ((f * 3 + c) * H + (py * P + dy)) * (long long)W + px * P + dx;
+            v = *reinterpret_cast<const float2*>(src);
+        }
+        if constexpr (sizeof(TO) == 2) {
+            bf16x2 o;
+            o[0] = (__bf16)v.x;
+            o[1] = (__bf16)v.y;
+            *reinterpret_cast<bf16x2*>(out + row * k_pad + k) = o;
+        } else {
+            *reinterpret_cast<float2*>(out + row * k_pad + k) = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, int F, int ntok, int D) {
+    const long long total = (long long)F * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long f = i / D;
+        const int d = (int)(i - f * D);
+        x[f * (long long)ntok * D + d] = cls[d] + pos[d];
+    }
+}
+
+// ---- A3 LayerNorm: one wave per row, row held in registers (<= 16 float4 per lane), two-pass statistics in fp32,
+// wavefront-shuffle reductions, vectorised 16-byte loads / 8- or 16-byte stores.
+constexpr int LN_MAXV = 16;
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long in_stride,
+                                                        TO* __restrict__ out, long long out_stride,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long long)row * in_stride;
+    const int nv = D >> 2;   // float4 count
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int j = i * 64 + lane;
+        if (j < nv) {
+            v[i] = *reinterpret_cast<const float4*>(xr + 4 * j);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int j = i * 64 + lane;
+        if (j < nv) {
+            const float a = v[i].x - mean, bq = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            ss += (a * a + bq * bq) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+    TO* orow = out + (long long)row * out_stride;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int j = i * 64 + lane;
+        if (j < nv) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + 4 * j);
+            const float4 bv = *reinterpret_cast<const float4*>(b + 4 * j);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * wv.x + bv.x;
+            o.y = (v[i].y - mean) * rstd * wv.y + bv.y;
+            o.z = (v[i].z - mean) * rstd * wv.z + bv.z;
+            o.w = (v[i].w - mean) * rstd * wv.w + bv.w;
+            if constexpr (sizeof(TO) == 2) {
+                bf16x4 ob;
+                ob[0] = (__bf16)o.x; ob[1] = (__bf16)o.y; ob[2] = (__bf16)o.z; ob[3] = (__bf16)o.w;
+                *reinterpret_cast<bf16x4*>(orow + 4 * j) = ob;
+            } else {
+                *reinterpret_cast<float4*>(orow + 4 * j) = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cfsar_im2col_patches(const float* frames, void* out, int out_dtype, int F, int H, int W, int P,
+                                    int k_pad, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(frames && out, "cfsar_im2col_patches: null pointer");
+    CFSAR_REQUIRE(F > 0 && P > 0 && P % 2 == 0 && H % P == 0 && W % P == 0, "cfsar_im2col_patches: bad geometry");
+    CFSAR_REQUIRE(k_pad >= 3 * P * P && k_pad % 2 == 0, "cfsar_im2col_patches: k_pad too small / odd");
+    const long long rows = (long long)F * (H / P) * (W / P);
+    const long long pairs = rows * (k_pad / 2);
+    long long blocks = (pairs + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dtype == CFSAR_BF16)
+        hipLaunchKernelGGL((im2col_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, s, frames,
+                           static_cast<__bf16*>(out), F, H, W, P, k_pad, pairs);
+    else if (out_dtype == CFSAR_F32)
+        hipLaunchKernelGGL((im2col_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, frames,
+                           static_cast<float*>(out), F, H, W, P, k_pad, pairs);
+    else
+        return cfsar_fail("cfsar_im2col_patches: bad dtype %d", out_dtype);
+    return cfsar_check_launch("cfsar_im2col_patches");
+}
+
+extern "C" int cfsar_cls_rows(float* x, const float* cls, const float* pos, int F, int ntok, int D,
+                              cfsar_stream_t stream) {
+    CFSAR_REQUIRE(x && cls && pos && F > 0 && ntok > 0 && D > 0, "cfsar_cls_rows: bad arguments");
+    const long long total = (long long)F * D;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, cls, pos, F,
+                       ntok, D);
+    return cfsar_check_launch("cfsar_cls_rows");
+}
+
+extern "C" int cfsar_layernorm(const float* x, int64_t in_stride, void* out, int64_t out_stride, int out_dtype,
+                               const float* weight, const float* bias, int rows, int D, float eps,
+                               cfsar_stream_t stream) {
+    CFSAR_REQUIRE(x && out && weight && bias, "cfsar_layernorm: null pointer");
+    CFSAR_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4 * 64 * LN_MAXV, "cfsar_layernorm: bad D=%d", D);
+    CFSAR_REQUIRE(in_stride % 4 == 0 && out_stride % 4 == 0, "cfsar_layernorm: strides must be multiples of 4");
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dtype == CFSAR_BF16)
+        hipLaunchKernelGGL((layernorm_kernel<__bf16>), dim3(blocks), dim3(256), 0, s, x, (long long)in_stride,
+                           static_cast<__bf16*>(out), (long long)out_stride, weight, bias, rows, D, eps);
+    else if (out_dtype == CFSAR_F32)
+        hipLaunchKernelGGL((layernorm_kernel<float>), dim3(blocks), dim3(256), 0, s, x, (long long)in_stride,
+                           static_cast<float*>(out), (long long)out_stride, weight, bias, rows, D, eps);
+    else
+        return cfsar_fail("cfsar_layernorm: bad dtype %d", out_dtype);
+    return cfsar_check_launch("cfsar_layernorm");
+}

@@ -1,0 +1,355 @@
+// The few-shot tail of CNN_OTAM_CLIPFSAR.forward (eval default branch, few_shot.py:2932-2990), fp32 throughout:
+// aux class logits, sequence building (text-token concat, optional class merge), short-sequence attention of the
+// temporal transformer, prototypes, and cosine + OTAM -> logits.  All kernels take a batch of episodes.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_S = 128;   // max support videos per episode handled by the label-rank helper
+
+// rank[s] = number of distinct label values smaller than labels[s]  (torch.unique sorts ascending: few_shot.py:2950)
+// returns number of distinct labels.  Executed by one thread; S is tiny (way*shot).
+__device__ int label_ranks(const float* labels, int S, int* rank) {
+    int distinct = 0;
+    for (int s = 0; s < S; ++s) {
+        int r = 0;
+        bool first = true;
+        for (int t = 0; t < S; ++t) {
+            if (labels[t] < labels[s]) {
+                bool seen = false;
+                for (int u = 0; u < t; ++u)
+                    if (labels[u] == labels[t]) { seen = true; break; }
+                if (!seen) ++r;
+            }
+            if (t < s && labels[t] == labels[s]) first = false;
+        }
+        rank[s] = r;
+        if (first) ++distinct;
+    }
+    return distinct;
+}
+
+// ---- A15b  cos_sim(mean_T(feats[v]), text) * scale    (few_shot.py:2937-2939; cos_sim :1115-1124)
+__global__ __launch_bounds__(256) void class_text_logits_kernel(const float* __restrict__ feats,
+                                                                const float* __restrict__ text,
+                                                                const float* __restrict__ scale,
+                                                                float* __restrict__ out, int T, int E, int n_cls) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* mean = reinterpret_cast<float*>(smem);       // [E]
+    __shared__ float red[4];
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* fv = feats + (size_t)v * T * E;
+    float ss = 0.f;
+    for (int e = tid; e < E; e += 256) {
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += fv[(size_t)t * E + e];
+        a = a / (float)T;
+        mean[e] = a;
+        ss += a * a;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float xnorm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float sc = scale[0];
+    for (int c = wave; c < n_cls; c += 4) {
+        const float* tr = text + (size_t)c * E;
+        float dot = 0.f, yy = 0.f;
+        for (int e = lane; e < E; e += 64) {
+            const float y = tr[e];
+            dot = fmaf(mean[e], y, dot);
+            yy = fmaf(y, y, yy);
+        }
+        dot = wave_sum(dot);
+        yy = wave_sum(yy);
+        if (lane == 0) out[(size_t)v * n_cls + c] = dot / (xnorm * sqrtf(yy) + 0.01f) * sc;
+    }
+}
+
+// ---- A10/A12  sequence building (few_shot.py:2946-2955).  One workgroup per output token row.
+__global__ __launch_bounds__(128) void build_sequences_kernel(const float* __restrict__ feats,
+                                                              const float* __restrict__ text_test,
+                                                              const float* __restrict__ support_labels,
+                                                              const float* __restrict__ real_labels,
+                                                              float* __restrict__ X, int B, int S, int Q, int T, int E,
+                                                              int way, int n_test, int merge_before) {
+    __shared__ int rank[MAX_S];
+    const int Sp = merge_before ? way : S;
+    const int q_rows = B * Q * T;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    float* xr = X + (size_t)row * E;
+    if (row < q_rows) {                                   // query token (b, q, t)
+        const int t = row % T, bq = row / T;
+        const int q = bq % Q, b = bq / Q;
+        const float* src = feats + (((size_t)b * (S + Q) + S + q) * T + t) * E;
+        for (int e = tid; e < E; e += 128) xr[e] = src[e];
+        return;
+    }
+    const int r2 = row - q_rows;
+    const int tt = r2 % (T + 1), bs = r2 / (T + 1);
+    const int sp = bs % Sp, b = bs / Sp;
+    const float* lab = support_labels + (size_t)b * S;
+    const float* rl = real_labels + (size_t)b * S;
+    if (!merge_before) {
+        const float* src;
+        if (tt < T) {
+            src = feats + (((size_t)b * (S + Q) + sp) * T + tt) * E;
+        } else {
+            int cls = (int)rl[sp];                         // .long() truncation (few_shot.py:2946)
+            cls = cls < 0 ? 0 : (cls >= n_test ? n_test - 1 : cls);
+            src = text_test + (size_t)cls * E;
+        }
+        for (int e = tid; e < E; e += 128) xr[e] = src[e];
+        return;
+    }
+    if (tid == 0) label_ranks(lab, S, rank);
+    __syncthreads();
+    int cnt = 0;
+    for (int s = 0; s < S; ++s) cnt += (rank[s] == sp);
+    const float inv = 1.0f / (float)cnt;
+    for (int e = tid; e < E; e += 128) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) {
+            if (rank[s] != sp) continue;
+            if (tt < T) {
+                a += feats[(((size_t)b * (S + Q) + s) * T + tt) * E + e];
+            } else {
+                int cls = (int)rl[s];
+                cls = cls < 0 ? 0 : (cls >= n_test ? n_test - 1 : cls);
+                a += text_test[(size_t)cls * E + e];
+            }
+        }
+        xr[e] = a * inv;
+    }
+}
+
+// ---- A11 attention on short sequences (few_shot.py:1056-1073).  One wave per (sequence, head).
+__global__ __launch_bounds__(64) void seq_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           int n_a, int len_a, int n_b, int len_b, int heads, int hd,
+                                                           float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int seq = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    int start, L;
+    if (seq < n_a) { start = seq * len_a; L = len_a; }
+    else { start = n_a * len_a + (seq - n_a) * len_b; L = len_b; }
+    const int inner = heads * hd;
+    const size_t ld = (size_t)3 * inner;
+    float* sq = reinterpret_cast<float*>(smem);      // [L][hd]
+    float* sk = sq + L * hd;
+    float* sv = sk + L * hd;
+    float* sp = sv + L * hd;                         // [L][L] probabilities
+    for (int idx = lane; idx < L * hd; idx += 64) {
+        const int i = idx / hd, d = idx - i * hd;
+        const float* rowp = qkv + (size_t)(start + i) * ld + h * hd + d;
+        sq[idx] = rowp[0];
+        sk[idx] = rowp[inner];
+        sv[idx] = rowp[2 * inner];
+    }
+    __syncthreads();
+    if (lane < L) {                                   // lane = query position i
+        float mx = -1e30f;
+        for (int j = 0; j < L; ++j) {
+            float dot = 0.f;
+            for (int d = 0; d < hd; ++d) dot = fmaf(sq[lane * hd + d], sk[j * hd + d], dot);
+            dot *= scale;
+            sp[lane * L + j] = dot;
+            mx = fmaxf(mx, dot);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < L; ++j) {
+            const float e = expf(sp[lane * L + j] - mx);
+            sp[lane * L + j] = e;
+            sum += e;
+        }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < L; ++j) sp[lane * L + j] *= inv;
+    }
+    __syncthreads();
+    for (int idx = lane; idx < L * hd; idx += 64) {
+        const int i = idx / hd, d = idx - i * hd;
+        float a = 0.f;
+        for (int j = 0; j < L; ++j) a = fmaf(sp[i * L + j], sv[j * hd + d], a);
+        out[(size_t)(start + i) * inner + h * hd + d] = a;
+    }
+}
+
+// ---- A12 prototypes (few_shot.py:2956-2962).  One workgroup per (b, class, t).
+__global__ __launch_bounds__(128) void prototypes_kernel(const float* __restrict__ Xs,
+                                                         const float* __restrict__ support_labels,
+                                                         float* __restrict__ protos, int S, int Sp, int T, int E, int way,
+                                                         int merge_before) {
+    __shared__ int rank[MAX_S];
+    const int t = blockIdx.x % T, bc = blockIdx.x / T;
+    const int c = bc % way, b = bc / way, tid = threadIdx.x;
+    float* pr = protos + (((size_t)b * way + c) * T + t) * E;
+    if (merge_before) {
+        const float* src = Xs + (((size_t)b * Sp + c) * (T + 1) + t) * E;
+        for (int e = tid; e < E; e += 128) pr[e] = src[e];
+        return;
+    }
+    if (tid == 0) label_ranks(support_labels + (size_t)b * S, S, rank);
+    __syncthreads();
+    int cnt = 0;
+    for (int s = 0; s < S; ++s) cnt += (rank[s] == c);
+    const float inv = 1.0f / (float)cnt;
+    for (int e = tid; e < E; e += 128) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s)
+            if (rank[s] == c) a += Xs[(((size_t)b * Sp + s) * (T + 1) + t) * E + e];
+        pr[e] = a * inv;
+    }
+}
+
+// ---- A13/A14/A15 cos_sim + OTAM both directions -> logits.  One workgroup per (b, q).
+//   LDS: query rows [T][E], sim [way][T][T].  Each wave computes dot products (wave-shuffle reduction over E),
+//   then 2*way threads run the sequential soft-min DP (few_shot.py:2657-2687), un-stabilised like the reference.
+constexpr int MAX_T = 32;
+__device__ float otam_dp(const float* d /*[T][T] row-major, row stride rs, col stride cs*/, int rs, int cs, int T,
+                         float lbda) {
+    // padded width M = T+2; columns 0 and T+1 are zero padding (few_shot.py:2663)
+    float prev[MAX_T + 2], cur[MAX_T + 2];
+    const float il = 1.0f / lbda;
+    prev[0] = 0.f;
+    for (int m = 1; m <= T + 1; ++m) {                      // first row: running sum (:2668-2671)
+        const float dv = (m <= T) ? d[0 * rs + (m - 1) * cs] : 0.f;
+        prev[m] = dv + prev[m - 1];
+    }
+    for (int l = 1; l < T; ++l) {
+        cur[0] = 0.f;
+        {   // first non-zero column (:2675)
+            const float dv = d[l * rs + 0 * cs];
+            cur[1] = dv - lbda * logf(expf(-prev[0] * il) + expf(-prev[1] * il) + expf(-cur[0] * il));
+        }
+        for (int m = 2; m <= T; ++m) {                      // middle columns (:2678-2679)
+            const float dv = d[l * rs + (m - 1) * cs];
+            cur[m] = dv - lbda * logf(expf(-prev[m - 1] * il) + expf(-cur[m - 1] * il));
+        }
+        // last (padding) column (:2683)
+        cur[T + 1] = 0.f - lbda * logf(expf(-prev[T] * il) + expf(-prev[T + 1] * il) + expf(-cur[T] * il));
+        for (int m = 0; m <= T + 1; ++m) prev[m] = cur[m];
+    }
+    return prev[T + 1];
+}
+
+__global__ __launch_bounds__(256) void cos_otam_kernel(const float* __restrict__ Xq, const float* __restrict__ protos,
+                                                       float* __restrict__ logits, float* __restrict__ dists_out, int Q,
+                                                       int way, int T, int E, float lbda, int single_direct) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sq = reinterpret_cast<float*>(smem);            // [T][E]
+    float* qn = sq + (size_t)T * E;                          // [T] query norms
+    float* sd = qn + T;                                      // [way][T][T] distances (1 - sim)
+    const int bq = blockIdx.x, b = bq / Q;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xq = Xq + (size_t)bq * T * E;
+    for (int i = tid; i < T * E; i += 256) sq[i] = xq[i];
+    __syncthreads();
+    for (int t = wave; t < T; t += 4) {
+        float ss = 0.f;
+        for (int e = lane; e < E; e += 64) ss = fmaf(sq[t * E + e], sq[t * E + e], ss);
+        ss = wave_sum(ss);
+        if (lane == 0) qn[t] = sqrtf(ss);
+    }
+    __syncthreads();
+    // one wave per support frame (c, j): its norm once, then dot with every query frame
+    const float* pb = protos + (size_t)b * way * T * E;
+    for (int cj = wave; cj < way * T; cj += 4) {
+        const float* pr = pb + (size_t)cj * E;
+        float yy = 0.f;
+        for (int e = lane; e < E; e += 64) yy = fmaf(pr[e], pr[e], yy);
+        const float yn = sqrtf(wave_sum(yy));
+        const int c = cj / T, j = cj - c * T;
+        for (int i = 0; i < T; ++i) {
+            float dot = 0.f;
+            for (int e = lane; e < E; e += 64) dot = fmaf(sq[i * E + e], pr[e], dot);
+            dot = wave_sum(dot);
+            if (lane == 0) sd[(c * T + i) * T + j] = 1.0f - dot / (qn[i] * yn + 0.01f);
+        }
+    }
+    __syncthreads();
+    if (dists_out)
+        for (int i = tid; i < way * T * T; i += 256) dists_out[(size_t)bq * way * T * T + i] = sd[i];
+    // DP: thread (c, dir)
+    __shared__ float res[2 * 64];
+    if (tid < 2 * way) {
+        const int c = tid >> 1, dir = tid & 1;
+        float v = 0.f;
+        if (dir == 0) v = otam_dp(sd + c * T * T, T, 1, T, lbda);
+        else if (!single_direct) v = otam_dp(sd + c * T * T, 1, T, T, lbda);     // transposed distances (:2982)
+        res[tid] = v;
+    }
+    __syncthreads();
+    if (tid < way) logits[(size_t)bq * way + tid] = -(res[2 * tid] + res[2 * tid + 1]);
+}
+
+}  // namespace
+
+extern "C" int cfsar_class_text_logits(const float* feats, const float* text, const float* scale, float* out,
+                                       int n_videos, int T, int E, int n_cls, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(feats && text && scale && out, "cfsar_class_text_logits: null pointer");
+    CFSAR_REQUIRE(n_videos > 0 && T > 0 && E > 0 && n_cls > 0 && E * 4 <= 60000, "cfsar_class_text_logits: bad shape");
+    hipLaunchKernelGGL(class_text_logits_kernel, dim3(n_videos), dim3(256), E * sizeof(float),
+                       static_cast<hipStream_t>(stream), feats, text, scale, out, T, E, n_cls);
+    return cfsar_check_launch("cfsar_class_text_logits");
+}
+
+extern "C" int cfsar_build_sequences(const float* feats, const float* text_test, const float* support_labels,
+                                     const float* real_support_labels, float* X, int B, int S, int Q, int T, int E,
+                                     int way, int n_test, int merge_before, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(feats && text_test && support_labels && real_support_labels && X, "cfsar_build_sequences: null pointer");
+    CFSAR_REQUIRE(B > 0 && S > 0 && Q > 0 && T > 0 && E > 0 && way > 0 && n_test > 0, "cfsar_build_sequences: bad shape");
+    CFSAR_REQUIRE(S <= MAX_S, "cfsar_build_sequences: S=%d > %d", S, MAX_S);
+    CFSAR_REQUIRE(S % way == 0, "cfsar_build_sequences: S=%d is not a multiple of way=%d", S, way);
+    const int Sp = merge_before ? way : S;
+    const long long rows = (long long)B * Q * T + (long long)B * Sp * (T + 1);
+    hipLaunchKernelGGL(build_sequences_kernel, dim3((unsigned)rows), dim3(128), 0, static_cast<hipStream_t>(stream),
+                       feats, text_test, support_labels, real_support_labels, X, B, S, Q, T, E, way, n_test,
+                       merge_before);
+    return cfsar_check_launch("cfsar_build_sequences");
+}
+
+extern "C" int cfsar_seq_attention(const float* qkv, float* out, int n_a, int len_a, int n_b, int len_b, int heads,
+                                   int head_dim, float scale, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(qkv && out, "cfsar_seq_attention: null pointer");
+    CFSAR_REQUIRE(n_a >= 0 && n_b >= 0 && n_a + n_b > 0 && heads > 0 && head_dim > 0, "cfsar_seq_attention: bad shape");
+    const int L = len_a > len_b ? len_a : len_b;
+    CFSAR_REQUIRE(L <= 64 && head_dim <= 128, "cfsar_seq_attention: len=%d (max 64) head_dim=%d (max 128)", L, head_dim);
+    const int lds = (3 * L * head_dim + L * L) * (int)sizeof(float);
+    static int attr_lds = 48 * 1024;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&seq_attention_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return cfsar_fail("cfsar_seq_attention: set LDS size: %s", hipGetErrorString(e));
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(seq_attention_kernel, dim3(n_a + n_b, heads), dim3(64), lds, static_cast<hipStream_t>(stream), qkv,
+                       out, n_a, len_a, n_b, len_b, heads, head_dim, scale);
+    return cfsar_check_launch("cfsar_seq_attention");
+}
+
+extern "C" int cfsar_prototypes(const float* Xs, const float* support_labels, float* protos, int B, int S, int Sp, int T,
+                                int E, int way, int merge_before, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(Xs && support_labels && protos, "cfsar_prototypes: null pointer");
+    CFSAR_REQUIRE(B > 0 && S > 0 && S <= MAX_S && T > 0 && E > 0 && way > 0, "cfsar_prototypes: bad shape");
+    CFSAR_REQUIRE(Sp == (merge_before ? way : S), "cfsar_prototypes: Sp=%d inconsistent with merge_before", Sp);
+    hipLaunchKernelGGL(prototypes_kernel, dim3((unsigned)(B * way * T)), dim3(128), 0, static_cast<hipStream_t>(stream), Xs,
+                       support_labels, protos, S, Sp, T, E, way, merge_before);
+    return cfsar_check_launch("cfsar_prototypes");
+}
+
+extern "C" int cfsar_cos_otam_logits(const float* Xq, const float* protos, float* logits, float* dists_out, int B, int Q,
+                                     int way, int T, int E, float lambda, int single_direct, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(Xq && protos && logits, "cfsar_cos_otam_logits: null pointer");
+    CFSAR_REQUIRE(B > 0 && Q > 0 && way > 0 && way <= 64 && T > 0 && T <= MAX_T && E > 0, "cfsar_cos_otam_logits: bad shape");
+    const int lds = (T * E + T + way * T * T) * (int)sizeof(float);
+    CFSAR_REQUIRE(lds <= 150 * 1024, "cfsar_cos_otam_logits: T*E too large for LDS");
+    static int attr_lds = 48 * 1024;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_otam_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return cfsar_fail("cfsar_cos_otam_logits: set LDS size: %s", hipGetErrorString(e));
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(cos_otam_kernel, dim3((unsigned)(B * Q)), dim3(256), lds, static_cast<hipStream_t>(stream), Xq,
+                       protos, logits, dists_out, Q, way, T, E, lambda, single_direct);
+    return cfsar_check_launch("cfsar_cos_otam_logits");
+}

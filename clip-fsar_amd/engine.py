@@ -1,0 +1,255 @@
+"""Host-side orchestration of the HIP kernels: the CLIP ViT image tower (A1-A8) and the few-shot tail (A9-A15).
+
+PyTorch is used only for device memory and the stream; every arithmetic step is a call into
+libclipfsar_hip.so (clip_fsar_amd.hip).  Two numeric modes:
+
+  * ``precision="bf16"``  -- throughput mode: bf16 MFMA GEMMs / attention with fp32 accumulation, fp32 residual
+    stream, fp32 LayerNorm / softmax statistics; the tail (features -> logits) is always fp32;
+  * ``precision="fp32"``  -- validation mode: fp32-input MFMA GEMMs (exact fp32 FMA chains) and an fp32 VALU
+    attention kernel; meets the 1e-3 logits tolerance against the reference's fp32 PyTorch path.
+
+Layout in HBM (row-major): tokens x [F*N, D] fp32 (frame-major, token-minor; token 0 = class token),
+packed qkv [F*N, 3D], MLP hidden [F*N, 4D] in the compute dtype; features [B, S+Q, T, E] fp32.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import hip
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class HipViT:
+    """CLIP VisionTransformer.forward (reference few_shot.py:671-688) on the HIP kernels."""
+
+    def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda"):
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.arch = dict(arch)
+        self.precision = precision
+        self.dev = torch.device(device)
+        self.cd = torch.bfloat16 if precision == "bf16" else torch.float32
+        D, P = arch["width"], arch["patch"]
+        if D != arch["heads"] * 64:
+            raise ValueError("HipViT needs head_dim == 64 (width %d, heads %d)" % (D, arch["heads"]))
+        self.D, self.P, self.L, self.H, self.E = D, P, arch["layers"], arch["heads"], arch["embed"]
+        self.grid = arch["res"] // P
+        self.ntok = self.grid * self.grid + 1
+        kq = 64 if precision == "bf16" else 32
+        self.kpad = _round_up(3 * P * P, kq)
+
+        def g(name):
+            t = sd[prefix + name]
+            if not isinstance(t, torch.Tensor):
+                t = torch.from_numpy(t)
+            return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+
+        cd = self.cd
+        wc = torch.zeros(D, self.kpad, device=self.dev, dtype=torch.float32)
+        wc[:, :3 * P * P] = g("conv1.weight").reshape(D, -1)
+        self.w_patch = wc.to(cd).contiguous()
+        self.cls = g("class_embedding")
+        self.pos = g("positional_embedding")
+        self.ln_pre = (g("ln_pre.weight"), g("ln_pre.bias"))
+        self.ln_post = (g("ln_post.weight"), g("ln_post.bias"))
+        self.w_proj_t = g("proj").t().contiguous()          # [E, D] fp32: final projection always in fp32
+        self.blocks = []
+        for i in range(self.L):
+            b = "transformer.resblocks.%d." % i
+            self.blocks.append(dict(
+                ln1=(g(b + "ln_1.weight"), g(b + "ln_1.bias")),
+                ln2=(g(b + "ln_2.weight"), g(b + "ln_2.bias")),
+                w_qkv=g(b + "attn.in_proj_weight").to(cd).contiguous(), b_qkv=g(b + "attn.in_proj_bias"),
+                w_out=g(b + "attn.out_proj.weight").to(cd).contiguous(), b_out=g(b + "attn.out_proj.bias"),
+                w_fc=g(b + "mlp.c_fc.weight").to(cd).contiguous(), b_fc=g(b + "mlp.c_fc.bias"),
+                w_pr=g(b + "mlp.c_proj.weight").to(cd).contiguous(), b_pr=g(b + "mlp.c_proj.bias")))
+        self._cap = 0
+        self._ws = None
+
+    # ------------------------------------------------------------------ workspace (caller-owned device buffers)
+    def _workspace(self, F_):
+        if F_ > self._cap:
+            M, D, cd, dev = F_ * self.ntok, self.D, self.cd, self.dev
+            self._ws = dict(
+                patches=torch.empty(F_ * (self.ntok - 1), self.kpad, device=dev, dtype=cd),
+                x=torch.empty(M, D, device=dev, dtype=torch.float32),
+                h=torch.empty(M, D, device=dev, dtype=cd),
+                qkv=torch.empty(M, 3 * D, device=dev, dtype=cd),
+                o=torch.empty(M, D, device=dev, dtype=cd),
+                u=torch.empty(M, 4 * D, device=dev, dtype=cd),
+                c=torch.empty(F_, D, device=dev, dtype=torch.float32))
+            self._cap = F_
+        return self._ws
+
+    def forward(self, frame_sets, feats_out=None, row_maps=None, taps=None):
+        """frame_sets: tensor [F,3,H,W] or list of such tensors (processed as one concatenated batch).
+        feats_out: optional fp32 [*, E] buffer; row_maps: per set (row_group, row_gap, row_off) mapping the set's
+        frame index m to the output feature row  m + (m // row_group) * row_gap + row_off.
+        Returns feats_out (fp32)."""
+        if isinstance(frame_sets, torch.Tensor):
+            frame_sets = [frame_sets]
+        counts = [int(f.shape[0]) for f in frame_sets]
+        F_ = sum(counts)
+        if row_maps is None:
+            row_maps, off = [], 0
+            for c in counts:
+                row_maps.append((0, 0, off))
+                off += c
+        if feats_out is None:
+            feats_out = torch.empty(F_, self.E, device=self.dev, dtype=torch.float32)
+        ws = self._workspace(F_)
+        N, D, npatch = self.ntok, self.D, self.ntok - 1
+        M = F_ * N
+        x, h, qkv, o, u = ws["x"], ws["h"], ws["qkv"], ws["o"], ws["u"]
+        # A2: patch gather -> GEMM with the epilogue scattering rows behind each class token and adding pos[1+p]
+        off = 0
+        for fr, c in zip(frame_sets, counts):
+            if fr.shape[1:] != (3, self.arch["res"], self.arch["res"]):
+                raise RuntimeError("frames must be [F,3,%d,%d], got %s" % (self.arch["res"], self.arch["res"], tuple(fr.shape)))
+            hip.im2col_patches(fr, ws["patches"][off * npatch:(off + c) * npatch], self.P)
+            off += c
+        hip.gemm(ws["patches"], self.w_patch, x, residual=self.pos, M=F_ * npatch, N=D, K=self.kpad, ldo=D, ldr=D,
+                 row_group=npatch, row_gap=1, row_off=1, res_mod=npatch, res_off=1)
+        hip.cls_rows(x, self.cls, self.pos, F_, N, D)
+        hip.layernorm(x, x, self.ln_pre[0], self.ln_pre[1], M, D)                     # ln_pre (:677), in place
+        if taps is not None:
+            taps["ln_pre"] = x[:M].clone()
+        for i, b in enumerate(self.blocks):                                           # :679-681
+            hip.layernorm(x, h, b["ln1"][0], b["ln1"][1], M, D)
+            hip.gemm(h, b["w_qkv"], qkv, bias=b["b_qkv"], M=M)
+            hip.vit_attention(qkv, o, F_, N, D, self.H)
+            hip.gemm(o, b["w_out"], x, bias=b["b_out"], residual=x, M=M)              # x += out_proj(attn)
+            hip.layernorm(x, h, b["ln2"][0], b["ln2"][1], M, D)
+            hip.gemm(h, b["w_fc"], u, bias=b["b_fc"], act=hip.ACT_QUICKGELU, M=M)
+            hip.gemm(u, b["w_pr"], x, bias=b["b_pr"], residual=x, M=M)                # x += c_proj(gelu(c_fc))
+            if taps is not None:
+                taps["block%d" % i] = x[:M].clone()
+        # A8: ln_post on the class-token rows (stride N*D) then @ proj, fp32
+        hip.layernorm(x, ws["c"], self.ln_post[0], self.ln_post[1], F_, D, in_stride=N * D, out_stride=D)
+        off = 0
+        for c, (rg, gap, roff) in zip(counts, row_maps):
+            hip.gemm(ws["c"][off:off + c], self.w_proj_t, feats_out, M=c, N=self.E, K=D, ldo=self.E,
+                     row_group=rg, row_gap=gap, row_off=roff)
+            off += c
+        return feats_out
+
+
+class HipTemporalHead:
+    """context2 (Transformer_v1) + prototypes + cosine/OTAM -> logits, fp32 (few_shot.py:2937-2990)."""
+
+    def __init__(self, sd: dict, dim: int, depth: int = 1, heads: int = 8, prefix: str = "context2.", device="cuda"):
+        self.dev = torch.device(device)
+        self.dim, self.depth, self.heads = dim, depth, heads
+
+        def g(name):
+            t = sd[prefix + name]
+            if not isinstance(t, torch.Tensor):
+                t = torch.from_numpy(t)
+            return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+
+        self.layers = []
+        for d in range(depth):
+            p = "layers.%d." % d
+            wq, wk, wv = g(p + "0.fn.to_q.weight"), g(p + "0.fn.to_k.weight"), g(p + "0.fn.to_v.weight")
+            inner = wq.shape[0]
+            self.layers.append(dict(
+                norm=(g(p + "0.norm.weight"), g(p + "0.norm.bias")),
+                w_qkv=torch.cat([wq, wk, wv], 0).contiguous(), inner=inner,
+                w_out=g(p + "0.fn.to_out.0.weight"), b_out=g(p + "0.fn.to_out.0.bias"),
+                w1=g(p + "1.net.0.weight"), b1=g(p + "1.net.0.bias"),
+                w2=g(p + "1.net.3.weight"), b2=g(p + "1.net.3.bias")))
+        self._ws_rows = 0
+        self._ws = None
+
+    def _workspace(self, rows):
+        if rows > self._ws_rows:
+            E, dev = self.dim, self.dev
+            inner = max(l["inner"] for l in self.layers)
+            hidden = max(l["w1"].shape[0] for l in self.layers)
+            f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+            self._ws = dict(X=f(rows, E), n=f(rows, E), qkv=f(rows, 3 * inner), o=f(rows, inner), y=f(rows, E),
+                            u=f(rows, hidden), z=f(rows, E))
+            self._ws_rows = rows
+        return self._ws
+
+    def forward(self, feats, text_test, support_labels, real_support_labels, B, S, Q, T, way, merge_before=False,
+                single_direct=False, taps=None):
+        """feats [B, S+Q, T, E] fp32 -> logits [B, Q, way] fp32."""
+        E = self.dim
+        Sp = way if merge_before else S
+        rows_q, rows_s = B * Q * T, B * Sp * (T + 1)
+        rows = rows_q + rows_s
+        ws = self._workspace(rows)
+        X = ws["X"]
+        hip.build_sequences(feats, text_test, support_labels, real_support_labels, X, B, S, Q, T, E, way, merge_before)
+        cur, nxt = X, ws["z"]
+        for l in self.layers:                                                            # few_shot.py:990-999
+            inner = l["inner"]
+            hd = inner // self.heads
+            hip.layernorm(cur, ws["n"], l["norm"][0], l["norm"][1], rows, E)              # shared LN for q,k,v (:971-977)
+            hip.gemm(ws["n"], l["w_qkv"], ws["qkv"], M=rows)                              # to_q|to_k|to_v, no bias
+            hip.seq_attention(ws["qkv"], ws["o"], B * Q, T, B * Sp, T + 1, self.heads, hd, hd ** -0.5)
+            hip.gemm(ws["o"], l["w_out"], ws["y"], bias=l["b_out"], residual=cur, M=rows)   # to_out + q residual
+            hip.gemm(ws["y"], l["w1"], ws["u"], bias=l["b1"], act=hip.ACT_GELU_ERF, M=rows)
+            hip.gemm(ws["u"], l["w2"], nxt, bias=l["b2"], residual=ws["y"], M=rows)         # ff(x) + x
+            cur, nxt = nxt, cur
+        protos = torch.empty(B, way, T, E, device=self.dev, dtype=torch.float32)
+        hip.prototypes(cur[rows_q:], support_labels, protos, B, S, Sp, T, E, way, merge_before)
+        logits = torch.empty(B, Q, way, device=self.dev, dtype=torch.float32)
+        dists = torch.empty(B, Q, way, T, T, device=self.dev, dtype=torch.float32) if taps is not None else None
+        hip.cos_otam_logits(cur[:rows_q], protos, logits, B, Q, way, T, E, 0.5, single_direct, dists_out=dists)
+        if taps is not None:
+            taps.update(ctx_q=cur[:rows_q].clone().reshape(B, Q, T, E), protos=protos, dists=dists)
+        return logits
+
+
+class ClipFsarEngine:
+    """Full episodic forward A0 -> A15 for a batch of B episodes with identical (way, shot, query, T)."""
+
+    def __init__(self, arch: dict, head_sd: dict, text_train, text_test, depth: int = 1, precision: str = "bf16",
+                 device="cuda", max_frames: int = 1280):
+        self.dev = torch.device(device)
+        self.arch = dict(arch)
+        self.vit = HipViT(arch, head_sd, prefix="backbone.", precision=precision, device=device)
+        self.temporal = HipTemporalHead(head_sd, arch["embed"], depth=depth, device=device)
+        f32 = lambda t: (t if isinstance(t, torch.Tensor) else torch.from_numpy(t)).detach().to(
+            device=self.dev, dtype=torch.float32).contiguous()
+        self.text_train, self.text_test = f32(text_train), f32(text_test)
+        self.scale = f32(head_sd["scale"])
+        self.max_frames = max_frames
+
+    def forward(self, support_set, target_set, support_labels, real_support_labels, way, T, merge_before=False,
+                single_direct=False, taps=None):
+        """support_set [B, S*T, 3, H, W], target_set [B, Q*T, 3, H, W] fp32 device tensors (B may be folded in:
+        4-D inputs mean B = 1); labels [B, S] fp32.  Returns (logits [B,Q,way], class_logits [B,S+Q,n_train])."""
+        if support_set.dim() == 4:
+            support_set, target_set = support_set.unsqueeze(0), target_set.unsqueeze(0)
+            support_labels, real_support_labels = support_labels.reshape(1, -1), real_support_labels.reshape(1, -1)
+        B = support_set.shape[0]
+        S, Q = support_set.shape[1] // T, target_set.shape[1] // T
+        E = self.arch["embed"]
+        per_ep = (S + Q) * T
+        feats = torch.empty(B, S + Q, T, E, device=self.dev, dtype=torch.float32)
+        chunk = max(1, self.max_frames // per_ep)
+        feats2d = feats.reshape(B * per_ep, E)
+        for b0 in range(0, B, chunk):
+            b1 = min(B, b0 + chunk)
+            sup = support_set[b0:b1].reshape(-1, *support_set.shape[2:])
+            tgt = target_set[b0:b1].reshape(-1, *target_set.shape[2:])
+            self.vit.forward([sup, tgt], feats2d,
+                             row_maps=[(S * T, Q * T, b0 * per_ep), (Q * T, S * T, b0 * per_ep + S * T)],
+                             taps=taps if b0 == 0 else None)
+        class_logits = torch.empty(B, S + Q, self.text_train.shape[0], device=self.dev, dtype=torch.float32)
+        hip.class_text_logits(feats, self.text_train, self.scale, class_logits, B * (S + Q), T, E)
+        sl = support_labels.to(device=self.dev, dtype=torch.float32).contiguous()
+        rl = real_support_labels.to(device=self.dev, dtype=torch.float32).contiguous()
+        logits = self.temporal.forward(feats, self.text_test, sl, rl, B, S, Q, T, way, merge_before, single_direct,
+                                       taps=taps)
+        if taps is not None:
+            taps["feats"] = feats
+        return logits, class_logits

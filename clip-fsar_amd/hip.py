@@ -1,0 +1,165 @@
+"""ctypes binding of libclipfsar_hip.so (C ABI declared in include/clipfsar_hip.h).
+
+There is NO fallback: if the shared library is missing, or a tensor is not a contiguous HIP device tensor of the
+expected dtype, these wrappers raise.  PyTorch only provides device memory (``tensor.data_ptr()``) and the stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (imported first so that torch's libamdhip64.so.7 is the HIP runtime the library binds to)
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclipfsar_hip.so")
+_lib = None
+
+_c_int, _c_p, _c_f, _c_i64 = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_int64
+
+# symbol -> argtypes; must match include/clipfsar_hip.h (tests/test_abi.py cross-checks against the header text)
+SIGNATURES = {
+    "cfsar_version": [],
+    "cfsar_im2col_patches": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_cls_rows": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_layernorm": [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p],
+    "cfsar_gemm": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 15 + [_c_p],
+    "cfsar_vit_attention": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_class_text_logits": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_build_sequences": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p],
+    "cfsar_seq_attention": [_c_p, _c_p] + [_c_int] * 6 + [_c_f, _c_p],
+    "cfsar_prototypes": [_c_p, _c_p, _c_p] + [_c_int] * 7 + [_c_p],
+    "cfsar_cos_otam_logits": [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_f, _c_int, _c_p],
+}
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises loudly when the HIP extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "clip_fsar_amd: HIP extension %s is missing -- build it with `python clip-fsar_amd/build.py` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback for the hot path." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _c_int
+        L.cfsar_last_error.restype = ctypes.c_char_p
+        L.cfsar_last_error.argtypes = []
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, lib().cfsar_last_error().decode(errors="replace")))
+
+
+def _dev(t, dtype=None, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("clip_fsar_amd.hip: %s must be a HIP device tensor (no CPU path exists)" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError("clip_fsar_amd.hip: %s has dtype %s, expected %s" % (name, t.dtype, dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("clip_fsar_amd.hip: %s must be contiguous" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _opt(t, dtype, name):
+    return None if t is None else _dev(t, dtype, name)
+
+
+def _code(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise RuntimeError("clip_fsar_amd.hip: unsupported dtype %s" % dtype)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ----------------------------------------------------------------------------------------------- ViT tower ops
+def im2col_patches(frames, out, patch):
+    """frames [F,3,H,W] f32 -> out [F*(H/P)*(W/P), k_pad] (f32|bf16), zero-padded columns."""
+    F_, C, H, W = frames.shape
+    assert C == 3
+    _check(lib().cfsar_im2col_patches(_dev(frames, torch.float32, "frames"), _dev(out, None, "out"), _code(out.dtype),
+                                      F_, H, W, patch, out.shape[1], _stream()), "cfsar_im2col_patches")
+
+
+def cls_rows(x, cls, pos, F_, ntok, D):
+    _check(lib().cfsar_cls_rows(_dev(x, torch.float32, "x"), _dev(cls, torch.float32, "cls"),
+                                _dev(pos, torch.float32, "pos"), F_, ntok, D, _stream()), "cfsar_cls_rows")
+
+
+def layernorm(x, out, weight, bias, rows, D, in_stride=None, out_stride=None, eps=1e-5):
+    in_stride = D if in_stride is None else in_stride
+    out_stride = D if out_stride is None else out_stride
+    _check(lib().cfsar_layernorm(_dev(x, torch.float32, "x"), in_stride, _dev(out, None, "out"), out_stride,
+                                 _code(out.dtype), _dev(weight, torch.float32, "weight"),
+                                 _dev(bias, torch.float32, "bias"), rows, D, eps, _stream()), "cfsar_layernorm")
+
+
+def gemm(A, W, out, bias=None, residual=None, act=ACT_NONE, M=None, N=None, K=None, lda=None, ldw=None, ldo=None,
+         ldr=None, row_group=0, row_gap=0, row_off=0, res_mod=0, res_off=0):
+    """out = act(A @ W.T + bias) + residual (see include/clipfsar_hip.h: cfsar_gemm)."""
+    if A.dtype != W.dtype:
+        raise RuntimeError("gemm: A and W dtypes differ (%s vs %s)" % (A.dtype, W.dtype))
+    M = A.shape[0] if M is None else M
+    K = A.shape[1] if K is None else K
+    N = W.shape[0] if N is None else N
+    lda = A.shape[1] if lda is None else lda
+    ldw = W.shape[1] if ldw is None else ldw
+    ldo = out.shape[-1] if ldo is None else ldo
+    ldr = (residual.shape[-1] if residual is not None else 0) if ldr is None else ldr
+    _check(lib().cfsar_gemm(_dev(A, None, "A"), _dev(W, None, "W"), _dev(out, None, "out"),
+                            _opt(bias, torch.float32, "bias"), _opt(residual, torch.float32, "residual"),
+                            M, N, K, lda, ldw, ldo, ldr, _code(A.dtype), _code(out.dtype), act,
+                            row_group, row_gap, row_off, res_mod, res_off, _stream()), "cfsar_gemm")
+
+
+def vit_attention(qkv, out, F_, ntok, D, heads):
+    if qkv.dtype != out.dtype:
+        raise RuntimeError("vit_attention: qkv/out dtype mismatch")
+    _check(lib().cfsar_vit_attention(_dev(qkv, None, "qkv"), _dev(out, None, "out"), _code(qkv.dtype), F_, ntok, D,
+                                     heads, _stream()), "cfsar_vit_attention")
+
+
+# ----------------------------------------------------------------------------------------------- few-shot tail ops
+def class_text_logits(feats, text, scale, out, n_videos, T, E):
+    _check(lib().cfsar_class_text_logits(_dev(feats, torch.float32, "feats"), _dev(text, torch.float32, "text"),
+                                         _dev(scale, torch.float32, "scale"), _dev(out, torch.float32, "out"),
+                                         n_videos, T, E, text.shape[0], _stream()), "cfsar_class_text_logits")
+
+
+def build_sequences(feats, text_test, support_labels, real_support_labels, X, B, S, Q, T, E, way, merge_before):
+    _check(lib().cfsar_build_sequences(_dev(feats, torch.float32, "feats"), _dev(text_test, torch.float32, "text_test"),
+                                       _dev(support_labels, torch.float32, "support_labels"),
+                                       _dev(real_support_labels, torch.float32, "real_support_labels"),
+                                       _dev(X, torch.float32, "X"), B, S, Q, T, E, way, text_test.shape[0],
+                                       int(bool(merge_before)), _stream()), "cfsar_build_sequences")
+
+
+def seq_attention(qkv, out, n_a, len_a, n_b, len_b, heads, head_dim, scale):
+    _check(lib().cfsar_seq_attention(_dev(qkv, torch.float32, "qkv"), _dev(out, torch.float32, "out"), n_a, len_a, n_b,
+                                     len_b, heads, head_dim, float(scale), _stream()), "cfsar_seq_attention")
+
+
+def prototypes(Xs, support_labels, protos, B, S, Sp, T, E, way, merge_before):
+    _check(lib().cfsar_prototypes(_dev(Xs, torch.float32, "Xs"), _dev(support_labels, torch.float32, "support_labels"),
+                                  _dev(protos, torch.float32, "protos"), B, S, Sp, T, E, way, int(bool(merge_before)),
+                                  _stream()), "cfsar_prototypes")
+
+
+def cos_otam_logits(Xq, protos, logits, B, Q, way, T, E, lbda=0.5, single_direct=False, dists_out=None):
+    _check(lib().cfsar_cos_otam_logits(_dev(Xq, torch.float32, "Xq"), _dev(protos, torch.float32, "protos"),
+                                       _dev(logits, torch.float32, "logits"), _opt(dists_out, torch.float32, "dists_out"),
+                                       B, Q, way, T, E, float(lbda), int(bool(single_direct)), _stream()),
+           "cfsar_cos_otam_logits")

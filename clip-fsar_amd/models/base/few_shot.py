@@ -1,0 +1,146 @@
+"""``CNN_OTAM_CLIPFSAR`` -- the CLIP-FSAR head (reference models/base/few_shot.py:2690-2993) with the same
+constructor / forward / loss / state-dict surface, executing on hand-written HIP kernels (clip_fsar_amd.engine).
+
+What is kept from the reference contract:
+  * registered in HEAD_REGISTRY under the same class name; ``CNN_OTAM_CLIPFSAR(cfg)`` reads
+    cfg.VIDEO.HEAD.BACKBONE_NAME, cfg.TRAIN.CLASS_NAME, cfg.TEST.CLASS_NAME, cfg.DATA.NUM_INPUT_FRAMES and the
+    absent-by-default flags cfg.TRAIN.{TRANSFORMER_DEPTH,MERGE_BEFORE,SINGLE_DIRECT} through ``hasattr`` (:2699-2739);
+  * parameter names and shapes (``scale``, ``backbone.*`` of the CLIP VisionTransformer, ``context2.layers.*``) so a
+    reference-trained checkpoint loads with ``load_state_dict`` (reference utils/checkpoint.py:329);
+  * ``text_features_train`` / ``text_features_test`` are plain attributes, not parameters/buffers (:2714-2728);
+  * ``forward(inputs: dict) -> {'logits': [Q, way], 'class_logits': [(S+Q), n_train]}`` (:2989-2990) on the eval
+    default branch (:2932-2982); ``loss`` = cross entropy on logits (:2992).
+
+What differs, by design:
+  * no network: weights are deterministic random-init (clip_fsar_amd.synth) unless cfg.VIDEO.HEAD.CLIP_VISUAL_WEIGHTS
+    points at a state-dict file; the CLIP text tower is init-time only and is replaced by a
+    synthetic [n_classes, E] table unless cfg.VIDEO.HEAD.TEXT_FEATURES_{TRAIN,TEST} point at tensors;
+  * "ViT-L/14" is accepted (extension A16: mid_dim 768, context2 by the same formula :2737-2739);
+  * inference only: the training branch (:2776-2832), EVAL_TEXT (:2835-2852) and COMBINE (:2855-2930) raise;
+  * a leading episode-batch dimension is accepted (support_set [B, S*T, 3, H, W]); the reference's single-episode
+    layout is the B = 1 case;
+  * there is no CPU path: forward raises unless the inputs live on a HIP device and libclipfsar_hip.so is built.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import synth
+from .base_blocks import HEAD_REGISTRY
+
+
+def _flag(ns, name):
+    return bool(hasattr(ns, name) and getattr(ns, name))
+
+
+def _nested_params(module: nn.Module, flat: dict):
+    """Materialise dotted parameter names (e.g. 'transformer.resblocks.0.attn.in_proj_weight') as nested plain
+    nn.Module containers holding nn.Parameters.  The containers have no forward: they exist for state_dict naming."""
+    for name, value in flat.items():
+        parts = name.split(".")
+        m = module
+        for p in parts[:-1]:
+            if p not in m._modules:
+                m.add_module(p, nn.Module())
+            m = m._modules[p]
+        m.register_parameter(parts[-1], nn.Parameter(torch.as_tensor(value).clone().float(), requires_grad=False))
+
+
+class CNN_FSHead(nn.Module):
+    """Base class surface of the reference (:1140-1199): ``loss`` is cross entropy on the logits."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.args = cfg
+        self.train()
+
+    def loss(self, task_dict, model_dict):
+        return F.cross_entropy(model_dict["logits"], task_dict["target_labels"].long())
+
+
+@HEAD_REGISTRY.register()
+class CNN_OTAM_CLIPFSAR(CNN_FSHead):
+    SUPPORTED = ("ViT-B/16", "ViT-L/14")
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        name = cfg.VIDEO.HEAD.BACKBONE_NAME
+        if name == "RN50":
+            raise NotImplementedError("BACKBONE_NAME 'RN50' (ModifiedResNet tower) is not built yet (SURVEY.md 8(f) N3); "
+                                      "use 'ViT-B/16'")
+        if name not in synth.ARCHS:
+            raise ValueError("unsupported BACKBONE_NAME %r (supported: %s)" % (name, ", ".join(self.SUPPORTED)))
+        self.arch_name = name
+        self.arch = dict(synth.ARCHS[name])
+        self.mid_dim = self.arch["embed"]                                    # 512 for ViT-B/16 (:2713)
+        self.class_real_train = cfg.TRAIN.CLASS_NAME
+        self.class_real_test = cfg.TEST.CLASS_NAME
+        seed = int(getattr(cfg, "RANDOM_SEED", 18))
+        depth = int(cfg.TRAIN.TRANSFORMER_DEPTH) if _flag(cfg.TRAIN, "TRANSFORMER_DEPTH") else 1   # :2736-2739
+        self.depth = depth
+        self.precision = str(getattr(cfg.VIDEO.HEAD, "PRECISION", "bf16"))
+
+        # ---- parameters under the reference's names
+        vis = synth.vit_state_dict(name, seed)
+        wpath = getattr(cfg.VIDEO.HEAD, "CLIP_VISUAL_WEIGHTS", None)
+        if wpath:
+            loaded = torch.load(wpath, map_location="cpu")
+            loaded = {k[len("visual."):] if k.startswith("visual.") else k: v for k, v in loaded.items()}
+            vis = {k: loaded[k].float().numpy() for k in vis}
+        self.backbone = nn.Module()
+        _nested_params(self.backbone, vis)
+        self.context2 = nn.Module()
+        _nested_params(self.context2, synth.context2_state_dict(self.mid_dim, 8, self.mid_dim // 8, 2048, depth, seed))
+        self.mid_layer = nn.Sequential()                                      # identity (:2731)
+        self.classification_layer = nn.Sequential()                           # identity (:2732)
+        self.scale = nn.Parameter(torch.ones(1), requires_grad=False)         # :2733-2734
+
+        # ---- text tables: plain attributes like the reference (:2714-2728)
+        def table(attr, n, split):
+            p = getattr(cfg.VIDEO.HEAD, attr, None)
+            if p:
+                t = torch.load(p, map_location="cpu").float()
+                assert t.shape == (n, self.mid_dim), (t.shape, n, self.mid_dim)
+                return t
+            return torch.from_numpy(synth.text_features(n, self.mid_dim, split, seed))
+
+        self.text_features_train = table("TEXT_FEATURES_TRAIN", len(self.class_real_train), "train")
+        self.text_features_test = table("TEXT_FEATURES_TEST", len(self.class_real_test), "test")
+        self._engine = None
+        self._engine_key = None
+
+    # ------------------------------------------------------------------ engine (device-side packed weights)
+    def _get_engine(self, device):
+        from ...engine import ClipFsarEngine        # imported lazily: constructing the head needs no GPU
+        key = (str(device), self.precision, tuple(p._version for p in self.parameters()))
+        if self._engine is None or self._engine_key != key:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            self._engine = ClipFsarEngine(self.arch, sd, self.text_features_train, self.text_features_test,
+                                          depth=self.depth, precision=self.precision, device=device,
+                                          max_frames=int(getattr(self.args.VIDEO.HEAD, "MAX_FRAMES_PER_LAUNCH", 1280)))
+            self._engine_key = key
+        return self._engine
+
+    def forward(self, inputs):
+        cfg = self.args
+        if self.training:
+            raise NotImplementedError("CNN_OTAM_CLIPFSAR (HIP): the training branch is out of scope; call .eval()")
+        if _flag(cfg.TRAIN, "EVAL_TEXT") or _flag(cfg.TRAIN, "COMBINE"):
+            raise NotImplementedError("TRAIN.EVAL_TEXT / TRAIN.COMBINE eval branches are not built yet (SURVEY.md N4)")
+        support_images, support_labels = inputs["support_set"], inputs["support_labels"]
+        target_images, support_real_class = inputs["target_set"], inputs["real_support_labels"]
+        if not support_images.is_cuda:
+            raise RuntimeError("CNN_OTAM_CLIPFSAR (HIP) has no CPU path: move the episode to the GPU "
+                               "(reference runs/test_net_few_shot.py:59-62 does the same)")
+        T = int(cfg.DATA.NUM_INPUT_FRAMES)
+        batched = support_images.dim() == 5
+        way = int(getattr(cfg.TRAIN, "WAY", 0)) or int(torch.unique(support_labels).numel())
+        eng = self._get_engine(support_images.device)
+        logits, class_logits = eng.forward(
+            support_images.float().contiguous(), target_images.float().contiguous(), support_labels, support_real_class,
+            way=way, T=T, merge_before=_flag(cfg.TRAIN, "MERGE_BEFORE"), single_direct=_flag(cfg.TRAIN, "SINGLE_DIRECT"))
+        if not batched:
+            logits, class_logits = logits[0], class_logits[0]
+        return {"logits": logits, "class_logits": class_logits}

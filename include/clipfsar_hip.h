@@ -1,0 +1,114 @@
+/*
+ * clipfsar_hip.h -- C ABI of libclipfsar_hip.so: the hand-written HIP (gfx950 / CDNA4) kernels of the
+ * CLIP-FSAR episodic-inference hot path.
+ *
+ * The reference (alibaba-mmai-research/CLIP-FSAR) is pure Python on stock torch.nn modules; it has no FFI for
+ * this path.  Each entry point below replaces the library-dispatched op(s) named in its comment
+ * (file:line in /root/reference/models/base/few_shot.py unless stated otherwise).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates; `tensor.data_ptr()`),
+ *     including all workspaces: the library allocates nothing and keeps no global state;
+ *   - `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); all work is enqueued on it and
+ *     no entry point synchronises with the host;
+ *   - return value 0 = success; non-zero = error, message via cfsar_last_error() (thread-local);
+ *   - dtype codes: CFSAR_F32 = 0, CFSAR_BF16 = 1;  matrices are row-major with explicit leading dimensions
+ *     (in elements).
+ */
+#ifndef CLIPFSAR_HIP_H
+#define CLIPFSAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFSAR_F32 0
+#define CFSAR_BF16 1
+
+#define CFSAR_ACT_NONE 0
+#define CFSAR_ACT_QUICKGELU 1 /* x*sigmoid(1.702x), few_shot.py:614-616 */
+#define CFSAR_ACT_GELU_ERF 2  /* nn.GELU() exact, few_shot.py:1647 */
+
+typedef void* cfsar_stream_t;
+
+/* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
+int cfsar_version(void);
+const char* cfsar_last_error(void);
+
+/* ---- A2 patch embedding, stage 1: gather non-overlapping PxP patches of NCHW fp32 frames into GEMM rows.
+ * Replaces the im2col implied by nn.Conv2d(3, D, kernel=P, stride=P, bias=False) (few_shot.py:659,672-674).
+ * frames [F,3,H,W] fp32 -> out [F*(H/P)*(W/P), k_pad] (dtype out_dtype); column k = c*P*P + dy*P + dx,
+ * columns >= 3*P*P are zero-filled.  P must be even. */
+int cfsar_im2col_patches(const float* frames, void* out, int out_dtype, int F, int H, int W, int P, int k_pad,
+                         cfsar_stream_t stream);
+
+/* ---- A2 stage 3: class-token rows.  x[f*ntok*D + d] = cls[d] + pos[d]  (few_shot.py:675-676). */
+int cfsar_cls_rows(float* x, const float* cls, const float* pos, int F, int ntok, int D, cfsar_stream_t stream);
+
+/* ---- A3 LayerNorm over the last dim (fp32 statistics, biased variance, eps inside the sqrt), few_shot.py:605-611
+ * (ln_pre/ln_1/ln_2/ln_post) and :971-977 (context2 pre-norm).  x rows at stride in_stride (elements), out rows at
+ * out_stride; out dtype f32 or bf16.  D % 4 == 0, D <= 4096.  In-place (out == x, f32) is allowed. */
+int cfsar_layernorm(const float* x, int64_t in_stride, void* out, int64_t out_stride, int out_dtype,
+                    const float* weight, const float* bias, int rows, int D, float eps, cfsar_stream_t stream);
+
+/* ---- A5/A6/A8/A11 dense projections: out = act(A . W^T + bias) + residual, MFMA (v_mfma_f32_32x32x16_bf16 for
+ * bf16 inputs, v_mfma_f32_32x32x2_f32 for f32 inputs), fp32 accumulation.
+ * Replaces nn.Linear / MultiheadAttention in_proj+out_proj / conv1-as-GEMM / `@ proj`
+ * (few_shot.py:623,626-628,635,672,686,1046-1053,1646-1650).
+ *   A [M,K] (in_dtype, lda), W [N,K] (in_dtype, ldw; nn.Linear weight layout), bias [N] f32 or NULL,
+ *   residual f32 (ldr) or NULL, out [.,N] (out_dtype, ldo).
+ *   Output row of GEMM row m:  orow = m + (m / row_group) * row_gap + row_off   (row_group == 0: orow = m);
+ *   residual row: res_mod > 0 ? (m % res_mod) + res_off : orow.   (Used to scatter patch rows behind the class
+ *   token and add the positional embedding in the patch-embed epilogue.)
+ *   K % 64 == 0 (bf16) / K % 32 == 0 (f32); N % 4 == 0; A and W 16-byte aligned rows. */
+int cfsar_gemm(const void* A, const void* W, void* out, const float* bias, const float* residual, int M, int N,
+               int K, int lda, int ldw, int ldo, int ldr, int in_dtype, int out_dtype, int act, int row_group,
+               int row_gap, int row_off, int res_mod, int res_off, cfsar_stream_t stream);
+
+/* ---- A5 scaled-dot-product attention of nn.MultiheadAttention for the ViT (no mask, no dropout), head_dim 64.
+ * qkv [F*ntok, 3*D] packed as [q | k | v], head h at columns h*64 of each third; out [F*ntok, D].
+ * dtype bf16: MFMA kernel (K and V^T of one (frame, head) staged in LDS, single-pass softmax in registers);
+ * dtype f32: fp32 VALU kernel (validation mode).  ntok <= 288. */
+int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads,
+                        cfsar_stream_t stream);
+
+/* ---- A15b aux class logits: cos_sim(mean_T(feats), text_train) * scale  (few_shot.py:2937-2939, cos_sim :1115-1124).
+ * feats [n_videos, T, E] f32, text [n_cls, E] f32, scale [1] f32 (device), out [n_videos, n_cls] f32. */
+int cfsar_class_text_logits(const float* feats, const float* text, const float* scale, float* out, int n_videos,
+                            int T, int E, int n_cls, cfsar_stream_t stream);
+
+/* ---- A10/A12 build the temporal-transformer input sequences of a batch of episodes (few_shot.py:2946-2955).
+ * feats [B, S+Q, T, E] f32 (support videos first), text_test [n_test, E], support_labels / real_support_labels
+ * [B, S] f32.  Output tokens X (row-major [rows, E]):
+ *    rows [0, B*Q*T)                       : query sequences, (b, q, t)
+ *    rows [B*Q*T, B*Q*T + B*Sp*(T+1))      : support sequences (b, s', 0..T): T frame tokens then the text token,
+ * Sp = S, or `way` when merge_before != 0 (class means of frames and of the text rows, classes in ascending label
+ * order as torch.unique sorts them).  Returns non-zero if way*shot != S. */
+int cfsar_build_sequences(const float* feats, const float* text_test, const float* support_labels,
+                          const float* real_support_labels, float* X, int B, int S, int Q, int T, int E, int way,
+                          int n_test, int merge_before, cfsar_stream_t stream);
+
+/* ---- A11 attention of Attention_qkv on short sequences (few_shot.py:1056-1073): softmax(q k^T * scale) v per
+ * (sequence, head).  qkv [rows, 3*inner] f32 packed [q | k | v]; out [rows, inner].  Sequences: n_a sequences of
+ * length len_a starting at row 0, then n_b sequences of length len_b.  len <= 64, head_dim <= 128. */
+int cfsar_seq_attention(const float* qkv, float* out, int n_a, int len_a, int n_b, int len_b, int heads,
+                        int head_dim, float scale, cfsar_stream_t stream);
+
+/* ---- A12 prototypes: first T tokens of each support sequence, class-mean over shots unless merged before
+ * (few_shot.py:2956-2962).  Xs = support part of the context2 output [B, Sp, T+1, E]; protos [B, way, T, E]. */
+int cfsar_prototypes(const float* Xs, const float* support_labels, float* protos, int B, int S, int Sp, int T, int E,
+                     int way, int merge_before, cfsar_stream_t stream);
+
+/* ---- A13/A14/A15 cos_sim (eps = 0.01 added to the product of norms) -> 1 - sim -> OTAM soft-DTW (lambda 0.5,
+ * zero-padded columns, both directions unless single_direct) -> logits = -cum_dists
+ * (few_shot.py:1115-1124, 2657-2687, 2970-2990).  Xq [B, Q, T, E], protos [B, way, T, E] f32;
+ * logits [B, Q, way]; dists_out (optional, may be NULL) [B, Q, way, T, T].  T <= 32. */
+int cfsar_cos_otam_logits(const float* Xq, const float* protos, float* logits, float* dists_out, int B, int Q,
+                          int way, int T, int E, float lambda, int single_direct, cfsar_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIPFSAR_HIP_H */

@@ -1,0 +1,57 @@
+"""Shared helpers for the parity tests: rebuild inputs/weights of a golden case from synth.py, run the oracle,
+run the HIP engine."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import clip_fsar_amd.synth as synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+SMALL_CASES = ["t_5w1s_T8", "t_5w5s_T8_mb", "t_5w5s_q2_T8", "t_5w3s_T16_mb_d2", "t_5w2s_T4_sd", "t197_5w1s_T2",
+               "t257_5w1s_T2"]
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLD, "head_%s.npz" % name))
+    out = {k: z[k] for k in z.files}
+    out["meta"] = json.loads(str(out["meta"]))
+    return out
+
+
+def case_inputs(meta, episode=None):
+    """(arch dict, head state dict (torch cpu), text_train, text_test, episode dict (torch cpu))"""
+    a = synth.ARCHS[meta["arch"]]
+    depth = meta.get("depth", 1)
+    sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(meta["arch"], seed=meta["seed"], depth=depth).items()}
+    tt = torch.from_numpy(synth.text_features(meta["n_train"], a["embed"], "train", meta["seed"]))
+    te = torch.from_numpy(synth.text_features(meta["n_test"], a["embed"], "test", meta["seed"]))
+    ep = synth.make_episode(way=meta["way"], shot=meta["shot"], query_per_class=meta["q"], frames=meta["T"],
+                            res=a["res"], n_test_classes=meta["n_test"],
+                            episode=meta["episode"] if episode is None else episode, seed=meta["seed"])
+    ep = {k: torch.from_numpy(v) for k, v in ep.items()}
+    return a, sd, tt, te, ep
+
+
+def run_engine(meta, a, sd, tt, te, eps, precision, taps=None):
+    """eps: list of episode dicts (cpu) -> (logits [B,Q,way], class_logits) on cpu."""
+    from clip_fsar_amd.engine import ClipFsarEngine
+    eng = ClipFsarEngine(a, sd, tt, te, depth=meta.get("depth", 1), precision=precision, device="cuda")
+    dev = torch.device("cuda")
+    sup = torch.stack([e["support_set"] for e in eps]).to(dev)
+    tgt = torch.stack([e["target_set"] for e in eps]).to(dev)
+    sl = torch.stack([e["support_labels"] for e in eps]).to(dev)
+    rl = torch.stack([e["real_support_labels"] for e in eps]).to(dev)
+    logits, cl = eng.forward(sup, tgt, sl, rl, way=meta["way"], T=meta["T"],
+                             merge_before=meta.get("merge_before", False),
+                             single_direct=meta.get("single_direct", False), taps=taps)
+    torch.cuda.synchronize()
+    return logits.cpu(), cl.cpu()
+
+
+def maxdiff(a, b):
+    a = torch.as_tensor(a).float()
+    b = torch.as_tensor(b).float()
+    return float((a - b).abs().max())

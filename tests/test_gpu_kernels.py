@@ -1,0 +1,231 @@
+"""GPU parity tests, kernel level: every C-ABI entry point of libclipfsar_hip.so against the CPU oracle
+(oracle/clipfsar_oracle.py) or a plain torch fp32 reference of the same op, on seeded inputs.
+
+Tolerances (written here, per the north star "within 1e-3 fp32"):
+  fp32 kernels: 2e-4 absolute on O(1)-O(30) values (accumulation-order differences only);
+  bf16 kernels: compared against the fp32 op applied to bf16-ROUNDED inputs, 2e-2 relative to the output scale.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import clipfsar_oracle as orc  # noqa: E402
+from _cases import maxdiff  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from clip_fsar_amd import hip as h
+    h.lib()
+    return h
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+GEMM_SHAPES = [(77, 64, 64), (300, 192, 128), (1000, 768, 768), (197 * 3, 2304, 768), (130, 512, 3072), (45, 2048, 512)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gemm_plain_and_epilogues(hip, M, N, K, dtype):
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    A = _rand(M, K, seed=1).to(td)
+    W = _rand(N, K, seed=2, scale=K ** -0.5).to(td)
+    bias = _rand(N, seed=3)
+    res = _rand(M, N, seed=4)
+    ref0 = A.float() @ W.float().t()
+    tol = 2e-4 if dtype == "f32" else 2e-2
+    Ad, Wd, bd, rd = A.cuda(), W.cuda(), bias.cuda(), res.cuda()
+    # plain, asymmetric operands (transpose-detecting)
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    hip.gemm(Ad, Wd, out)
+    assert maxdiff(out.cpu(), ref0) < tol * max(1.0, float(ref0.abs().max()))
+    # bias + QuickGELU, output in the input dtype
+    out2 = torch.empty(M, N, device="cuda", dtype=td)
+    hip.gemm(Ad, Wd, out2, bias=bd, act=hip.ACT_QUICKGELU)
+    ref = orc.quick_gelu(ref0 + bias)
+    assert maxdiff(out2.float().cpu(), ref) < (tol if dtype == "f32" else 4e-2) * max(1.0, float(ref.abs().max()))
+    # bias + GELU(erf)
+    hip.gemm(Ad, Wd, out, bias=bd, act=hip.ACT_GELU_ERF)
+    assert maxdiff(out.cpu(), orc.gelu_erf(ref0 + bias)) < tol * max(1.0, float(ref0.abs().max()))
+    # bias + residual, in place on the residual buffer (the residual-stream update)
+    x = rd.clone()
+    hip.gemm(Ad, Wd, x, bias=bd, residual=x)
+    assert maxdiff(x.cpu(), ref0 + bias + res) < tol * max(1.0, float(ref0.abs().max()))
+
+
+def test_gemm_row_remap(hip):
+    """patch-embed epilogue: rows scattered behind the class token + positional rows added."""
+    F_, npatch, D, K = 3, 16, 128, 64
+    A = _rand(F_ * npatch, K, seed=5)
+    W = _rand(D, K, seed=6, scale=K ** -0.5)
+    pos = _rand(npatch + 1, D, seed=7)
+    x = torch.full((F_ * (npatch + 1), D), -7.0, device="cuda")
+    hip.gemm(A.cuda(), W.cuda(), x, residual=pos.cuda(), M=F_ * npatch, N=D, K=K, ldo=D, ldr=D, row_group=npatch,
+             row_gap=1, row_off=1, res_mod=npatch, res_off=1)
+    ref = (A @ W.t()).reshape(F_, npatch, D) + pos[1:]
+    got = x.cpu().reshape(F_, npatch + 1, D)
+    assert maxdiff(got[:, 1:], ref) < 2e-4
+    assert torch.all(got[:, 0] == -7.0)          # class-token rows untouched
+
+
+@pytest.mark.parametrize("rows,D", [(5, 64), (197 * 4, 768), (33, 1024), (85, 512)])
+def test_layernorm(hip, rows, D):
+    x = _rand(rows, D, seed=8, scale=3.0) + 0.5
+    w, b = _rand(D, seed=9) * 0.1 + 1.0, _rand(D, seed=10) * 0.1
+    ref = orc.layer_norm(x, w, b)
+    o32 = torch.empty(rows, D, device="cuda")
+    hip.layernorm(x.cuda(), o32, w.cuda(), b.cuda(), rows, D)
+    assert maxdiff(o32.cpu(), ref) < 2e-5
+    o16 = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    hip.layernorm(x.cuda(), o16, w.cuda(), b.cuda(), rows, D)
+    assert maxdiff(o16.float().cpu(), ref) < 4e-2
+    # strided rows (ln_post on the class-token rows) and in place
+    xs = _rand(rows, 3 * D, seed=11)
+    os_ = torch.empty(rows, D, device="cuda")
+    hip.layernorm(xs.cuda(), os_, w.cuda(), b.cuda(), rows, D, in_stride=3 * D, out_stride=D)
+    assert maxdiff(os_.cpu(), orc.layer_norm(xs[:, :D], w, b)) < 2e-5
+    xi = x.cuda()
+    hip.layernorm(xi, xi, w.cuda(), b.cuda(), rows, D)
+    assert maxdiff(xi.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("P,res", [(16, 64), (14, 56), (16, 224)])
+def test_im2col_and_cls_rows(hip, P, res):
+    F_, D = 3, 128
+    frames = _rand(F_, 3, res, res, seed=12)
+    g = res // P
+    kreal = 3 * P * P
+    kpad = (kreal + 63) // 64 * 64
+    ref = frames.reshape(F_, 3, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(F_ * g * g, kreal)
+    for td in (torch.float32, torch.bfloat16):
+        out = torch.full((F_ * g * g, kpad), 9.0, device="cuda", dtype=td)
+        hip.im2col_patches(frames.cuda(), out, P)
+        got = out.float().cpu()
+        assert maxdiff(got[:, :kreal], ref.to(td).float()) == 0.0
+        assert torch.all(got[:, kreal:] == 0)
+    ntok = g * g + 1
+    x = torch.zeros(F_ * ntok, D, device="cuda")
+    cls, pos = _rand(D, seed=13), _rand(ntok, D, seed=14)
+    hip.cls_rows(x, cls.cuda(), pos.cuda(), F_, ntok, D)
+    got = x.cpu().reshape(F_, ntok, D)
+    assert maxdiff(got[:, 0], (cls + pos[0]).expand(F_, D)) == 0.0
+    assert torch.all(got[:, 1:] == 0)
+
+
+def _ref_attention(qkv, F_, ntok, D, heads):
+    q, k, v = qkv.float().reshape(F_, ntok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+    return (att @ v).permute(0, 2, 1, 3).reshape(F_ * ntok, D)
+
+
+@pytest.mark.parametrize("ntok", [5, 17, 197, 257])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_vit_attention(hip, ntok, dtype):
+    F_, heads = 3, 2
+    D = heads * 64
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    qkv = (_rand(F_ * ntok, 3 * D, seed=15) * 1.5).to(td)
+    # spike one key against one query so the softmax is far from uniform somewhere
+    ref = _ref_attention(qkv, F_, ntok, D, heads)
+    out = torch.empty(F_ * ntok, D, device="cuda", dtype=td)
+    hip.vit_attention(qkv.cuda(), out, F_, ntok, D, heads)
+    tol = 2e-5 if dtype == "f32" else 3e-2
+    assert maxdiff(out.float().cpu(), ref) < tol
+
+
+def test_class_text_logits(hip):
+    nv, T, E, ncls = 10, 8, 512, 64
+    feats, text, scale = _rand(nv, T, E, seed=16), _rand(ncls, E, seed=17), torch.tensor([1.7])
+    out = torch.empty(nv, ncls, device="cuda")
+    hip.class_text_logits(feats.cuda(), text.cuda(), scale.cuda(), out, nv, T, E)
+    assert maxdiff(out.cpu(), orc.cos_sim(feats.mean(1), text) * scale) < 1e-5
+
+
+@pytest.mark.parametrize("merge_before", [False, True])
+def test_build_sequences_and_prototypes(hip, merge_before):
+    B, way, shot, Q, T, E, ntest = 2, 5, 3, 5, 4, 64, 24
+    S = way * shot
+    feats = _rand(B, S + Q, T, E, seed=18)
+    text = _rand(ntest, E, seed=19)
+    lab = torch.stack([torch.arange(way).repeat_interleave(shot)[torch.randperm(S, generator=torch.Generator().manual_seed(b))]
+                       for b in range(B)]).float()
+    real = (lab * 3 + 2)                                                   # real class id per support video
+    Sp = way if merge_before else S
+    X = torch.empty(B * Q * T + B * Sp * (T + 1), E, device="cuda")
+    hip.build_sequences(feats.cuda(), text.cuda(), lab.cuda(), real.cuda(), X, B, S, Q, T, E, way, merge_before)
+    Xc = X.cpu()
+    assert maxdiff(Xc[:B * Q * T].reshape(B, Q, T, E), feats[:, S:]) == 0.0
+    sup = Xc[B * Q * T:].reshape(B, Sp, T + 1, E)
+    for b in range(B):
+        fs, ctx = feats[b, :S], text[real[b].long()].unsqueeze(1)
+        if merge_before:
+            fs, _ = orc.class_means(fs, lab[b])
+            ctx, _ = orc.class_means(ctx, lab[b])
+        assert maxdiff(sup[b], torch.cat([fs, ctx], 1)) < 1e-6
+    protos = torch.empty(B, way, T, E, device="cuda")
+    hip.prototypes(X[B * Q * T:], lab.cuda(), protos, B, S, Sp, T, E, way, merge_before)
+    for b in range(B):
+        ref = sup[b][:, :T]
+        if not merge_before:
+            ref, _ = orc.class_means(ref, lab[b])
+        assert maxdiff(protos[b].cpu(), ref) < 1e-6
+
+
+def test_seq_attention(hip):
+    heads, hd, na, la, nb, lb = 8, 64, 5, 8, 5, 9
+    inner = heads * hd
+    rows = na * la + nb * lb
+    qkv = _rand(rows, 3 * inner, seed=20)
+    out = torch.empty(rows, inner, device="cuda")
+    hip.seq_attention(qkv.cuda(), out, na, la, nb, lb, heads, hd, hd ** -0.5)
+    got = out.cpu()
+    r0 = 0
+    for n, L in ((na, la), (nb, lb)):
+        for s in range(n):
+            blk = qkv[r0:r0 + L]
+            q, k, v = [t.reshape(L, heads, hd).transpose(0, 1) for t in blk.split(inner, dim=1)]
+            a = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1)
+            ref = (a @ v).transpose(0, 1).reshape(L, inner)
+            assert maxdiff(got[r0:r0 + L], ref) < 1e-5
+            r0 += L
+
+
+@pytest.mark.parametrize("T", [1, 4, 8, 16])
+@pytest.mark.parametrize("single_direct", [False, True])
+def test_cos_otam_logits(hip, T, single_direct):
+    B, Q, way, E = 2, 5, 5, 512
+    xq, pr = _rand(B, Q, T, E, seed=21), _rand(B, way, T, E, seed=22)
+    logits = torch.empty(B, Q, way, device="cuda")
+    dists = torch.empty(B, Q, way, T, T, device="cuda")
+    hip.cos_otam_logits(xq.cuda(), pr.cuda(), logits, B, Q, way, T, E, 0.5, single_direct, dists_out=dists)
+    for b in range(B):
+        sim = orc.cos_sim(xq[b].reshape(Q * T, E), pr[b].reshape(way * T, E))
+        d = (1 - sim).reshape(Q, T, way, T).permute(0, 2, 1, 3)
+        cum = orc.otam_cum_dist(d)
+        if not single_direct:
+            cum = cum + orc.otam_cum_dist(d.transpose(-1, -2))
+        assert maxdiff(dists[b].cpu(), d) < 1e-5
+        assert maxdiff(logits[b].cpu(), -cum) < 1e-4
+
+
+def test_otam_known_answers(hip):
+    """SURVEY.md section 4 known answers through the HIP kernel: dists are produced from orthogonal / identical
+    unit vectors so that 1 - cos takes known values."""
+    T, E = 8, 64
+    # identical unit vectors everywhere -> sim = 1/(1+0.01), dist = 1 - 1/1.01 everywhere
+    x = torch.zeros(1, 1, T, E)
+    x[..., 0] = 1.0
+    logits = torch.empty(1, 1, 1, device="cuda")
+    hip.cos_otam_logits(x.cuda(), x.cuda(), logits, 1, 1, 1, T, E, 0.5, True)
+    dconst = 1.0 - 1.0 / 1.01
+    ref = orc.otam_cum_dist(torch.full((1, 1, T, T), dconst))
+    assert abs(float(logits.cpu()) + float(ref)) < 1e-5
