@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the CLIP-FSAR episodic-inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--episodes-per-step B] [--precision bf16|fp32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): episodes/sec, 5-way 1-shot, 8 frames, ViT-B/16 (config[1]: bf16 on MI355X, random-init CLIP
+weights, synthetic frames).  One "step" = the full forward A0 -> A15 (+ top-1) over a batch of B synthetic episodes
+that are already resident in HBM.  Episodes shard over ranks with no data-path collective (weak scaling: every rank
+does K steps of B episodes); the only collective is ONE all-gather (RCCL) of the per-episode accuracies, inside the
+timed region.  Rank 0 prints ONE JSON line.
+
+The line also carries
+  roofline     -- for the dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs of its launches / their measured
+                  duration (HIP events on the launch stream, recorded live during the timed steps), against the dense
+                  bf16 MFMA peak of MI355X (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md);
+  cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference path, oracle/clipfsar_oracle.py) timed on the
+                  host cores of this box on a bounded sample (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import clip_fsar_amd.synth as synth  # noqa: E402
+
+ARCH = "ViT-B/16"
+WAY, SHOT, QPC, T = 5, 1, 1, 8
+N_TRAIN, N_TEST, SEED = 64, 24, 18
+# algorithmic FLOPs (2 per MAC) of the ViT-B/16 tower per frame and per cfg2 episode (80 frames)
+GFLOP_PER_FRAME = 35.127
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+
+
+class GemmTimer:
+    """Wraps hip.gemm: brackets every bf16 GEMM launch with HIP events on the current stream (no host sync) and sums
+    algorithmic FLOPs; durations are read after the timed region."""
+
+    def __init__(self, hip_mod):
+        self.hip = hip_mod
+        self.orig = hip_mod.gemm
+        self.events = []
+        self.flops = 0.0
+        self.launches = 0
+        self.enabled = False
+
+    def install(self):
+        def gemm(A, W, out, *a, **k):
+            if not (self.enabled and A.dtype == torch.bfloat16):
+                return self.orig(A, W, out, *a, **k)
+            M = k.get("M") or A.shape[0]
+            N = k.get("N") or W.shape[0]
+            K = k.get("K") or A.shape[1]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self.orig(A, W, out, *a, **k)
+            e.record()
+            self.events.append((s, e))
+            self.flops += 2.0 * M * N * K
+            self.launches += 1
+            return r
+        self.hip.gemm = gemm
+        # engine.py binds `hip` as a module attribute, so patching the module function is enough
+
+    def result(self):
+        ms = sum(s.elapsed_time(e) for s, e in self.events)
+        return ms, self.flops, self.launches
+
+
+def cpu_baseline(sample_episodes: int = 3):
+    """Oracle (kind "port") on the host cores, bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import clipfsar_oracle as orc
+    a = synth.ARCHS[ARCH]
+    sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(ARCH, SEED).items()}
+    tt = torch.from_numpy(synth.text_features(N_TRAIN, a["embed"], "train", SEED))
+    te = torch.from_numpy(synth.text_features(N_TEST, a["embed"], "test", SEED))
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    times = []
+    with torch.no_grad():
+        for e in range(sample_episodes + 1):
+            ep = {k: torch.from_numpy(v) for k, v in synth.make_episode(WAY, SHOT, QPC, T, a["res"], N_TEST, e, SEED).items()}
+            t0 = time.perf_counter()
+            orc.head_forward(ep, sd, tt, te, a, frames=T)
+            dt = time.perf_counter() - t0
+            if e > 0:                              # first episode = warm-up
+                times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "episodes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "torch-fp32 CPU oracle, 1 warm-up + %d timed cfg2 episodes (5-way 1-shot, 8x224^2 frames, "
+                      "ViT-B/16), median %.2f s/episode" % (sample_episodes, med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--episodes-per-step", type=int, default=4)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic episodes resident in HBM per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)       # "nccl" on ROCm == RCCL over xGMI
+
+    from clip_fsar_amd import hip
+    from clip_fsar_amd.engine import ClipFsarEngine
+    hip.lib()
+    a = synth.ARCHS[ARCH]
+    B = args.episodes_per_step
+    # identical weights on every rank, built locally (no broadcast needed)
+    sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(ARCH, SEED).items()}
+    tt = synth.text_features(N_TRAIN, a["embed"], "train", SEED)
+    te = synth.text_features(N_TEST, a["embed"], "test", SEED)
+    eng = ClipFsarEngine(a, sd, tt, te, precision=args.precision, device=dev, max_frames=max(1280, B * 80))
+    # synthetic episodes of this rank (episode ids e with e % world == rank), resident in HBM before timing
+    pool = [synth.make_episode(WAY, SHOT, QPC, T, a["res"], N_TEST, rank + world * i, SEED) for i in range(args.pool)]
+    batches = []
+    for j in range(args.pool):
+        eps = [pool[(j + i) % args.pool] for i in range(B)]
+        st = lambda key: torch.stack([torch.from_numpy(e[key]) for e in eps]).to(dev)
+        batches.append(dict(sup=st("support_set"), tgt=st("target_set"), sl=st("support_labels"),
+                            rl=st("real_support_labels"), tl=st("target_labels")))
+
+    timer = GemmTimer(hip)
+    timer.install()
+
+    def step(i, acc_out):
+        b = batches[i % len(batches)]
+        logits, _ = eng.forward(b["sup"], b["tgt"], b["sl"], b["rl"], way=WAY, T=T)
+        # A17: per-episode top-1 accuracy (metrics.topks_correct semantics, reference utils/metrics.py:100-138)
+        acc_out[i * B:(i + 1) * B] = (logits.argmax(dim=2) == b["tl"].long()).float().mean(dim=1)
+
+    acc = torch.zeros(max(args.steps, args.warmup) * B, device=dev)
+    for i in range(args.warmup):
+        step(i, acc)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = not args.no_kernel_events
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, acc)
+    gathered = acc[:args.steps * B]
+    if world > 1:                                                    # the path's single collective
+        allacc = torch.empty(world * args.steps * B, device=dev)
+        dist.all_gather_into_tensor(allacc, gathered.contiguous())
+        gathered = allacc
+        torch.cuda.synchronize()
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        episodes = world * args.steps * B
+        eps_per_s = episodes / elapsed
+        frames_per_ep = (WAY * SHOT + WAY * QPC) * T
+        tflop_per_ep = GFLOP_PER_FRAME * frames_per_ep / 1e3
+        out = {
+            "metric": "episodes/sec (5-way 1-shot, 8 frames, ViT-B/16)", "value": round(eps_per_s, 3),
+            "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config[1]: 5-way 1-shot, 1 query/class, 8x224^2 frames, ViT-B/16, "
+                                   "random-init CLIP weights, synthetic structured frames",
+                       "episodes_per_step_per_gpu": B, "frames_per_episode": frames_per_ep,
+                       "tflop_per_episode": round(tflop_per_ep, 4), "precision": args.precision,
+                       "parallelism": "episodes sharded over %d rank(s); one all-gather of accuracies" % world},
+            "top1_acc_mean": round(float(gathered.mean().item()), 4),
+            "end_to_end_vit_tflops_per_gpu": round(eps_per_s / world * tflop_per_ep, 2),
+        }
+        if timer.launches:
+            ms, flops, n = timer.result()
+            achieved = flops / (ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "kernel": "gemm_kernel<bf16> (QKV / out_proj / c_fc / c_proj / patch-embed)",
+                               "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+                               "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3)}
+        else:
+            out["roofline"] = None
+        out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,8 @@
 //   * bf16 inputs: v_mfma_f32_32x32x16_bf16; f32 inputs: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, the
 //     validation mode); fp32 accumulation in both;
 //   * workgroup id -> tile mapping is XCD-aware (bijective remap: each XCD's L2 sees a contiguous band of tiles).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -36,6 +38,7 @@ struct GemmArgs {
     int act;
     int row_group, row_gap, row_off, res_mod, res_off;
     int tiles_n;
+    int dbg;   // ablation bits (env CFSAR_GEMM_DEBUG): 1 = no in-loop DMA, 2 = no in-loop barrier, 4 = no epilogue
 };
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
@@ -46,9 +49,199 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == CFSAR_ACT_QUICKGELU) return v / (1.0f + __expf(-1.702f * v));
+    if (act == CFSAR_ACT_QUICKGELU)     // x * sigmoid(1.702 x); v_exp_f32 + v_rcp_f32 (1 ulp each)
+        return v * __builtin_amdgcn_rcpf(1.0f + exp2f(-1.702f * 1.4426950408889634f * v));
     if (act == CFSAR_ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     return v;
+}
+
+// ---- epilogue: D[n][m] layout -> lane owns token row m = mbase+32mi+(lane&31) and columns 8g+4hi..+3 of each
+// 32-column tile; bias / activation / residual fused; 8-byte (bf16) or 16-byte (f32) stores.
+template <typename TO>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], const GemmArgs& p, int mbase, int nbase, int lane) {
+    const int lr = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = mbase + mi * 32 + lr;
+        if (m >= p.M) continue;
+        int orow = m + p.row_off;
+        if (p.row_group > 0) orow += (m / p.row_group) * p.row_gap;
+        const int rrow = p.res_mod > 0 ? (m % p.res_mod) + p.res_off : orow;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + ni * 32 + 8 * g + 4 * hi;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][4 * g + j];
+                if (p.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (p.act != CFSAR_ACT_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+                }
+                if (p.res) {
+                    const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)rrow * p.ldr + n);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                }
+                if constexpr (sizeof(TO) == 2) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + (size_t)orow * p.ldo + n) = o;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow * p.ldo + n) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+    }
+}
+
+// ---- one 128-byte K slice of a wave's 64x64 sub-tile: 16 ds_read_b128 + 16 (bf16) / 64 (f32) MFMAs
+template <typename TI>
+__device__ __forceinline__ void mma_slice(f32x16 (&acc)[2][2], const char* sX, const char* sW, const int (&offX)[2],
+                                          const int (&offW)[2], const int (&sxX)[2], const int (&sxW)[2], int hi) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = 2 * s + hi;
+        uint4 xf[2], wf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            xf[i] = *reinterpret_cast<const uint4*>(sX + offX[i] + ((c ^ sxX[i]) << 4));
+            wf[i] = *reinterpret_cast<const uint4*>(sW + offW[i] + ((c ^ sxW[i]) << 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                if constexpr (sizeof(TI) == 2) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]), acc[mi][ni], 0, 0, 0);
+                } else {
+                    const f32x4 a = __builtin_bit_cast(f32x4, wf[ni]);
+                    const f32x4 bb = __builtin_bit_cast(f32x4, xf[mi]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bb[j], acc[mi][ni], 0, 0, 0);
+                }
+            }
+    }
+}
+
+
+// ---- epilogue through LDS (p3 kernel): each wave transposes its 64x64 fp32 sub-tile through a private LDS region so
+// that global traffic is whole contiguous rows: a lane ends up with 4 consecutive columns of a row, 16 lanes cover one
+// 64-column row segment (128 B bf16 / 256 B f32 stores, 256 B residual loads) instead of 32 rows x 16 B per instruction.
+constexpr int EPI_RS = 272;                     // staged row: 64 fp32 + 16 B pad (conflict-free b128 writes)
+constexpr int EPI_WAVE_BYTES = 64 * EPI_RS;     // 17408 B per wave
+template <typename TO, int ACT, bool HAS_RES, bool REMAP, bool FULL>
+__device__ __forceinline__ void epilogue_lds(f32x16 (&acc)[2][2], const GemmArgs& p, int mbase, int nbase, int lane,
+                                             char* wbuf) {
+    const int lr = lane & 31, hi = lane >> 5;
+    const int rsub = lane >> 4, cc = lane & 15;
+    const int M = p.M, N = p.N, ldo = p.ldo, ldr = p.ldr, row_off = p.row_off;
+    const int n = nbase + cc * 4;
+    const bool nvalid = n < N;
+    const int nc = nvalid ? n : N - 4;                       // clamped column: loads stay in bounds, stores are predicated
+    const float* resp = p.res;
+    TO* outp = reinterpret_cast<TO*>(p.out);
+    // (1) issue every residual load of this lane up front (16 x 16 B, whole 256-byte row segments per 16 lanes)
+    float4 rv[16];
+    size_t ooff[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int m = mbase + it * 4 + rsub;
+        const int mc = m < M ? m : M - 1;
+        int orow = mc + row_off;
+        int rrow = orow;
+        if constexpr (REMAP) {
+            if (p.row_group > 0) orow += (mc / p.row_group) * p.row_gap;
+            rrow = p.res_mod > 0 ? (mc % p.res_mod) + p.res_off : orow;
+        }
+        ooff[it] = (size_t)orow * ldo + nc;
+        if constexpr (HAS_RES) rv[it] = *reinterpret_cast<const float4*>(resp + (size_t)rrow * ldr + nc);
+    }
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + nc);
+    // (2) transpose the accumulators through the wave-private LDS region
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(wbuf + (mi * 32 + lr) * EPI_RS + (ni * 32 + 8 * g + 4 * hi) * 4) =
+                    make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private region: in-order DS + this wait suffice
+    // (3) row-contiguous epilogue math + stores
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + rsub;
+        const float4 a = *reinterpret_cast<const float4*>(wbuf + row * EPI_RS + cc * 16);
+        float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
+        if constexpr (ACT != CFSAR_ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], ACT);
+        }
+        if constexpr (HAS_RES) {
+            v[0] += rv[it].x; v[1] += rv[it].y; v[2] += rv[it].z; v[3] += rv[it].w;
+        }
+        if (FULL || (nvalid && mbase + row < M)) {       // FULL: straight-line code, counted vmcnt waits
+            if constexpr (sizeof(TO) == 2) {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+                *reinterpret_cast<bf16x4*>(outp + ooff[it]) = o;
+            } else {
+                *reinterpret_cast<float4*>(outp + ooff[it]) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+// ---- K slice with register double-buffered fragments: the ds_read_b128 of sub-step s+1 are in flight while the
+// MFMAs of sub-step s execute.
+template <typename TI>
+__device__ __forceinline__ void mma_slice_db(f32x16 (&acc)[2][2], const char* sX, const char* sW, const int (&offX)[2],
+                                             const int (&offW)[2], const int (&sxX)[2], const int (&sxW)[2], int hi) {
+    uint4 xf[2][2], wf[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        xf[0][i] = *reinterpret_cast<const uint4*>(sX + offX[i] + ((hi ^ sxX[i]) << 4));
+        wf[0][i] = *reinterpret_cast<const uint4*>(sW + offW[i] + ((hi ^ sxW[i]) << 4));
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s < 3) {
+            const int c = 2 * (s + 1) + hi;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                xf[nxt][i] = *reinterpret_cast<const uint4*>(sX + offX[i] + ((c ^ sxX[i]) << 4));
+                wf[nxt][i] = *reinterpret_cast<const uint4*>(sW + offW[i] + ((c ^ sxW[i]) << 4));
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                if constexpr (sizeof(TI) == 2) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[cur][ni]),
+                                                                          __builtin_bit_cast(bf16x8, xf[cur][mi]),
+                                                                          acc[mi][ni], 0, 0, 0);
+                } else {
+                    const f32x4 a = __builtin_bit_cast(f32x4, wf[cur][ni]);
+                    const f32x4 bb = __builtin_bit_cast(f32x4, xf[cur][mi]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bb[j], acc[mi][ni], 0, 0, 0);
+                }
+            }
+    }
 }
 
 template <typename TI, typename TO>
@@ -161,46 +354,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
         if (++kt >= nk) break;
     }
 
-    // ---- epilogue: D[n][m] layout -> lane owns token row m = ..+lr and columns 8g+4hi..+3 of each 32-col tile
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wm * 64 + mi * 32 + lr;
-        if (m >= p.M) continue;
-        int orow = m + p.row_off;
-        if (p.row_group > 0) orow += (m / p.row_group) * p.row_gap;
-        const int rrow = p.res_mod > 0 ? (m % p.res_mod) + p.res_off : orow;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hi;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][4 * g + j];
-                if (p.bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                }
-                if (p.act != CFSAR_ACT_NONE) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
-                }
-                if (p.res) {
-                    const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)rrow * p.ldr + n);
-                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                }
-                if constexpr (sizeof(TO) == 2) {
-                    bf16x4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + (size_t)orow * p.ldo + n) = o;
-                } else {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow * p.ldo + n) =
-                        make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-    }
+    epilogue<TO>(acc, p, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 template <typename TI, typename TO>
@@ -208,6 +362,163 @@ int launch(const GemmArgs& a, hipStream_t s) {
     const int tiles_m = (a.M + BM - 1) / BM;
     hipLaunchKernelGGL((gemm_kernel<TI, TO>), dim3(tiles_m * a.tiles_n), dim3(NTHREADS), 0, s, a);
     return cfsar_check_launch("cfsar_gemm");
+}
+
+
+// ============================================================================================================
+// v2 ("p3"): 256(M) x 128(N) tile, 512 threads (8 waves as 4x2, each 64x64), THREE-stage LDS ring (144 KiB) with the
+// LDS-DMA issued from inline asm, so hipcc does not see it: no compiler-inserted vmcnt(0) at the barrier or before
+// fragment reads.  Loads run two K-slices ahead and stay in flight ACROSS the (single) barrier per slice; each wave
+// drains only the slice it is about to read with a counted `s_waitcnt vmcnt(6)`.
+// ============================================================================================================
+constexpr int BM2 = 256;
+constexpr int BN2 = 128;
+constexpr int STAGE2 = (BM2 + BN2) * ROWB;   // 48 KiB
+constexpr int NSTAGE2 = 3;
+constexpr int NTHREADS2 = 512;
+
+// LDS-DMA, 16 B per lane: LDS[m0 + lane*16 .. +16] = *(src).  M0 is compiler-reserved: save/restore inside the statement.
+__device__ __forceinline__ void glds16_asm(const char* src, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_addr)
+        : "memory");
+}
+
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
+__global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BK = ROWB / (int)sizeof(TI);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    // staging: X tile = 32 instructions of 8 rows, W tile = 16; wave w issues X instr {w, w+8, w+16, w+24}, W {w, w+8}
+    const char* srcX[4];
+    const char* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);
+        int gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);
+        int gn = n0 + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        srcW[i] = p.W + ((size_t)gn * p.ldw) * sizeof(TI) + chunk * 16;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+    auto issue = [&](int stage, int kt) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)stage * (unsigned)STAGE2);
+        const size_t koff = (size_t)kt * ROWB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_asm(srcX[i] + koff, base + i * 8192);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_asm(srcW[i] + koff, base + BM2 * ROWB + i * 8192);
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, hi = lane >> 5;
+    int offX[2], offW[2], sxX[2], sxW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rx = wm * 64 + i * 32 + lr;
+        const int rw = wn * 64 + i * 32 + lr;
+        offX[i] = rx * ROWB;
+        sxX[i] = swz(rx);
+        offW[i] = rw * ROWB;
+        sxW[i] = swz(rw);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.K / BK;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int st = 0;                      // stage holding slice kt
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // slice kt landed, kt+1 may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(p.dbg & 2)) __syncthreads();   // everyone's part of slice kt is in LDS; everyone is done reading slice kt-1
+        int st2 = st + 2;
+        st2 = st2 >= NSTAGE2 ? st2 - NSTAGE2 : st2;
+        if (kt + 2 < nk && !(p.dbg & 1)) issue(st2, kt + 2);
+        const char* sX = smem + st * STAGE2;
+        mma_slice_db<TI>(acc, sX, sX + BM2 * ROWB, offX, offW, sxX, sxW, hi);
+        st = st + 1 >= NSTAGE2 ? 0 : st + 1;
+    }
+    __syncthreads();                 // every wave is done with the ring: reuse it as per-wave transpose buffers
+    const int mb = m0 + wm * 64, nb = n0 + wn * 64;
+    if (p.dbg & 4) {
+        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3];
+        return;
+    }
+    if (mb + 64 <= p.M && nb + 64 <= p.N)
+        epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(acc, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+    else
+        epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(acc, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+}
+
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
+int launch_p3_inst(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
+        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tiles_m = (a.M + BM2 - 1) / BM2;
+    hipLaunchKernelGGL((gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP>), dim3(tiles_m * a.tiles_n), dim3(NTHREADS2),
+                       NSTAGE2 * STAGE2, s, a);
+    return cfsar_check_launch("cfsar_gemm(p3)");
+}
+
+// instantiated combinations: {no act, QuickGELU, GELU} x {residual or not}; the row remap (patch-embed scatter) only
+// exists with a residual and no activation.
+template <typename TI, typename TO>
+int launch_p3(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_n = (a.N + BN2 - 1) / BN2;
+    const bool r = a.res != nullptr;
+    const bool remap = a.row_group > 0 || a.res_mod > 0;
+    if (remap) {
+        if (a.act != CFSAR_ACT_NONE || !r) return -2;        // caller falls back to the generic v1 kernel
+        return launch_p3_inst<TI, TO, CFSAR_ACT_NONE, true, true>(a, s);
+    }
+    switch (a.act) {
+        case CFSAR_ACT_QUICKGELU:
+            return r ? launch_p3_inst<TI, TO, CFSAR_ACT_QUICKGELU, true, false>(a, s)
+                     : launch_p3_inst<TI, TO, CFSAR_ACT_QUICKGELU, false, false>(a, s);
+        case CFSAR_ACT_GELU_ERF:
+            return r ? launch_p3_inst<TI, TO, CFSAR_ACT_GELU_ERF, true, false>(a, s)
+                     : launch_p3_inst<TI, TO, CFSAR_ACT_GELU_ERF, false, false>(a, s);
+        default:
+            return r ? launch_p3_inst<TI, TO, CFSAR_ACT_NONE, true, false>(a, s)
+                     : launch_p3_inst<TI, TO, CFSAR_ACT_NONE, false, false>(a, s);
+    }
 }
 
 }  // namespace
@@ -240,7 +551,20 @@ extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* 
     a.row_group = row_group; a.row_gap = row_gap; a.row_off = row_off;
     a.res_mod = res_mod; a.res_off = res_off;
     a.tiles_n = (N + BN - 1) / BN;
+    static const int dbg = [] { const char* e = getenv("CFSAR_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // variant: 0 = auto, 1 = v1 (128x128, 2-stage, compiler-managed LDS-DMA), 2 = p3 (256x128, 3-stage, asm LDS-DMA)
+    static const int forced = [] { const char* e = getenv("CFSAR_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+    const bool use_p3 = forced == 2 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
+    if (use_p3) {
+        int rc;
+        if (in_dtype == CFSAR_BF16)
+            rc = out_dtype == CFSAR_BF16 ? launch_p3<__bf16, __bf16>(a, s) : launch_p3<__bf16, float>(a, s);
+        else
+            rc = out_dtype == CFSAR_BF16 ? launch_p3<float, __bf16>(a, s) : launch_p3<float, float>(a, s);
+        if (rc != -2) return rc;
+    }
     if (in_dtype == CFSAR_BF16)
         return out_dtype == CFSAR_BF16 ? launch<__bf16, __bf16>(a, s) : launch<__bf16, float>(a, s);
     return out_dtype == CFSAR_BF16 ? launch<float, __bf16>(a, s) : launch<float, float>(a, s);

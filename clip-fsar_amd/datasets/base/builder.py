@@ -1,0 +1,65 @@
+"""build_loader(cfg, split) (reference datasets/base/builder.py:47-94) for the synthetic episode dataset.
+
+The reference's loader yields the 7-key episode dict with a leading batch dim of 1 per GPU
+(TEST.BATCH_SIZE / NUM_GPUS = 1) which the test loop strips (runs/test_net_few_shot.py:59-62).  This loader yields
+the same dict with a leading dim of ``cfg.TEST.EPISODES_PER_STEP`` (default 1) episodes, for the static shard
+{e : e % world == rank} of a seed-indexed episode list."""
+import torch
+
+from ... import synth
+from ...utils import distributed as du
+from ...utils.registry import Registry
+
+DATASET_REGISTRY = Registry("DATASET")
+
+
+@DATASET_REGISTRY.register()
+class Synthetic_few_shot(torch.utils.data.Dataset):
+    """Deterministic structured episodes (clip_fsar_amd.synth.make_episode) in the layout of
+    Ssv2_few_shot.__getitem__ (reference datasets/base/ssv2_few_shot.py:275-285)."""
+
+    def __init__(self, cfg, split):
+        self.cfg = cfg
+        self.split = split
+        self.num = int(cfg.TRAIN.NUM_TEST_TASKS)
+        arch = synth.ARCHS[cfg.VIDEO.HEAD.BACKBONE_NAME]
+        self.res = int(getattr(cfg.DATA, "TEST_CROP_SIZE", arch["res"]))
+        self.shot = int(getattr(cfg.TRAIN, "SHOT_TEST", getattr(cfg.TRAIN, "SHOT", 1)))
+        self.qpc = int(getattr(cfg.TRAIN, "QUERY_PER_CLASS_TEST", getattr(cfg.TRAIN, "QUERY_PER_CLASS", 1)))
+
+    def __len__(self):
+        return self.num
+
+    def __getitem__(self, index):
+        cfg = self.cfg
+        ep = synth.make_episode(way=int(cfg.TRAIN.WAY), shot=self.shot, query_per_class=self.qpc,
+                                frames=int(cfg.DATA.NUM_INPUT_FRAMES), res=self.res,
+                                n_test_classes=len(cfg.TEST.CLASS_NAME), episode=int(index),
+                                seed=int(getattr(cfg, "RANDOM_SEED", 18)))
+        return {k: torch.from_numpy(v) for k, v in ep.items()}
+
+
+def build_dataset(name, cfg, split):
+    cls = DATASET_REGISTRY.get(name)
+    if cls is None:
+        raise KeyError("dataset %r is not registered (only the synthetic episode dataset is built; the video decode "
+                       "pipeline is SURVEY.md 8(f) N2)" % name)
+    return cls(cfg, split)
+
+
+def build_loader(cfg, split):
+    assert split in ("test", "val", "train")
+    name = getattr(cfg.TEST, "DATASET", "Synthetic_few_shot")
+    if name in ("Ssv2_few_shot", "Kinetics_few_shot"):
+        name = "Synthetic_few_shot"                       # no video files exist here: same contract, synthetic frames
+    ds = build_dataset(name, cfg, split)
+    idx = du.shard_episodes(len(ds))
+    sub = torch.utils.data.Subset(ds, idx)
+    bs = int(getattr(cfg.TEST, "EPISODES_PER_STEP", 1))
+    return torch.utils.data.DataLoader(sub, batch_size=bs, shuffle=False,
+                                       num_workers=int(getattr(getattr(cfg, "DATA_LOADER", None), "NUM_WORKERS", 0) or 0),
+                                       drop_last=False)
+
+
+def shuffle_dataset(loader, cur_epoch):
+    pass    # episodes are a fixed seed-indexed list

@@ -1,0 +1,93 @@
+"""test_epoch / test_few_shot with the reference's names and flow (reference runs/test_net_few_shot.py:36-305),
+re-designed for sharded inference:
+
+  * the loader yields `EPISODES_PER_STEP` episodes per step for this rank's static shard of the episode list;
+  * `model(task_dict)` is the same call as reference :109 (BaseVideoModel -> Identity -> CNN_OTAM_CLIPFSAR);
+  * loss / top-1 / top-5 per episode stay on the GPU; nothing is synchronised per episode.  The reference's three
+    scalar all-reduces + `.item()` per episode (:168-178) become ONE all-gather of the [episodes, 3] stats matrix
+    after the loop (utils.distributed.gather_episode_stats), then the ValMeter is fed in episode order;
+  * per-class accuracy tallies (:148-160) are computed from the gathered predictions on the master.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..datasets.base.builder import build_loader
+from ..models.base.builder import build_model
+from ..utils import checkpoint as cu
+from ..utils import distributed as du
+from ..utils import logging
+from ..utils import metrics
+from ..utils import misc
+from ..utils.meters import ValMeter
+
+logger = logging.get_logger(__name__)
+
+
+@torch.no_grad()
+def test_epoch(val_loader, model, val_meter, cur_epoch, cfg, writer=None):
+    model.eval()
+    val_meter.iter_tic()
+    dev = torch.device("cuda", torch.cuda.current_device()) if misc.get_num_gpus(cfg) else torch.device("cpu")
+    stats, preds_all, real_all, lab_all = [], [], [], []
+    n_local = 0
+    for cur_iter, task_dict in enumerate(val_loader):
+        if n_local >= cfg.TRAIN.NUM_TEST_TASKS:
+            break
+        if misc.get_num_gpus(cfg):
+            task_dict = {k: v.cuda(non_blocking=True) for k, v in task_dict.items()}
+        model_dict = model(task_dict)
+        logits = model_dict["logits"]                                  # [B, Q, way]
+        labels = task_dict["target_labels"]
+        B, Q, way = logits.shape
+        flat, flab = logits.reshape(B * Q, way), labels.reshape(B * Q).long()
+        loss = F.cross_entropy(flat, flab, reduction="none").reshape(B, Q).mean(1) / cfg.TRAIN.BATCH_SIZE
+        _, idx = torch.topk(flat, min(5, way), dim=1)
+        hit = idx.eq(flab.unsqueeze(1))
+        top1 = (1.0 - hit[:, :1].any(1).float().reshape(B, Q).mean(1)) * 100.0
+        top5 = (1.0 - hit.any(1).float().reshape(B, Q).mean(1)) * 100.0
+        stats.append(torch.stack([loss, top1, top5], dim=1))
+        preds_all.append(idx[:, 0].reshape(B, Q))
+        real_all.append(task_dict["real_target_labels"].reshape(B, Q))
+        lab_all.append(labels.reshape(B, Q))
+        n_local += B
+    total = min(int(cfg.TRAIN.NUM_TEST_TASKS), du.get_world_size() * max(n_local, 0) if du.get_world_size() > 1 else n_local)
+    local = torch.cat(stats) if stats else torch.zeros(0, 3, device=dev)
+    extra = torch.cat([torch.cat(preds_all).float(), torch.cat(real_all).float(), torch.cat(lab_all).float()], dim=1) \
+        if stats else torch.zeros(0, 3, device=dev)
+    num_eps = int(getattr(val_loader.dataset, "dataset", val_loader.dataset).__len__()) if du.get_world_size() > 1 else n_local
+    num_eps = min(num_eps, int(cfg.TRAIN.NUM_TEST_TASKS))
+    allstats = du.gather_episode_stats(torch.cat([local, extra], dim=1), num_eps).cpu()     # the ONE collective
+    val_meter.iter_toc()
+    Q = (allstats.shape[1] - 3) // 3
+    top1_per_class, num_per_class = {}, {}
+    for e in range(allstats.shape[0]):
+        val_meter.update_stats(float(allstats[e, 1]), float(allstats[e, 2]), 1)
+        pred, real, lab = allstats[e, 3:3 + Q], allstats[e, 3 + Q:3 + 2 * Q], allstats[e, 3 + 2 * Q:3 + 3 * Q]
+        for qi in range(Q):
+            key = str(float(real[qi]))
+            num_per_class[key] = num_per_class.get(key, 0) + 1
+            top1_per_class[key] = top1_per_class.get(key, 0) + int(pred[qi] == lab[qi])
+        val_meter.log_iter_stats(cur_epoch, e)
+    epoch_stats = val_meter.log_epoch_stats(cur_epoch)
+    if du.is_master_proc():
+        for c in sorted(top1_per_class):
+            logger.info("class: {}, acc: {}".format(c, top1_per_class[c] / num_per_class[c]))
+    acc = 100.0 - allstats[:, 1]
+    result = {"episodes": int(allstats.shape[0]), "top1_acc": float(acc.mean()) if len(acc) else float("nan"),
+              "top1_acc_ci95": float(1.96 * acc.std(unbiased=False) / max(len(acc), 1) ** 0.5) if len(acc) else float("nan"),
+              "loss": float(allstats[:, 0].mean()) if len(acc) else float("nan"), "epoch_stats": epoch_stats}
+    val_meter.reset()
+    return result
+
+
+def test_few_shot(cfg):
+    du.init_distributed_training(cfg)
+    np.random.seed(cfg.RANDOM_SEED)
+    torch.manual_seed(cfg.RANDOM_SEED)
+    logging.setup_logging(cfg, getattr(cfg.TEST, "LOG_FILE", None))
+    model, model_ema = build_model(cfg)
+    cu.load_test_checkpoint(cfg, model, model_ema, None)
+    val_loader = build_loader(cfg, "test")
+    val_meter = ValMeter(len(val_loader), cfg)
+    return test_epoch(val_loader, model, val_meter, 0, cfg, None)
