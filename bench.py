@@ -77,30 +77,42 @@ class GemmTimer:
         return ms, self.flops, self.launches
 
 
-def cpu_baseline(sample_episodes: int = 3):
-    """Oracle (kind "port") on the host cores, bounded sample of the same workload."""
+def cpu_baseline(sample_episodes: int = 2):
+    """Oracle (kind "port") on the host cores of this box, bounded sample of the same workload (~15-25 s of CPU work).
+
+    torch's intra-op pool does not scale on this path beyond a few tens of threads (on the 256-thread GPU-box host
+    128 threads are 6x SLOWER than 16), so the thread count is calibrated first on a 4-frame ViT pass and the best
+    candidate is used and reported as `cores`."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import clipfsar_oracle as orc
     a = synth.ARCHS[ARCH]
     sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(ARCH, SEED).items()}
     tt = torch.from_numpy(synth.text_features(N_TRAIN, a["embed"], "train", SEED))
     te = torch.from_numpy(synth.text_features(N_TEST, a["embed"], "test", SEED))
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    times = []
+    ncpu = os.cpu_count() or 1
+    ep0 = {k: torch.from_numpy(v) for k, v in synth.make_episode(WAY, SHOT, QPC, T, a["res"], N_TEST, 0, SEED).items()}
+    best_t, best_dt = 1, float("inf")
     with torch.no_grad():
-        for e in range(sample_episodes + 1):
+        for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+            torch.set_num_threads(th)
+            orc.vit_forward(ep0["support_set"][:2], sd, a)                      # warm the pool
+            t0 = time.perf_counter()
+            orc.vit_forward(ep0["support_set"][:4], sd, a)
+            dt = time.perf_counter() - t0
+            if dt < best_dt:
+                best_t, best_dt = th, dt
+        torch.set_num_threads(best_t)
+        times = []
+        for e in range(sample_episodes):
             ep = {k: torch.from_numpy(v) for k, v in synth.make_episode(WAY, SHOT, QPC, T, a["res"], N_TEST, e, SEED).items()}
             t0 = time.perf_counter()
             orc.head_forward(ep, sd, tt, te, a, frames=T)
-            dt = time.perf_counter() - t0
-            if e > 0:                              # first episode = warm-up
-                times.append(dt)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(1.0 / med, 4), "unit": "episodes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "torch-fp32 CPU oracle, 1 warm-up + %d timed cfg2 episodes (5-way 1-shot, 8x224^2 frames, "
-                      "ViT-B/16), median %.2f s/episode" % (sample_episodes, med)}
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "episodes/s", "cores": best_t, "kind": "port",
+            "sample": "torch-fp32 CPU oracle (restatement of the reference path), %d timed cfg2 episodes (5-way 1-shot, "
+                      "8x224^2 frames, ViT-B/16) after a thread-count calibration pass; %d of %d host threads used; "
+                      "median %.2f s/episode" % (sample_episodes, best_t, ncpu, med)}
 
 
 def main():
