@@ -18,8 +18,11 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 //   only a summation index: k-slot (g, j<4) <-> key 32kb+4g+j, (g, j>=4) <-> key 32kb+16+4g+(j-4); V^T fragments are
 //   read from LDS with the same key permutation.  No P round trip through LDS, no cross-lane data movement.
 // ------------------------------------------------------------------------------------------------------------
-template <int NKB>   // number of 32-key blocks (7 -> up to 224 keys, 9 -> up to 288 keys)
-__global__ __launch_bounds__(256) void vit_attn_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
+// NKB = number of 32-key blocks (7 -> up to 224 keys, 9 -> up to 288 keys); NTV = number of 16-key tiles that hold at
+// least one real key when known at compile time (13 for 197 tokens, 17 for 257), 0 = generic (all tiles, all masked).
+constexpr int ATT_THREADS = 512;   // 8 waves share one staged (frame, head); 2 workgroups per CU (LDS) = 4 waves/SIMD
+template <int NKB, int NTV>
+__global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
                                                             int ntok, int D, float scale_log2e) {
     constexpr int NP = NKB * 32;
     constexpr int NT = NKB * 2;                                    // 16-key tiles
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(256) void vit_attn_bf16_kernel(const __bf16* __rest
     const __bf16* base = qkv + (size_t)f * ntok * ld + h * 64;
 
     // ---- stage K (swizzled rows) : NP*8 16-byte chunks
-    for (int idx = tid; idx < NP * 8; idx += 256) {
+    for (int idx = tid; idx < NP * 8; idx += ATT_THREADS) {
         const int r = idx >> 3, pc = idx & 7;
         const int c = pc ^ swz(r);
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(256) void vit_attn_bf16_kernel(const __bf16* __rest
         *reinterpret_cast<uint4*>(sK + r * 128 + pc * 16) = v;
     }
     // ---- stage V^T: thread takes keys (2kp, 2kp+1) x 8 d values, writes 8 packed bf16 pairs
-    for (int idx = tid; idx < (NP / 2) * 8; idx += 256) {
+    for (int idx = tid; idx < (NP / 2) * 8; idx += ATT_THREADS) {
         const int kp = idx % (NP / 2), dc = idx / (NP / 2);
         uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
         if (2 * kp < ntok) v0 = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp) * ld + 2 * D + dc * 8);
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(256) void vit_attn_bf16_kernel(const __bf16* __rest
 
     const int q16 = lane & 15, g = lane >> 4;
     const int nqt = (ntok + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    constexpr int nt_valid = NTV > 0 ? NTV : NKB * 2;   // 16-key tiles that are computed
+    for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
         int qrow = qt * 16 + q16;
         const bool qvalid = qrow < ntok;
         if (!qvalid) qrow = ntok - 1;
@@ -71,43 +75,51 @@ __global__ __launch_bounds__(256) void vit_attn_bf16_kernel(const __bf16* __rest
         for (int ks = 0; ks < 2; ++ks)
             qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + ks * 32 + g * 8);
 
-        // S^T tiles
+        // S^T tiles (tiles that hold only padded keys are skipped; their probabilities are 0)
         f32x4 s[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int kr = j * 16 + q16;   // key row this lane reads for the "A" operand
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (j < nt_valid) {
+                const int kr = j * 16 + q16;   // key row this lane reads for the "A" operand
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kr * 128 + (((ks * 4 + g) ^ swz(kr)) << 4));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kr * 128 + (((ks * 4 + g) ^ swz(kr)) << 4));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
+                }
             }
             s[j] = acc;
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the K-fragment live ranges (no spills)
         }
-        // mask padded keys, row max
+        // mask the padded keys of the last (partial) tile, row max over keys (in-lane, then across the 4 lane groups)
         float mx = -1e30f;
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) {
+            if (NTV == 0 || j == nt_valid - 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = j * 16 + g * 4 + r;
-                if (key >= ntok) s[j][r] = -1e30f;
-                mx = fmaxf(mx, s[j][r]);
+                for (int r = 0; r < 4; ++r)
+                    if (j * 16 + g * 4 + r >= ntok) s[j][r] = -1e30f;
             }
+            if (j < nt_valid) mx = fmaxf(fmaxf(mx, fmaxf(s[j][0], s[j][1])), fmaxf(s[j][2], s[j][3]));
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mxs = mx * scale_log2e;
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) {
+            if (j < nt_valid) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = exp2f((s[j][r] - mx) * scale_log2e);
-                s[j][r] = pv;
-                sum += pv;
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[j][r], scale_log2e, -mxs));   // raw v_exp_f32
+                    s[j][r] = pv;
+                    sum += pv;
+                }
             }
+        }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
 
         // O^T = V^T . P^T
         f32x4 o[4];
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(256) void vit_attn_bf16_kernel(const __bf16* __rest
                 const uint4 packed = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, packed), pf, o[dt], 0, 0, 0);
             }
+            if (kb & 1) __builtin_amdgcn_sched_barrier(0);
         }
         // O^T[d][q]: lane owns query q16, d = 16dt + 4g + r
         if (qvalid) {
@@ -195,20 +208,20 @@ __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float* __restri
     }
 }
 
-template <int NKB>
+template <int NKB, int NTV>
 int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
     constexpr int NP = NKB * 32;
     constexpr int VT_STRIDE = ((NP * 2 + 255) / 256) * 256 + 16;
     constexpr int LDS = NP * 128 + 64 * VT_STRIDE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<NKB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<NKB, NTV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return cfsar_fail("cfsar_vit_attention: set LDS size: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const float scale_log2e = 0.125f * 1.4426950408889634f;
-    hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB>), dim3(heads, F), dim3(256), LDS, s,
+    hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB, NTV>), dim3(heads, F), dim3(ATT_THREADS), LDS, s,
                        static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e);
     return cfsar_check_launch("cfsar_vit_attention(bf16)");
 }
@@ -224,8 +237,10 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == CFSAR_BF16) {
         CFSAR_REQUIRE(ntok <= 288, "cfsar_vit_attention: ntok=%d > 288", ntok);
-        if (ntok <= 224) return launch_bf16<7>(qkv, out, F, ntok, D, heads, s);
-        return launch_bf16<9>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197) return launch_bf16<7, 13>(qkv, out, F, ntok, D, heads, s);     // ViT-B/16 @224
+        if (ntok == 257) return launch_bf16<9, 17>(qkv, out, F, ntok, D, heads, s);     // ViT-L/14 @224
+        if (ntok <= 224) return launch_bf16<7, 0>(qkv, out, F, ntok, D, heads, s);
+        return launch_bf16<9, 0>(qkv, out, F, ntok, D, heads, s);
     }
     if (dtype == CFSAR_F32) {
         const int lds = ntok * 64 * 4 * 2;

@@ -139,7 +139,7 @@ __device__ __forceinline__ void mma_slice(f32x16 (&acc)[2][2], const char* sX, c
 constexpr int EPI_RS = 272;                     // staged row: 64 fp32 + 16 B pad (conflict-free b128 writes)
 constexpr int EPI_WAVE_BYTES = 64 * EPI_RS;     // 17408 B per wave
 template <typename TO, int ACT, bool HAS_RES, bool REMAP, bool FULL>
-__device__ __forceinline__ void epilogue_lds(f32x16 (&acc)[2][2], const GemmArgs& p, int mbase, int nbase, int lane,
+__device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p, int mbase, int nbase, int lane,
                                              char* wbuf) {
     const int lr = lane & 31, hi = lane >> 5;
     const int rsub = lane >> 4, cc = lane & 15;
@@ -225,6 +225,7 @@ __device__ __forceinline__ void mma_slice_db(f32x16 (&acc)[2][2], const char* sX
                 wf[nxt][i] = *reinterpret_cast<const uint4*>(sW + offW[i] + ((c ^ sxW[i]) << 4));
             }
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the next sub-step's reads AHEAD of this sub-step's MFMAs
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -471,14 +472,15 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
     }
     __syncthreads();                 // every wave is done with the ring: reuse it as per-wave transpose buffers
     const int mb = m0 + wm * 64, nb = n0 + wn * 64;
+    f32x16 (*accp)[2] = acc;
     if (p.dbg & 4) {
         if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3];
         return;
     }
     if (mb + 64 <= p.M && nb + 64 <= p.N)
-        epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(acc, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+        epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
     else
-        epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(acc, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+        epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
 }
 
 template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
@@ -521,6 +523,338 @@ int launch_p3(const GemmArgs& a0, hipStream_t s) {
     }
 }
 
+// ============================================================================================================
+// v3 ("p4"): 256(M) x 256(N) tile, 512 threads (8 waves as 2(M) x 4(N), each wave 128 x 64 = 4x2 MFMA 32x32 tiles,
+// 128 accumulator VGPRs).  K in 64-byte slices (32 bf16) through a FOUR-stage LDS ring (4 x 32 KiB) filled by asm
+// LDS-DMA running three slices ahead (counted vmcnt).  Versus p3 this moves 1/3 fewer bytes global->LDS and 1/4 fewer
+// bytes LDS->VGPR per MFMA.  64-byte LDS rows: chunk ^= (row>>2)&3 keeps ds_read_b128 conflict-free.
+// ============================================================================================================
+constexpr int BM4 = 256;
+constexpr int BN4 = 256;
+constexpr int ROWB4 = 64;
+constexpr int STAGE4 = (BM4 + BN4) * ROWB4;   // 32 KiB
+constexpr int NSTAGE4 = 4;
+constexpr int LDS4 = 8 * EPI_WAVE_BYTES > NSTAGE4 * STAGE4 ? 8 * EPI_WAVE_BYTES : NSTAGE4 * STAGE4;   // 139264 B
+
+__device__ __forceinline__ int swz4(int row) { return (row >> 2) & 3; }
+
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
+__global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p4(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BK = ROWB4 / (int)sizeof(TI);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+    const int m0 = tm * BM4, n0 = tn * BN4;
+
+    // staging: each operand tile = 16 instructions of 16 rows x 64 B; wave w issues instructions {w, w+8} of X and of W
+    const char* srcX[2];
+    const char* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 8 + wave) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ swz4(row);
+        int gm = ((p.dbg & 8) ? 0 : m0) + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        int gn = ((p.dbg & 8) ? 0 : n0) + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
+        srcW[i] = p.W + ((size_t)gn * p.ldw) * sizeof(TI) + chunk * 16;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+    auto issue = [&](int stage, int kt) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)stage * (unsigned)STAGE4);
+        const size_t koff = (size_t)kt * ROWB4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_asm(srcX[i] + koff, base + i * 8192);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_asm(srcW[i] + koff, base + BM4 * ROWB4 + i * 8192);
+    };
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lr = lane & 31, hi = lane >> 5;
+    int offX[4], offW[2], sxX[4], sxW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rx = wm * 128 + i * 32 + lr;
+        offX[i] = rx * ROWB4;
+        sxX[i] = swz4(rx);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rw = wn * 64 + i * 32 + lr;
+        offW[i] = BM4 * ROWB4 + rw * ROWB4;
+        sxW[i] = swz4(rw);
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.K / BK;
+    // Fragments of slice kt+1 are read from LDS (into the other register set) while the MFMAs of slice kt execute, so
+    // no MFMA ever waits for LDS latency behind a barrier.  Invariant at the barrier of step kt: slices <= kt+1 have
+    // landed for every wave (each wave leaves only its share of slice kt+2 in flight: vmcnt(4)); slice kt+3 is then
+    // issued into the stage of slice kt-1, whose fragments were consumed one step ago.
+    auto load_frags = [&](int kt, uint4 (&xf)[2][4], uint4 (&wf)[2][2]) {
+        const char* base = smem + (kt & 3) * STAGE4;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xf[s2][i] = *reinterpret_cast<const uint4*>(base + offX[i] + (((2 * s2 + hi) ^ sxX[i]) << 4));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                wf[s2][i] = *reinterpret_cast<const uint4*>(base + offW[i] + (((2 * s2 + hi) ^ sxW[i]) << 4));
+        }
+    };
+    auto mma = [&](uint4 (&xf)[2][4], uint4 (&wf)[2][2]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if constexpr (sizeof(TI) == 2) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s2][ni]),
+                                                                              __builtin_bit_cast(bf16x8, xf[s2][mi]),
+                                                                              acc[mi][ni], 0, 0, 0);
+                    } else {
+                        const f32x4 a = __builtin_bit_cast(f32x4, wf[s2][ni]);
+                        const f32x4 bb = __builtin_bit_cast(f32x4, xf[s2][mi]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bb[j], acc[mi][ni], 0, 0, 0);
+                    }
+                }
+    };
+    auto step = [&](int kt, uint4 (&xc)[2][4], uint4 (&wc)[2][2], uint4 (&xn)[2][4], uint4 (&wn_)[2][2]) {
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 3 < nk) issue((kt + 3) & 3, kt + 3);
+        if (kt + 1 < nk) load_frags(kt + 1, xn, wn_);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xc, wc);
+    };
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint4 xfA[2][4], wfA[2][2], xfB[2][4], wfB[2][2];
+    load_frags(0, xfA, wfA);
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, xfA, wfA, xfB, wfB);
+        if (kt + 1 < nk) step(kt + 1, xfB, wfB, xfA, wfA);
+    }
+    __syncthreads();
+    char* wbuf = smem + wave * EPI_WAVE_BYTES;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 64;
+        if (mb + 64 <= p.M && nb + 64 <= p.N)
+            epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
+        else
+            epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
+    }
+}
+
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
+int launch_p4_inst(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p4<TI, TO, ACT, HAS_RES, REMAP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tiles_m = (a.M + BM4 - 1) / BM4;
+    hipLaunchKernelGGL((gemm_kernel_p4<TI, TO, ACT, HAS_RES, REMAP>), dim3(tiles_m * a.tiles_n), dim3(NTHREADS2), LDS4, s, a);
+    return cfsar_check_launch("cfsar_gemm(p4)");
+}
+
+// bf16 only, the shapes of the ViT blocks
+template <typename TO>
+int launch_p4(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_n = (a.N + BN4 - 1) / BN4;
+    const bool r = a.res != nullptr;
+    if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF) return -2;
+    if (a.act == CFSAR_ACT_QUICKGELU)
+        return r ? -2 : launch_p4_inst<__bf16, TO, CFSAR_ACT_QUICKGELU, false, false>(a, s);
+    return r ? launch_p4_inst<__bf16, TO, CFSAR_ACT_NONE, true, false>(a, s)
+             : launch_p4_inst<__bf16, TO, CFSAR_ACT_NONE, false, false>(a, s);
+}
+
+// ============================================================================================================
+// v4 ("p5"): 256(M) x 128(N) tile, 256 threads (4 waves as 2x2, each wave 128 x 64 = 4x2 MFMA tiles), 64-byte K
+// slices, THREE-stage ring of 24 KiB (72 KiB per workgroup) -> TWO independent workgroups per CU.  The two workgroups
+// drift out of phase, so one workgroup's pipeline fill / epilogue (no MFMA) overlaps the other's main loop -- the
+// serialisation that caps the one-workgroup-per-CU kernels (p3/p4) on the short-K (768) GEMMs of the ViT.
+// ============================================================================================================
+constexpr int BM5 = 256;
+constexpr int BN5 = 128;
+constexpr int STAGE5 = (BM5 + BN5) * ROWB4;   // 24 KiB
+constexpr int NSTAGE5 = 3;
+constexpr int LDS5 = NSTAGE5 * STAGE5;        // 73728 B  (>= 4 * EPI_WAVE_BYTES = 69632)
+
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_p5(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BK = ROWB4 / (int)sizeof(TI);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+    const int m0 = tm * BM5, n0 = tn * BN5;
+
+    // staging: X tile = 16 instructions of 16 rows x 64 B, W tile = 8; wave w issues X {w, w+4, w+8, w+12}, W {w, w+4}
+    const char* srcX[4];
+    const char* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 4 + wave) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ swz4(row);
+        int gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 4 + wave) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ swz4(row);
+        int gn = n0 + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        srcW[i] = p.W + ((size_t)gn * p.ldw) * sizeof(TI) + chunk * 16;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+    auto issue = [&](int stage, int kt) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)stage * (unsigned)STAGE5);
+        const size_t koff = (size_t)kt * ROWB4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_asm(srcX[i] + koff, base + i * 4096);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_asm(srcW[i] + koff, base + BM5 * ROWB4 + i * 4096);
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, hi = lane >> 5;
+    int offX[4], offW[2], sxX[4], sxW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rx = wm * 128 + i * 32 + lr;
+        offX[i] = rx * ROWB4;
+        sxX[i] = swz4(rx);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rw = wn * 64 + i * 32 + lr;
+        offW[i] = BM5 * ROWB4 + rw * ROWB4;
+        sxW[i] = swz4(rw);
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.K / BK;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int st2 = st + 2;
+        st2 = st2 >= NSTAGE5 ? st2 - NSTAGE5 : st2;
+        if (kt + 2 < nk) issue(st2, kt + 2);
+        const char* base = smem + st * STAGE5;
+        uint4 xf[2][4], wf[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[0][i] = *reinterpret_cast<const uint4*>(base + offX[i] + ((hi ^ sxX[i]) << 4));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[0][i] = *reinterpret_cast<const uint4*>(base + offW[i] + ((hi ^ sxW[i]) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[1][i] = *reinterpret_cast<const uint4*>(base + offX[i] + (((2 + hi) ^ sxX[i]) << 4));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[1][i] = *reinterpret_cast<const uint4*>(base + offW[i] + (((2 + hi) ^ sxW[i]) << 4));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if constexpr (sizeof(TI) == 2) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s2][ni]),
+                                                                              __builtin_bit_cast(bf16x8, xf[s2][mi]),
+                                                                              acc[mi][ni], 0, 0, 0);
+                    } else {
+                        const f32x4 a = __builtin_bit_cast(f32x4, wf[s2][ni]);
+                        const f32x4 bb = __builtin_bit_cast(f32x4, xf[s2][mi]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bb[j], acc[mi][ni], 0, 0, 0);
+                    }
+                }
+        st = st + 1 >= NSTAGE5 ? 0 : st + 1;
+    }
+    __syncthreads();
+    char* wbuf = smem + wave * EPI_WAVE_BYTES;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 64;
+        if (mb + 64 <= p.M && nb + 64 <= p.N)
+            epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
+        else
+            epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
+    }
+}
+
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
+int launch_p5_inst(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p5<TI, TO, ACT, HAS_RES, REMAP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
+        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tiles_m = (a.M + BM5 - 1) / BM5;
+    hipLaunchKernelGGL((gemm_kernel_p5<TI, TO, ACT, HAS_RES, REMAP>), dim3(tiles_m * a.tiles_n), dim3(256), LDS5, s, a);
+    return cfsar_check_launch("cfsar_gemm(p5)");
+}
+
+template <typename TO>
+int launch_p5(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_n = (a.N + BN5 - 1) / BN5;
+    const bool r = a.res != nullptr;
+    if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF) return -2;
+    if (a.act == CFSAR_ACT_QUICKGELU)
+        return r ? -2 : launch_p5_inst<__bf16, TO, CFSAR_ACT_QUICKGELU, false, false>(a, s);
+    return r ? launch_p5_inst<__bf16, TO, CFSAR_ACT_NONE, true, false>(a, s)
+             : launch_p5_inst<__bf16, TO, CFSAR_ACT_NONE, false, false>(a, s);
+}
+
 }  // namespace
 
 extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* bias, const float* residual, int M,
@@ -556,7 +890,18 @@ extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     // variant: 0 = auto, 1 = v1 (128x128, 2-stage, compiler-managed LDS-DMA), 2 = p3 (256x128, 3-stage, asm LDS-DMA)
     static const int forced = [] { const char* e = getenv("CFSAR_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
-    const bool use_p3 = forced == 2 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
+    // p4 needs enough 256x256 tiles to fill the 256 CUs for >= 2 rounds
+    const long tiles4 = (long)((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
+    const bool use_p4 = in_dtype == CFSAR_BF16 && (forced == 3 || (forced == 0 && tiles4 >= 512));
+    if (use_p4) {
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p4<__bf16>(a, s) : launch_p4<float>(a, s);
+        if (rc != -2) return rc;
+    }
+    if (in_dtype == CFSAR_BF16 && forced == 4) {
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p5<__bf16>(a, s) : launch_p5<float>(a, s);
+        if (rc != -2) return rc;
+    }
+    const bool use_p3 = forced == 2 || forced == 3 || forced == 4 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
     if (use_p3) {
         int rc;
         if (in_dtype == CFSAR_BF16)
