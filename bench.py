@@ -77,6 +77,21 @@ class GemmTimer:
         return ms, self.flops, self.launches
 
 
+def measured_traffic(episodes_per_step):
+    """HBM bytes per bf16-GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
+    runs, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md; tools/collect_profiles.sh).  PMC collection
+    cannot run inside the timed bench, so the value is read from profiles/ and only reported when it was measured at the
+    same episodes-per-step; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+    try:
+        d = json.load(open(path))["_all_bf16_gemm"]
+        if "--episodes-per-step %d" % episodes_per_step in d["note"]:
+            return round(d["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(sample_episodes: int = 2):
     """Oracle (kind "port") on the host cores of this box, bounded sample of the same workload (~15-25 s of CPU work).
 
@@ -118,9 +133,9 @@ def cpu_baseline(sample_episodes: int = 2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--episodes-per-step", type=int, default=4)
+    ap.add_argument("--episodes-per-step", type=int, default=8)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic episodes resident in HBM per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -216,7 +231,8 @@ def main():
             ms, flops, n = timer.result()
             achieved = flops / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                               "traffic": measured_traffic(B),
                                "kernel": "gemm_kernel<bf16> (QKV / out_proj / c_fc / c_proj / patch-embed)",
                                "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                                "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3)}

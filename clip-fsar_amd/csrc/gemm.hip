@@ -38,6 +38,7 @@ struct GemmArgs {
     int act;
     int row_group, row_gap, row_off, res_mod, res_off;
     int tiles_n;
+    int stagger;   // p4: first-round phase offset in units of s_sleep(127) (~4 us)
     int dbg;   // ablation bits (env CFSAR_GEMM_DEBUG): 1 = no in-loop DMA, 2 = no in-loop barrier, 4 = no epilogue
 };
 
@@ -199,6 +200,61 @@ __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p
             } else {
                 *reinterpret_cast<float4*>(outp + ooff[it]) = make_float4(v[0], v[1], v[2], v[3]);
             }
+        }
+    }
+}
+
+// ---- bf16-output epilogue without residual (QKV, c_fc): bias + activation are applied in registers (the lane owns 4
+// consecutive columns), the result is packed to bf16 BEFORE the LDS transpose (half the LDS traffic), and each lane
+// then stores 16 bytes: 8 lanes cover one 128-byte row segment, 8 rows per wave-instruction.
+// Measured on MI355X (r01): not faster than the fp32-staged path (QKV 326 vs 322 us, c_fc 434 vs 415 us at M = 63040):
+// the epilogue is bound by the store drain, not by LDS traffic.  Kept for the next round's persistent-tile kernel.
+constexpr bool kBf16PackedEpilogue = false;
+constexpr int EPI_RS16 = 144;                    // staged row: 64 bf16 + 16 B pad (keeps ds_read_b128 16-byte aligned)
+template <int ACT, bool FULL>
+__device__ __forceinline__ void epilogue_lds_bf16(f32x16 (*acc)[2], const GemmArgs& p, int mbase, int nbase, int lane,
+                                                  char* wbuf) {
+    const int lr = lane & 31, hi = lane >> 5;
+    const int M = p.M, N = p.N, ldo = p.ldo;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = ni * 32 + 8 * g + 4 * hi;                 // column inside the 64-wide wave tile
+            int n = nbase + cl;
+            n = n < N ? n : N - 4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                float v[4] = {acc[mi][ni][4 * g] + bv.x, acc[mi][ni][4 * g + 1] + bv.y, acc[mi][ni][4 * g + 2] + bv.z,
+                              acc[mi][ni][4 * g + 3] + bv.w};
+                if constexpr (ACT != CFSAR_ACT_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], ACT);
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+                *reinterpret_cast<bf16x4*>(wbuf + (mi * 32 + lr) * EPI_RS16 + cl * 2) = o;
+            }
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int rsub = lane >> 3, cc = lane & 7;
+    const int n = nbase + cc * 8;
+    __bf16* outp = reinterpret_cast<__bf16*>(p.out);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + rsub;
+        const int m = mbase + row;
+        const uint4 a = *reinterpret_cast<const uint4*>(wbuf + row * EPI_RS16 + cc * 16);
+        if (FULL || (m < M && n + 8 <= N))
+            *reinterpret_cast<uint4*>(outp + (size_t)(m + p.row_off) * ldo + n) = a;
+        else if (m < M) {                                            // ragged right edge (N % 8 == 4)
+            const unsigned w[4] = {a.x, a.y, a.z, a.w};
+            for (int j = 0; j < 8; ++j)
+                if (n + j < N) reinterpret_cast<unsigned short*>(outp)[(size_t)(m + p.row_off) * ldo + n + j] =
+                    (unsigned short)(w[j >> 1] >> ((j & 1) * 16));
         }
     }
 }
@@ -477,10 +533,14 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
         if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3];
         return;
     }
-    if (mb + 64 <= p.M && nb + 64 <= p.N)
-        epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
-    else
-        epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+    const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
+    if constexpr (kBf16PackedEpilogue && sizeof(TO) == 2 && !HAS_RES && !REMAP) {
+        if (full) epilogue_lds_bf16<ACT, true>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+        else epilogue_lds_bf16<ACT, false>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+    } else {
+        if (full) epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+        else epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+    }
 }
 
 template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
@@ -600,6 +660,12 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p4(GemmArgs p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int nk = p.K / BK;
+    // Phase stagger: the workgroups of the first round start together and would stay in lockstep for the whole launch
+    // (same work per tile), so every CU would hit its store-only epilogue -- an HBM write burst with idle MFMA pipes --
+    // at the same moment.  Half of the first-round workgroups therefore start `stagger` x ~4 us late; later rounds
+    // inherit the offset because a workgroup is dispatched when its predecessor on that CU retires.
+    if (p.stagger > 0 && b < 256 && ((b >> 3) & 1))
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     // Fragments of slice kt+1 are read from LDS (into the other register set) while the MFMAs of slice kt execute, so
     // no MFMA ever waits for LDS latency behind a barrier.  Invariant at the barrier of step kt: slices <= kt+1 have
     // landed for every wave (each wave leaves only its share of slice kt+2 in flight: vmcnt(4)); slice kt+3 is then
@@ -639,9 +705,9 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p4(GemmArgs p) {
     auto step = [&](int kt, uint4 (&xc)[2][4], uint4 (&wc)[2][2], uint4 (&xn)[2][4], uint4 (&wn_)[2][2]) {
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 3 < nk) issue((kt + 3) & 3, kt + 3);
-        if (kt + 1 < nk) load_frags(kt + 1, xn, wn_);
+        if (!(p.dbg & 2)) __syncthreads();
+        if (kt + 3 < nk && !(p.dbg & 1)) issue((kt + 3) & 3, kt + 3);
+        if (kt + 1 < nk && !(p.dbg & 16)) load_frags(kt + 1, xn, wn_);
         __builtin_amdgcn_sched_barrier(0);
         mma(xc, wc);
     };
@@ -659,14 +725,22 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p4(GemmArgs p) {
         if (kt + 1 < nk) step(kt + 1, xfB, wfB, xfA, wfA);
     }
     __syncthreads();
+    if (p.dbg & 4) {
+        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[3][1][2] + acc[2][0][1];
+        return;
+    }
     char* wbuf = smem + wave * EPI_WAVE_BYTES;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 64;
-        if (mb + 64 <= p.M && nb + 64 <= p.N)
-            epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
-        else
-            epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
+        const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
+        if constexpr (kBf16PackedEpilogue && sizeof(TO) == 2 && !HAS_RES && !REMAP) {
+            if (full) epilogue_lds_bf16<ACT, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
+            else epilogue_lds_bf16<ACT, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
+        } else {
+            if (full) epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
+            else epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
+        }
     }
 }
 
@@ -822,10 +896,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_p5(GemmArgs p) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 64;
-        if (mb + 64 <= p.M && nb + 64 <= p.N)
-            epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
-        else
-            epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
+        const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
+        if constexpr (kBf16PackedEpilogue && sizeof(TO) == 2 && !HAS_RES && !REMAP) {
+            if (full) epilogue_lds_bf16<ACT, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
+            else epilogue_lds_bf16<ACT, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
+        } else {
+            if (full) epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
+            else epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
+        }
     }
 }
 
@@ -887,6 +965,8 @@ extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* 
     a.tiles_n = (N + BN - 1) / BN;
     static const int dbg = [] { const char* e = getenv("CFSAR_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
+    static const int stag = [] { const char* e = getenv("CFSAR_GEMM_STAGGER"); return e ? atoi(e) : -1; }();
+    a.stagger = stag;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // variant: 0 = auto, 1 = v1 (128x128, 2-stage, compiler-managed LDS-DMA), 2 = p3 (256x128, 3-stage, asm LDS-DMA)
     static const int forced = [] { const char* e = getenv("CFSAR_GEMM_VARIANT"); return e ? atoi(e) : 0; }();

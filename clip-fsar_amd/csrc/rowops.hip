@@ -51,60 +51,96 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ x, co
 }
 
 // ---- A3 LayerNorm: one wave per row, row held in registers (<= 16 float4 per lane), two-pass statistics in fp32,
-// wavefront-shuffle reductions, vectorised 16-byte loads / 8- or 16-byte stores.
+// wavefront-shuffle reductions, vectorised 16-byte loads / 8- or 16-byte stores.  Each wave handles RPW rows at once so
+// that 2x the loads are in flight per wave (the kernel is HBM-bound: 4 B in + 2 B out per element in bf16 mode).
 constexpr int LN_MAXV = 16;
-template <typename TO>
+template <typename TO, int NV, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long in_stride,
                                                         TO* __restrict__ out, long long out_stride,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + (long long)row * in_stride;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
     const int nv = D >> 2;   // float4 count
-    float4 v[LN_MAXV];
-    float s = 0.f;
+    float4 v[RPW][NV];
+    float s[RPW];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int j = i * 64 + lane;
-        if (j < nv) {
-            v[i] = *reinterpret_cast<const float4*>(xr + 4 * j);
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r < rows ? row0 + r : rows - 1;
+        const float* xr = x + (long long)row * in_stride;
+        s[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int j = i * 64 + lane;
+            if (j < nv) v[r][i] = *reinterpret_cast<const float4*>(xr + 4 * j);
         }
     }
-    const float mean = wave_sum(s) / (float)D;
-    float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int r = 0; r < RPW; ++r) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (i * 64 + lane < nv) s[r] += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+    }
+    float4 wv[NV], bv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
         const int j = i * 64 + lane;
         if (j < nv) {
-            const float a = v[i].x - mean, bq = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-            ss += (a * a + bq * bq) + (c * c + d * d);
+            wv[i] = *reinterpret_cast<const float4*>(w + 4 * j);
+            bv[i] = *reinterpret_cast<const float4*>(b + 4 * j);
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
-    TO* orow = out + (long long)row * out_stride;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int j = i * 64 + lane;
-        if (j < nv) {
-            const float4 wv = *reinterpret_cast<const float4*>(w + 4 * j);
-            const float4 bv = *reinterpret_cast<const float4*>(b + 4 * j);
-            float4 o;
-            o.x = (v[i].x - mean) * rstd * wv.x + bv.x;
-            o.y = (v[i].y - mean) * rstd * wv.y + bv.y;
-            o.z = (v[i].z - mean) * rstd * wv.z + bv.z;
-            o.w = (v[i].w - mean) * rstd * wv.w + bv.w;
-            if constexpr (sizeof(TO) == 2) {
-                bf16x4 ob;
-                ob[0] = (__bf16)o.x; ob[1] = (__bf16)o.y; ob[2] = (__bf16)o.z; ob[3] = (__bf16)o.w;
-                *reinterpret_cast<bf16x4*>(orow + 4 * j) = ob;
-            } else {
-                *reinterpret_cast<float4*>(orow + 4 * j) = o;
+    for (int r = 0; r < RPW; ++r) {
+        const float mean = wave_sum(s[r]) / (float)D;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (i * 64 + lane < nv) {
+                const float a = v[r][i].x - mean, bq = v[r][i].y - mean, c = v[r][i].z - mean, d = v[r][i].w - mean;
+                ss += (a * a + bq * bq) + (c * c + d * d);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+        if (row0 + r >= rows) continue;
+        TO* orow = out + (long long)(row0 + r) * out_stride;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int j = i * 64 + lane;
+            if (j < nv) {
+                float4 o;
+                o.x = (v[r][i].x - mean) * rstd * wv[i].x + bv[i].x;
+                o.y = (v[r][i].y - mean) * rstd * wv[i].y + bv[i].y;
+                o.z = (v[r][i].z - mean) * rstd * wv[i].z + bv[i].z;
+                o.w = (v[r][i].w - mean) * rstd * wv[i].w + bv[i].w;
+                if constexpr (sizeof(TO) == 2) {
+                    bf16x4 ob;
+                    ob[0] = (__bf16)o.x; ob[1] = (__bf16)o.y; ob[2] = (__bf16)o.z; ob[3] = (__bf16)o.w;
+                    *reinterpret_cast<bf16x4*>(orow + 4 * j) = ob;
+                } else {
+                    *reinterpret_cast<float4*>(orow + 4 * j) = o;
+                }
             }
         }
     }
+}
+
+template <typename TO>
+int launch_ln(const float* x, long long in_stride, TO* out, long long out_stride, const float* w, const float* b, int rows,
+              int D, float eps, hipStream_t s) {
+    const int nvl = (D / 4 + 63) / 64;          // float4 per lane
+#define CFSAR_LN(NV, RPW)                                                                                             \
+    hipLaunchKernelGGL((layernorm_kernel<TO, NV, RPW>), dim3((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), dim3(256), 0, \
+                       s, x, in_stride, out, out_stride, w, b, rows, D, eps)
+    if (nvl <= 1) CFSAR_LN(1, 4);
+    else if (nvl <= 2) CFSAR_LN(2, 2);
+    else if (nvl <= 3) CFSAR_LN(3, 2);
+    else if (nvl <= 4) CFSAR_LN(4, 2);
+    else if (nvl <= 8) CFSAR_LN(8, 1);
+    else CFSAR_LN(16, 1);
+#undef CFSAR_LN
+    return cfsar_check_launch("cfsar_layernorm");
 }
 
 }  // namespace
@@ -146,15 +182,12 @@ extern "C" int cfsar_layernorm(const float* x, int64_t in_stride, void* out, int
     CFSAR_REQUIRE(x && out && weight && bias, "cfsar_layernorm: null pointer");
     CFSAR_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4 * 64 * LN_MAXV, "cfsar_layernorm: bad D=%d", D);
     CFSAR_REQUIRE(in_stride % 4 == 0 && out_stride % 4 == 0, "cfsar_layernorm: strides must be multiples of 4");
-    const unsigned blocks = (unsigned)((rows + 3) / 4);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (out_dtype == CFSAR_BF16)
-        hipLaunchKernelGGL((layernorm_kernel<__bf16>), dim3(blocks), dim3(256), 0, s, x, (long long)in_stride,
-                           static_cast<__bf16*>(out), (long long)out_stride, weight, bias, rows, D, eps);
-    else if (out_dtype == CFSAR_F32)
-        hipLaunchKernelGGL((layernorm_kernel<float>), dim3(blocks), dim3(256), 0, s, x, (long long)in_stride,
-                           static_cast<float*>(out), (long long)out_stride, weight, bias, rows, D, eps);
-    else
-        return cfsar_fail("cfsar_layernorm: bad dtype %d", out_dtype);
-    return cfsar_check_launch("cfsar_layernorm");
+        return launch_ln<__bf16>(x, (long long)in_stride, static_cast<__bf16*>(out), (long long)out_stride, weight, bias,
+                                 rows, D, eps, s);
+    if (out_dtype == CFSAR_F32)
+        return launch_ln<float>(x, (long long)in_stride, static_cast<float*>(out), (long long)out_stride, weight, bias, rows,
+                                D, eps, s);
+    return cfsar_fail("cfsar_layernorm: bad dtype %d", out_dtype);
 }

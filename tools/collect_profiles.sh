@@ -1,0 +1,41 @@
+#!/bin/bash
+# GPU box: rocprofv3 kernel-trace stats + the two PMC passes (FETCH_SIZE, WRITE_SIZE separately: TCC slots) for the
+# bench command; summaries land in gpurun_out/ and are copied to profiles/ by hand.
+set -u
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+CMD="python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-events"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
+python tools/trace_summary.py $OUT/trace/t_kernel_trace.csv 0 > $OUT/kernel_summary.txt
+cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- $CMD > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- $CMD > $OUT/write.log 2>&1
+python - <<PY
+import csv, json, collections, re
+def agg(path, counter):
+    rows = list(csv.DictReader(open(path)))
+    d = collections.defaultdict(list)
+    for r in rows:
+        if r["Counter_Name"] != counter: continue
+        n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        d[n.split("(")[0][:80]].append(float(r["Counter_Value"]))
+    return d
+f = agg("$OUT/fetch/p_counter_collection.csv", "FETCH_SIZE")
+w = agg("$OUT/write/p_counter_collection.csv", "WRITE_SIZE")
+out = {}
+tot_f = tot_w = n = 0
+for k in f:
+    if "gemm_kernel_p" not in k: continue
+    # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM)
+    fb = sum(f[k]) * 1024 * 2
+    wb = sum(w.get(k, [0])) * 1024
+    out[k] = {"launches": len(f[k]), "fetch_bytes_per_launch": fb / len(f[k]), "write_bytes_per_launch": wb / max(len(w.get(k, [1])), 1)}
+    tot_f += fb; tot_w += wb; n += len(f[k])
+out["_all_bf16_gemm"] = {"launches": n, "hbm_bytes_per_launch": (tot_f + tot_w) / max(n, 1),
+                         "note": "FETCH_SIZE*1024*2 (gfx950 correction) + WRITE_SIZE*1024, separate --pmc passes, bench.py --episodes-per-step 8"}
+json.dump(out, open("$OUT/gemm_traffic.json", "w"), indent=1)
+print(json.dumps(out["_all_bf16_gemm"]))
+PY
+cat $OUT/kernel_summary.txt

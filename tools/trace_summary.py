@@ -8,7 +8,11 @@ agg = collections.OrderedDict()
 busy = 0
 for r in rows:
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    n = r["Kernel_Name"].split("(")[0][-70:]
+    n = r["Kernel_Name"]
+    import re
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    n = n.split("(")[0][:90]
     a = agg.setdefault(n, [0, 0])
     a[0] += 1; a[1] += d
     busy += d
