@@ -709,7 +709,7 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p4(GemmArgs p) {
         if (kt + 3 < nk && !(p.dbg & 1)) issue((kt + 3) & 3, kt + 3);
         if (kt + 1 < nk && !(p.dbg & 16)) load_frags(kt + 1, xn, wn_);
         __builtin_amdgcn_sched_barrier(0);
-        mma(xc, wc);
+        if (!(p.dbg & 32)) mma(xc, wc);
     };
     issue(0, 0);
     if (nk > 1) issue(1, 1);
@@ -723,6 +723,158 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p4(GemmArgs p) {
     for (int kt = 0; kt < nk; kt += 2) {
         step(kt, xfA, wfA, xfB, wfB);
         if (kt + 1 < nk) step(kt + 1, xfB, wfB, xfA, wfA);
+    }
+    __syncthreads();
+    if (p.dbg & 4) {
+        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[3][1][2] + acc[2][0][1];
+        return;
+    }
+    char* wbuf = smem + wave * EPI_WAVE_BYTES;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 64;
+        const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
+        if constexpr (kBf16PackedEpilogue && sizeof(TO) == 2 && !HAS_RES && !REMAP) {
+            if (full) epilogue_lds_bf16<ACT, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
+            else epilogue_lds_bf16<ACT, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
+        } else {
+            if (full) epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
+            else epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
+        }
+    }
+}
+
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
+__global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p6(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BK = ROWB4 / (int)sizeof(TI);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+    const int m0 = tm * BM4, n0 = tn * BN4;
+
+    // staging: each operand tile = 16 instructions of 16 rows x 64 B; wave w issues instructions {w, w+8} of X and of W
+    const char* srcX[2];
+    const char* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 8 + wave) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ swz4(row);
+        int gm = ((p.dbg & 8) ? 0 : m0) + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        int gn = ((p.dbg & 8) ? 0 : n0) + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
+        srcW[i] = p.W + ((size_t)gn * p.ldw) * sizeof(TI) + chunk * 16;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+    auto issue = [&](int stage, int kt) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)stage * (unsigned)STAGE4);
+        const size_t koff = (size_t)kt * ROWB4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_asm(srcX[i] + koff, base + i * 8192);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_asm(srcW[i] + koff, base + BM4 * ROWB4 + i * 8192);
+    };
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lr = lane & 31, hi = lane >> 5;
+    int offX[4], offW[2], sxX[4], sxW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rx = wm * 128 + i * 32 + lr;
+        offX[i] = rx * ROWB4;
+        sxX[i] = swz4(rx);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rw = wn * 64 + i * 32 + lr;
+        offW[i] = BM4 * ROWB4 + rw * ROWB4;
+        sxW[i] = swz4(rw);
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.K / BK;
+    // ---- ping-pong schedule.  Waves 0-3 (group A, top 128 rows) and 4-7 (group B, bottom 128 rows) share the four SIMDs
+    // pairwise (wave w and w+4).  Every wave alternates a MEMORY phase (12 ds_read_b128 of slice j's fragments + its 4
+    // LDS-DMA issues for slice j+3 + counted waits) and a COMPUTE phase (16 MFMAs), separated by s_barrier; group B runs
+    // one barrier behind group A, so on each SIMD one wave feeds the matrix pipe while its partner does LDS/DMA work.
+    // Barrier G(2j) .. G(2j+1): A memory j | B compute j-1;   G(2j+1) .. G(2j+2): A compute j | B memory j.
+    // Invariants (4 stages, DMA distance 3): a wave ends memory phase j only when its own DMA share of slice j+1 has
+    // landed (vmcnt(8) leaves slices j+2, j+3 in flight), so after G(2j) every share of slice j is in LDS for A's reads
+    // and after G(2j+1) for B's; slice j+3 overwrites the stage of slice j-1, last read by B before G(2j).
+    const bool grpB = wave >= 4;
+    uint4 xf[2][4], wf[2][2];
+    auto mem_phase = [&](int j) {
+        const char* base = smem + (j & 3) * STAGE4;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xf[s2][i] = *reinterpret_cast<const uint4*>(base + offX[i] + (((2 * s2 + hi) ^ sxX[i]) << 4));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                wf[s2][i] = *reinterpret_cast<const uint4*>(base + offW[i] + (((2 * s2 + hi) ^ sxW[i]) << 4));
+        }
+        if (j + 3 < nk) {
+            issue((j + 3) & 3, j + 3);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (j + 2 < nk) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute_phase = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s2][ni]),
+                                                                          __builtin_bit_cast(bf16x8, xf[s2][mi]),
+                                                                          acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // G0: slice 0 is in LDS for everyone
+    __builtin_amdgcn_sched_barrier(0);
+    if (grpB) {
+        __builtin_amdgcn_s_barrier();                  // group B starts one barrier late
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int j = 0; j < nk; ++j) {
+        mem_phase(j);
+        compute_phase();
+    }
+    if (!grpB) {
+        __builtin_amdgcn_s_barrier();                  // group A absorbs the stagger
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     if (p.dbg & 4) {
@@ -769,6 +921,32 @@ int launch_p4(const GemmArgs& a0, hipStream_t s) {
         return r ? -2 : launch_p4_inst<__bf16, TO, CFSAR_ACT_QUICKGELU, false, false>(a, s);
     return r ? launch_p4_inst<__bf16, TO, CFSAR_ACT_NONE, true, false>(a, s)
              : launch_p4_inst<__bf16, TO, CFSAR_ACT_NONE, false, false>(a, s);
+}
+
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
+int launch_p6_inst(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p6<TI, TO, ACT, HAS_RES, REMAP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tiles_m = (a.M + BM4 - 1) / BM4;
+    hipLaunchKernelGGL((gemm_kernel_p6<TI, TO, ACT, HAS_RES, REMAP>), dim3(tiles_m * a.tiles_n), dim3(NTHREADS2), LDS4, s, a);
+    return cfsar_check_launch("cfsar_gemm(p6)");
+}
+
+template <typename TO>
+int launch_p6(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_n = (a.N + BN4 - 1) / BN4;
+    const bool r = a.res != nullptr;
+    if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF) return -2;
+    if (a.act == CFSAR_ACT_QUICKGELU)
+        return r ? -2 : launch_p6_inst<__bf16, TO, CFSAR_ACT_QUICKGELU, false, false>(a, s);
+    return r ? launch_p6_inst<__bf16, TO, CFSAR_ACT_NONE, true, false>(a, s)
+             : launch_p6_inst<__bf16, TO, CFSAR_ACT_NONE, false, false>(a, s);
 }
 
 // ============================================================================================================
@@ -972,7 +1150,13 @@ extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* 
     static const int forced = [] { const char* e = getenv("CFSAR_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
     // p4 needs enough 256x256 tiles to fill the 256 CUs for >= 2 rounds
     const long tiles4 = (long)((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
-    const bool use_p4 = in_dtype == CFSAR_BF16 && (forced == 3 || (forced == 0 && tiles4 >= 512));
+    // variants: 1 = v1 (128x128), 2 = p3 (256x128, 3-stage), 3 = p4 (256x256, 4-stage), 4 = p5 (256x128, 2 WG/CU),
+    // 6 = p6 (256x256 ping-pong).  auto: p6 when >= 2 rounds of 256x256 tiles exist, else p3 / v1.
+    if (in_dtype == CFSAR_BF16 && (forced == 6 || (forced == 0 && tiles4 >= 512))) {
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p6<__bf16>(a, s) : launch_p6<float>(a, s);
+        if (rc != -2) return rc;
+    }
+    const bool use_p4 = in_dtype == CFSAR_BF16 && (forced == 3 || forced == 6 || (forced == 0 && tiles4 >= 512));
     if (use_p4) {
         const int rc = out_dtype == CFSAR_BF16 ? launch_p4<__bf16>(a, s) : launch_p4<float>(a, s);
         if (rc != -2) return rc;
@@ -981,7 +1165,7 @@ extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* 
         const int rc = out_dtype == CFSAR_BF16 ? launch_p5<__bf16>(a, s) : launch_p5<float>(a, s);
         if (rc != -2) return rc;
     }
-    const bool use_p3 = forced == 2 || forced == 3 || forced == 4 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
+    const bool use_p3 = forced == 2 || forced == 3 || forced == 4 || forced == 6 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
     if (use_p3) {
         int rc;
         if (in_dtype == CFSAR_BF16)
