@@ -51,7 +51,7 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_dst) {
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == CFSAR_ACT_QUICKGELU)     // x * sigmoid(1.702 x); v_exp_f32 + v_rcp_f32 (1 ulp each)
-        return v * __builtin_amdgcn_rcpf(1.0f + exp2f(-1.702f * 1.4426950408889634f * v));
+        return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
     if (act == CFSAR_ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     return v;
 }

@@ -123,54 +123,80 @@ __global__ __launch_bounds__(128) void build_sequences_kernel(const float* __res
     }
 }
 
-// ---- A11 attention on short sequences (few_shot.py:1056-1073).  One wave per (sequence, head).
-__global__ __launch_bounds__(64) void seq_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                           int n_a, int len_a, int n_b, int len_b, int heads, int hd,
-                                                           float scale) {
+// ---- A11 attention on short sequences (few_shot.py:1056-1073); with causal != 0 it is also the masked attention of
+// the CLIP text transformer (N1: few_shot.py:778-784 additive -inf mask above the diagonal).  One 128-thread workgroup
+// per (sequence, head); thread i owns query position i (len <= 128).
+__global__ __launch_bounds__(128) void seq_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                            int n_a, int len_a, int n_b, int len_b, int heads, int hd,
+                                                            float scale, int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int seq = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int seq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
     int start, L;
     if (seq < n_a) { start = seq * len_a; L = len_a; }
     else { start = n_a * len_a + (seq - n_a) * len_b; L = len_b; }
     const int inner = heads * hd;
     const size_t ld = (size_t)3 * inner;
-    float* sq = reinterpret_cast<float*>(smem);      // [L][hd]
-    float* sk = sq + L * hd;
-    float* sv = sk + L * hd;
-    float* sp = sv + L * hd;                         // [L][L] probabilities
-    for (int idx = lane; idx < L * hd; idx += 64) {
+    const int hp = hd + 1;                           // padded row: conflict-free column walks
+    float* sq = reinterpret_cast<float*>(smem);      // [L][hp]
+    float* sk = sq + L * hp;
+    float* sv = sk + L * hp;
+    float* sp = sv + L * hp;                         // [L][L+1] probabilities
+    const int lp = L + 1;
+    for (int idx = tid; idx < L * hd; idx += 128) {
         const int i = idx / hd, d = idx - i * hd;
         const float* rowp = qkv + (size_t)(start + i) * ld + h * hd + d;
-        sq[idx] = rowp[0];
-        sk[idx] = rowp[inner];
-        sv[idx] = rowp[2 * inner];
+        sq[i * hp + d] = rowp[0];
+        sk[i * hp + d] = rowp[inner];
+        sv[i * hp + d] = rowp[2 * inner];
     }
     __syncthreads();
-    if (lane < L) {                                   // lane = query position i
+    if (tid < L) {                                    // thread = query position i
+        const int jmax = causal ? tid + 1 : L;
         float mx = -1e30f;
-        for (int j = 0; j < L; ++j) {
+        for (int j = 0; j < jmax; ++j) {
             float dot = 0.f;
-            for (int d = 0; d < hd; ++d) dot = fmaf(sq[lane * hd + d], sk[j * hd + d], dot);
+            for (int d = 0; d < hd; ++d) dot = fmaf(sq[tid * hp + d], sk[j * hp + d], dot);
             dot *= scale;
-            sp[lane * L + j] = dot;
+            sp[tid * lp + j] = dot;
             mx = fmaxf(mx, dot);
         }
         float sum = 0.f;
-        for (int j = 0; j < L; ++j) {
-            const float e = expf(sp[lane * L + j] - mx);
-            sp[lane * L + j] = e;
+        for (int j = 0; j < jmax; ++j) {
+            const float e = expf(sp[tid * lp + j] - mx);
+            sp[tid * lp + j] = e;
             sum += e;
         }
         const float inv = 1.0f / sum;
-        for (int j = 0; j < L; ++j) sp[lane * L + j] *= inv;
+        for (int j = 0; j < jmax; ++j) sp[tid * lp + j] *= inv;
+        for (int j = jmax; j < L; ++j) sp[tid * lp + j] = 0.f;
     }
     __syncthreads();
-    for (int idx = lane; idx < L * hd; idx += 64) {
+    for (int idx = tid; idx < L * hd; idx += 128) {
         const int i = idx / hd, d = idx - i * hd;
+        const int jmax = causal ? i + 1 : L;
         float a = 0.f;
-        for (int j = 0; j < L; ++j) a = fmaf(sp[i * L + j], sv[j * hd + d], a);
+        for (int j = 0; j < jmax; ++j) a = fmaf(sp[i * lp + j], sv[j * hp + d], a);
         out[(size_t)(start + i) * inner + h * hd + d] = a;
     }
+}
+
+// ---- N1 token embedding + positional embedding (few_shot.py:794-796) and row gather (EOT pooling, :804)
+__global__ __launch_bounds__(128) void embed_tokens_kernel(const int* __restrict__ tokens, const float* __restrict__ table,
+                                                           const float* __restrict__ pos, float* __restrict__ out, int L,
+                                                           int W, int vocab) {
+    const int row = blockIdx.x;                       // (sequence, position)
+    int t = tokens[row];
+    t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+    const float* e = table + (size_t)t * W;
+    const float* pe = pos + (size_t)(row % L) * W;
+    for (int d = threadIdx.x; d < W; d += 128) out[(size_t)row * W + d] = e[d] + pe[d];
+}
+
+__global__ __launch_bounds__(128) void gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ idx,
+                                                          float* __restrict__ out, int D, int rows_in) {
+    int r = idx[blockIdx.x];
+    r = r < 0 ? 0 : (r >= rows_in ? rows_in - 1 : r);
+    for (int d = threadIdx.x; d < D; d += 128) out[(size_t)blockIdx.x * D + d] = x[(size_t)r * D + d];
 }
 
 // ---- A12 prototypes (few_shot.py:2956-2962).  One workgroup per (b, class, t).
@@ -308,12 +334,13 @@ extern "C" int cfsar_build_sequences(const float* feats, const float* text_test,
 }
 
 extern "C" int cfsar_seq_attention(const float* qkv, float* out, int n_a, int len_a, int n_b, int len_b, int heads,
-                                   int head_dim, float scale, cfsar_stream_t stream) {
+                                   int head_dim, float scale, int causal, cfsar_stream_t stream) {
     CFSAR_REQUIRE(qkv && out, "cfsar_seq_attention: null pointer");
     CFSAR_REQUIRE(n_a >= 0 && n_b >= 0 && n_a + n_b > 0 && heads > 0 && head_dim > 0, "cfsar_seq_attention: bad shape");
     const int L = len_a > len_b ? len_a : len_b;
-    CFSAR_REQUIRE(L <= 64 && head_dim <= 128, "cfsar_seq_attention: len=%d (max 64) head_dim=%d (max 128)", L, head_dim);
-    const int lds = (3 * L * head_dim + L * L) * (int)sizeof(float);
+    CFSAR_REQUIRE(L <= 128 && head_dim <= 128, "cfsar_seq_attention: len=%d (max 128) head_dim=%d (max 128)", L, head_dim);
+    const int lds = (3 * L * (head_dim + 1) + L * (L + 1)) * (int)sizeof(float);
+    CFSAR_REQUIRE(lds <= 160 * 1024, "cfsar_seq_attention: len x head_dim too large for LDS");
     static int attr_lds = 48 * 1024;
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&seq_attention_kernel),
@@ -321,9 +348,26 @@ extern "C" int cfsar_seq_attention(const float* qkv, float* out, int n_a, int le
         if (e != hipSuccess) return cfsar_fail("cfsar_seq_attention: set LDS size: %s", hipGetErrorString(e));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(seq_attention_kernel, dim3(n_a + n_b, heads), dim3(64), lds, static_cast<hipStream_t>(stream), qkv,
-                       out, n_a, len_a, n_b, len_b, heads, head_dim, scale);
+    hipLaunchKernelGGL(seq_attention_kernel, dim3(n_a + n_b, heads), dim3(128), lds, static_cast<hipStream_t>(stream), qkv,
+                       out, n_a, len_a, n_b, len_b, heads, head_dim, scale, causal);
     return cfsar_check_launch("cfsar_seq_attention");
+}
+
+extern "C" int cfsar_embed_tokens(const int32_t* tokens, const float* table, const float* pos, float* out, int n_seq,
+                                  int L, int W, int vocab, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(tokens && table && pos && out, "cfsar_embed_tokens: null pointer");
+    CFSAR_REQUIRE(n_seq > 0 && L > 0 && W > 0 && vocab > 0, "cfsar_embed_tokens: bad shape");
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)(n_seq * L)), dim3(128), 0, static_cast<hipStream_t>(stream),
+                       tokens, table, pos, out, L, W, vocab);
+    return cfsar_check_launch("cfsar_embed_tokens");
+}
+
+extern "C" int cfsar_gather_rows(const float* x, const int32_t* idx, float* out, int n, int D, int rows_in,
+                                 cfsar_stream_t stream) {
+    CFSAR_REQUIRE(x && idx && out && n > 0 && D > 0 && rows_in > 0, "cfsar_gather_rows: bad arguments");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(128), 0, static_cast<hipStream_t>(stream), x, idx, out, D,
+                       rows_in);
+    return cfsar_check_launch("cfsar_gather_rows");
 }
 
 extern "C" int cfsar_prototypes(const float* Xs, const float* support_labels, float* protos, int B, int S, int Sp, int T,

@@ -29,7 +29,9 @@ SIGNATURES = {
     "cfsar_vit_attention": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_class_text_logits": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_build_sequences": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p],
-    "cfsar_seq_attention": [_c_p, _c_p] + [_c_int] * 6 + [_c_f, _c_p],
+    "cfsar_seq_attention": [_c_p, _c_p] + [_c_int] * 6 + [_c_f, _c_int, _c_p],
+    "cfsar_embed_tokens": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_gather_rows": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_prototypes": [_c_p, _c_p, _c_p] + [_c_int] * 7 + [_c_p],
     "cfsar_cos_otam_logits": [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_f, _c_int, _c_p],
 }
@@ -147,9 +149,23 @@ def build_sequences(feats, text_test, support_labels, real_support_labels, X, B,
                                        int(bool(merge_before)), _stream()), "cfsar_build_sequences")
 
 
-def seq_attention(qkv, out, n_a, len_a, n_b, len_b, heads, head_dim, scale):
+def seq_attention(qkv, out, n_a, len_a, n_b, len_b, heads, head_dim, scale, causal=False):
     _check(lib().cfsar_seq_attention(_dev(qkv, torch.float32, "qkv"), _dev(out, torch.float32, "out"), n_a, len_a, n_b,
-                                     len_b, heads, head_dim, float(scale), _stream()), "cfsar_seq_attention")
+                                     len_b, heads, head_dim, float(scale), int(bool(causal)), _stream()),
+           "cfsar_seq_attention")
+
+
+def embed_tokens(tokens, table, pos, out):
+    n_seq, L = tokens.shape
+    _check(lib().cfsar_embed_tokens(_dev(tokens, torch.int32, "tokens"), _dev(table, torch.float32, "table"),
+                                    _dev(pos, torch.float32, "pos"), _dev(out, torch.float32, "out"), n_seq, L,
+                                    table.shape[1], table.shape[0], _stream()), "cfsar_embed_tokens")
+
+
+def gather_rows(x, idx, out):
+    _check(lib().cfsar_gather_rows(_dev(x, torch.float32, "x"), _dev(idx, torch.int32, "idx"),
+                                   _dev(out, torch.float32, "out"), idx.shape[0], x.shape[1], x.shape[0], _stream()),
+           "cfsar_gather_rows")
 
 
 def prototypes(Xs, support_labels, protos, B, S, Sp, T, E, way, merge_before):

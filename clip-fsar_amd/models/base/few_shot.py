@@ -97,13 +97,19 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
         self.classification_layer = nn.Sequential()                           # identity (:2732)
         self.scale = nn.Parameter(torch.ones(1), requires_grad=False)         # :2733-2734
 
-        # ---- text tables: plain attributes like the reference (:2714-2728)
+        # ---- text tables: plain attributes like the reference (:2714-2728).  Three sources, in priority order:
+        #   VIDEO.HEAD.TEXT_FEATURES_{TRAIN,TEST}: tensor files [n_cls, E];
+        #   VIDEO.HEAD.TEXT_TOWER: "synthetic" (deterministic random-init tower) or a CLIP state-dict file -> the class
+        #       names are tokenized and encoded by the HIP text encoder (clip_fsar_amd.text, N1) at first GPU use;
+        #   otherwise a deterministic synthetic [n_cls, E] table.
         def table(attr, n, split):
             p = getattr(cfg.VIDEO.HEAD, attr, None)
             if p:
                 t = torch.load(p, map_location="cpu").float()
                 assert t.shape == (n, self.mid_dim), (t.shape, n, self.mid_dim)
                 return t
+            if getattr(cfg.VIDEO.HEAD, "TEXT_TOWER", None):
+                return None                                   # encoded lazily on the device
             return torch.from_numpy(synth.text_features(n, self.mid_dim, split, seed))
 
         self.text_features_train = table("TEXT_FEATURES_TRAIN", len(self.class_real_train), "train")
@@ -111,10 +117,32 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
         self._engine = None
         self._engine_key = None
 
+    def _encode_text_tables(self, device):
+        """few_shot.py:2714-2728: encode_text(tokenize(prompt.format(class))) for the train and test class lists."""
+        from ... import text as ctext
+        cfg = self.args
+        src = cfg.VIDEO.HEAD.TEXT_TOWER
+        seed = int(getattr(cfg, "RANDOM_SEED", 18))
+        if src == "synthetic":
+            tsd = ctext.text_tower_state_dict(width=512 if self.mid_dim == 512 else 768, layers=12, embed=self.mid_dim,
+                                              seed=seed)
+        else:
+            tsd = {k: v for k, v in torch.load(src, map_location="cpu").items() if not k.startswith("visual.")}
+        template = cfg.TEST.PROMPT if (hasattr(cfg.TEST, "PROMPT") and cfg.TEST.PROMPT) else None
+        bpe = getattr(cfg.VIDEO.HEAD, "BPE_PATH", None)
+        tok = ctext.ClipBpeTokenizer(bpe)
+        enc = ctext.HipTextEncoder(tsd, device=device)
+        if self.text_features_train is None:
+            self.text_features_train = enc.encode(tok.tokenize(ctext.prompts(self.class_real_train, template))).cpu()
+        if self.text_features_test is None:
+            self.text_features_test = enc.encode(tok.tokenize(ctext.prompts(self.class_real_test, template))).cpu()
+
     # ------------------------------------------------------------------ engine (device-side packed weights)
     def _get_engine(self, device):
         from ...engine import ClipFsarEngine        # imported lazily: constructing the head needs no GPU
         key = (str(device), self.precision, tuple(p._version for p in self.parameters()))
+        if self.text_features_train is None or self.text_features_test is None:
+            self._encode_text_tables(device)
         if self._engine is None or self._engine_key != key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             self._engine = ClipFsarEngine(self.arch, sd, self.text_features_train, self.text_features_test,

@@ -92,9 +92,18 @@ int cfsar_build_sequences(const float* feats, const float* text_test, const floa
 
 /* ---- A11 attention of Attention_qkv on short sequences (few_shot.py:1056-1073): softmax(q k^T * scale) v per
  * (sequence, head).  qkv [rows, 3*inner] f32 packed [q | k | v]; out [rows, inner].  Sequences: n_a sequences of
- * length len_a starting at row 0, then n_b sequences of length len_b.  len <= 64, head_dim <= 128. */
+ * length len_a starting at row 0, then n_b sequences of length len_b.  len <= 128, head_dim <= 128.
+ * causal != 0: keys j > i are masked (the CLIP text transformer's additive -inf mask, few_shot.py:778-784; N1). */
 int cfsar_seq_attention(const float* qkv, float* out, int n_a, int len_a, int n_b, int len_b, int heads,
-                        int head_dim, float scale, cfsar_stream_t stream);
+                        int head_dim, float scale, int causal, cfsar_stream_t stream);
+
+/* ---- N1 (init-time text tower) token embedding lookup + positional embedding, CLIP.encode_text few_shot.py:794-796.
+ * tokens [n_seq, L] int32, table [vocab, W], pos [L, W] -> out [n_seq*L, W] f32. */
+int cfsar_embed_tokens(const int32_t* tokens, const float* table, const float* pos, float* out, int n_seq, int L, int W,
+                       int vocab, cfsar_stream_t stream);
+
+/* ---- N1 row gather: out[i] = x[idx[i]] (EOT-token pooling x[arange, text.argmax(-1)], few_shot.py:804). */
+int cfsar_gather_rows(const float* x, const int32_t* idx, float* out, int n, int D, int rows_in, cfsar_stream_t stream);
 
 /* ---- A12 prototypes: first T tokens of each support sequence, class-mean over shots unless merged before
  * (few_shot.py:2956-2962).  Xs = support part of the context2 output [B, Sp, T+1, E]; protos [B, way, T, E]. */

@@ -197,3 +197,34 @@ def head_forward(episode, sd, text_train, text_test, arch, frames: int, merge_be
 def top1_correct(logits, target_labels):
     """metrics.topks_correct(...,(1,)) (reference utils/metrics.py:100-138): count of argmax hits."""
     return int((logits.argmax(dim=1) == target_labels.long()).sum())
+
+
+# ------------------------------------------------------------------ N1 CLIP.encode_text (:793-806), causal mask :778-784
+def text_resblock(x, sd, pre: str, heads: int):
+    """ResidualAttentionBlock with the text tower's additive causal mask (-inf above the diagonal)."""
+    n, L, W = x.shape
+    hd = W // heads
+    h = layer_norm(x, sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"])
+    qkv = h @ sd[pre + "attn.in_proj_weight"].t() + sd[pre + "attn.in_proj_bias"]
+    q, k, v = [t.reshape(n, L, heads, hd).transpose(1, 2) for t in qkv.split(W, dim=-1)]
+    mask = torch.full((L, L), float("-inf")).triu_(1)
+    att = torch.softmax((q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(hd)) + mask, dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(n, L, W)
+    x = x + o @ sd[pre + "attn.out_proj.weight"].t() + sd[pre + "attn.out_proj.bias"]
+    h = layer_norm(x, sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"])
+    u = quick_gelu(h @ sd[pre + "mlp.c_fc.weight"].t() + sd[pre + "mlp.c_fc.bias"])
+    return x + u @ sd[pre + "mlp.c_proj.weight"].t() + sd[pre + "mlp.c_proj.bias"]
+
+
+def encode_text(tokens, sd):
+    """tokens [n, L] integer ids -> [n, embed].  token embedding + positional embedding (:794-796), causal transformer,
+    ln_final (:800), features at the position of the largest id = EOT (:804), @ text_projection."""
+    tokens = tokens.long()
+    W = sd["token_embedding.weight"].shape[1]
+    heads = W // 64                                                      # build_model convention (:867)
+    layers = len({k.split(".")[2] for k in sd if k.startswith("transformer.resblocks.")})
+    x = sd["token_embedding.weight"][tokens] + sd["positional_embedding"][: tokens.shape[1]]
+    for i in range(layers):
+        x = text_resblock(x, sd, "transformer.resblocks.%d." % i, heads)
+    x = layer_norm(x, sd["ln_final.weight"], sd["ln_final.bias"])
+    return x[torch.arange(x.shape[0]), tokens.argmax(dim=-1)] @ sd["text_projection"]

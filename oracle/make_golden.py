@@ -154,16 +154,53 @@ def run_known_answers():
     print("known_answers         ok")
 
 
+
+K100_TRAIN = ['air drumming', 'arm wrestling', 'beatboxing', 'biking through snow', 'blowing glass', 'blowing out candles',
+              'bowling', 'breakdancing', 'bungee jumping', 'catching or throwing baseball', 'cheerleading', 'cleaning floor']
+K100_TEST = ['blasting sand', 'busking', 'cutting watermelon', 'dancing ballet', 'dancing charleston', 'dancing macarena',
+             'diving cliff', 'filling eyebrows', 'folding paper', 'hula hooping', 'hurling (sport)', 'ice skating',
+             'paragliding', 'playing drums', 'playing monopoly', 'playing trumpet', 'pushing car', 'riding elephant',
+             'shearing sheep', 'side kick', 'stretching arm', 'tap dancing', 'throwing axe', 'unboxing']
+
+
+def run_text_cases():
+    """N1: tokenizer ids from the reference's tokenize() and CLIP.encode_text outputs of the reference's CLIP class
+    (text tower only matters) with deterministic synthetic text-tower weights."""
+    import clip_fsar_amd.text as ctext
+    fs = rh.import_reference()
+    names = K100_TRAIN + K100_TEST                       # class-name strings from the K100 yaml (config data)
+    texts = ["a photo of {}".format(c) for c in names] + ["Hello, World! it's 2024 -- naive cafe & co.", "x"]
+    tok = fs.tokenize(texts).numpy().astype(np.int32)
+    out = {"texts": json.dumps(texts), "tokens": tok}
+    for tag, (width, layers, embed) in {"small": (128, 2, 64), "b16": (512, 12, 512)}.items():
+        sd = ctext.text_tower_state_dict(width=width, layers=layers, embed=embed, seed=SEED)
+        clip = fs.CLIP(embed_dim=embed, image_resolution=32, vision_layers=1, vision_width=64, vision_patch_size=16,
+                       context_length=77, vocab_size=49408, transformer_width=width, transformer_heads=width // 64,
+                       transformer_layers=layers).float().eval()
+        missing = clip.load_state_dict(rh.to_torch_sd(sd), strict=False)
+        assert all(k.startswith("visual.") or k == "logit_scale" for k in missing.missing_keys), missing.missing_keys
+        with torch.no_grad():
+            feats = clip.encode_text(torch.from_numpy(tok).long())
+        out["feats_" + tag] = feats.numpy()
+        print("text_%-5s            feats std %.3f" % (tag, float(feats.std())))
+    np.savez_compressed(os.path.join(GOLD, "text_cases.npz"), meta=json.dumps(dict(seed=SEED)), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
     ap.add_argument("--skip-large", action="store_true")
+    ap.add_argument("--text-only", action="store_true")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
+    if args.text_only:
+        run_text_cases()
+        return
     if not args.only:
         run_known_answers()
         run_vit_taps()
+        run_text_cases()
     for name, p in HEAD_CASES.items():
         if args.only and name not in args.only:
             continue
