@@ -151,8 +151,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CFSAR_BENCH_FORCE_DIST") == "1"    # the flag exercises the RCCL path at N=1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group(backend="nccl", device_id=dev)       # "nccl" on ROCm == RCCL over xGMI
 
     from clip_fsar_amd import hip
@@ -187,7 +191,7 @@ def main():
     for i in range(args.warmup):
         step(i, acc)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = not args.no_kernel_events
@@ -195,7 +199,7 @@ def main():
     for i in range(args.steps):
         step(i, acc)
     gathered = acc[:args.steps * B]
-    if world > 1:                                                    # the path's single collective
+    if use_dist:                                                     # the path's single collective
         allacc = torch.empty(world * args.steps * B, device=dev)
         dist.all_gather_into_tensor(allacc, gathered.contiguous())
         gathered = allacc
@@ -204,7 +208,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -240,7 +244,7 @@ def main():
             out["roofline"] = None
         out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

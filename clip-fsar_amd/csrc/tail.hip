@@ -199,6 +199,90 @@ __global__ __launch_bounds__(128) void gather_rows_kernel(const float* __restric
     for (int d = threadIdx.x; d < D; d += 128) out[(size_t)blockIdx.x * D + d] = x[(size_t)r * D + d];
 }
 
+// ---- N4 text-matching logits of the EVAL_TEXT / COMBINE eval branches (few_shot.py:2835-2849, 2855-2870):
+// softmax_c( scale * <norm(mean_T target feats), norm(class-mean of text_test[real_support_labels])> ).
+// One workgroup per (b, q); classes in ascending label order.
+__global__ __launch_bounds__(256) void text_match_kernel(const float* __restrict__ feats, const float* __restrict__ text_test,
+                                                         const float* __restrict__ support_labels,
+                                                         const float* __restrict__ real_labels,
+                                                         const float* __restrict__ scale, float* __restrict__ probs, int S,
+                                                         int Q, int T, int E, int way, int n_test) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* img = reinterpret_cast<float*>(smem);           // [E]
+    float* txt = img + E;                                  // [E]
+    __shared__ int rank[MAX_S];
+    __shared__ float red[4];
+    __shared__ float logit[64];
+    const int bq = blockIdx.x, b = bq / Q, q = bq - b * Q;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) label_ranks(support_labels + (size_t)b * S, S, rank);
+    const float* fq = feats + (((size_t)b * (S + Q) + S + q) * T) * E;
+    float ss = 0.f;
+    for (int e = tid; e < E; e += 256) {
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += fq[(size_t)t * E + e];
+        a /= (float)T;
+        img[e] = a;
+        ss += a * a;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float inorm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float* rl = real_labels + (size_t)b * S;
+    for (int c = 0; c < way; ++c) {
+        __syncthreads();
+        int cnt = 0;
+        for (int s = 0; s < S; ++s) cnt += (rank[s] == c);
+        float tt = 0.f, dot = 0.f;
+        for (int e = tid; e < E; e += 256) {
+            float a = 0.f;
+            for (int s = 0; s < S; ++s)
+                if (rank[s] == c) {
+                    int cls = (int)rl[s];
+                    cls = cls < 0 ? 0 : (cls >= n_test ? n_test - 1 : cls);
+                    a += text_test[(size_t)cls * E + e];
+                }
+            a /= (float)cnt;
+            tt += a * a;
+            dot += a * img[e];
+        }
+        tt = wave_sum(tt);
+        dot = wave_sum(dot);
+        __syncthreads();
+        if (lane == 0) { red[wave] = tt; txt[wave] = dot; }
+        __syncthreads();
+        if (tid == 0) {
+            const float tn = sqrtf(red[0] + red[1] + red[2] + red[3]);
+            const float d = txt[0] + txt[1] + txt[2] + txt[3];
+            logit[c] = scale[0] * (d / inorm / tn);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mx = -1e30f, sum = 0.f;
+        for (int c = 0; c < way; ++c) mx = fmaxf(mx, logit[c]);
+        for (int c = 0; c < way; ++c) sum += expf(logit[c] - mx);
+        for (int c = 0; c < way; ++c) probs[(size_t)bq * way + c] = expf(logit[c] - mx) / sum;
+    }
+}
+
+// ---- N4 COMBINE (few_shot.py:2921-2926): -( p_text^coff * softmax_c((8 - cum)/8)^(1-coff) ), cum = -visual logits.
+__global__ __launch_bounds__(64) void combine_kernel(const float* __restrict__ text_probs, const float* __restrict__ vis_logits,
+                                                     float* __restrict__ out, int way, float coff) {
+    const int bq = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const float* p = text_probs + (size_t)bq * way;
+    const float* v = vis_logits + (size_t)bq * way;
+    float mx = -1e30f, sum = 0.f;
+    for (int c = 0; c < way; ++c) mx = fmaxf(mx, (8.0f + v[c]) / 8.0f);          // (8 - cum)/8 with cum = -v
+    for (int c = 0; c < way; ++c) sum += expf((8.0f + v[c]) / 8.0f - mx);
+    for (int c = 0; c < way; ++c) {
+        const float soft = expf((8.0f + v[c]) / 8.0f - mx) / sum;
+        out[(size_t)bq * way + c] = powf(p[c], coff) * powf(soft, 1.0f - coff);   // logits = -cum_dists
+    }
+}
+
 // ---- A12 prototypes (few_shot.py:2956-2962).  One workgroup per (b, class, t).
 __global__ __launch_bounds__(128) void prototypes_kernel(const float* __restrict__ Xs,
                                                          const float* __restrict__ support_labels,
@@ -368,6 +452,27 @@ extern "C" int cfsar_gather_rows(const float* x, const int32_t* idx, float* out,
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(128), 0, static_cast<hipStream_t>(stream), x, idx, out, D,
                        rows_in);
     return cfsar_check_launch("cfsar_gather_rows");
+}
+
+extern "C" int cfsar_text_match_probs(const float* feats, const float* text_test, const float* support_labels,
+                                      const float* real_support_labels, const float* scale, float* probs, int B, int S,
+                                      int Q, int T, int E, int way, int n_test, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(feats && text_test && support_labels && real_support_labels && scale && probs,
+                  "cfsar_text_match_probs: null pointer");
+    CFSAR_REQUIRE(B > 0 && S > 0 && S <= MAX_S && Q > 0 && T > 0 && E > 0 && way > 0 && way <= 64 && n_test > 0,
+                  "cfsar_text_match_probs: bad shape");
+    hipLaunchKernelGGL(text_match_kernel, dim3((unsigned)(B * Q)), dim3(256), 2 * E * sizeof(float),
+                       static_cast<hipStream_t>(stream), feats, text_test, support_labels, real_support_labels, scale, probs, S,
+                       Q, T, E, way, n_test);
+    return cfsar_check_launch("cfsar_text_match_probs");
+}
+
+extern "C" int cfsar_combine_logits(const float* text_probs, const float* visual_logits, float* out, int n_queries, int way,
+                                    float text_coff, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(text_probs && visual_logits && out && n_queries > 0 && way > 0, "cfsar_combine_logits: bad arguments");
+    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)n_queries), dim3(64), 0, static_cast<hipStream_t>(stream), text_probs,
+                       visual_logits, out, way, text_coff);
+    return cfsar_check_launch("cfsar_combine_logits");
 }
 
 extern "C" int cfsar_prototypes(const float* Xs, const float* support_labels, float* protos, int B, int S, int Sp, int T,

@@ -224,7 +224,7 @@ class ClipFsarEngine:
         self.max_frames = max_frames
 
     def forward(self, support_set, target_set, support_labels, real_support_labels, way, T, merge_before=False,
-                single_direct=False, taps=None):
+                single_direct=False, taps=None, mode="otam", text_coff=0.9):
         """support_set [B, S*T, 3, H, W], target_set [B, Q*T, 3, H, W] fp32 device tensors (B may be folded in:
         4-D inputs mean B = 1); labels [B, S] fp32.  Returns (logits [B,Q,way], class_logits [B,S+Q,n_train])."""
         if support_set.dim() == 4:
@@ -244,10 +244,19 @@ class ClipFsarEngine:
             self.vit.forward([sup, tgt], feats2d,
                              row_maps=[(S * T, Q * T, b0 * per_ep), (Q * T, S * T, b0 * per_ep + S * T)],
                              taps=taps if b0 == 0 else None)
-        class_logits = torch.empty(B, S + Q, self.text_train.shape[0], device=self.dev, dtype=torch.float32)
-        hip.class_text_logits(feats, self.text_train, self.scale, class_logits, B * (S + Q), T, E)
         sl = support_labels.to(device=self.dev, dtype=torch.float32).contiguous()
         rl = real_support_labels.to(device=self.dev, dtype=torch.float32).contiguous()
+        if mode in ("eval_text", "combine"):                     # N4: few_shot.py:2835-2852 / :2855-2930
+            probs = torch.empty(B, Q, way, device=self.dev, dtype=torch.float32)
+            hip.text_match_probs(feats, self.text_test, sl, rl, self.scale, probs, B, S, Q, T, E, way)
+            if mode == "eval_text":
+                return probs, None                               # logits = -cum_dists = softmax probs; class_logits None
+            vis = self.temporal.forward(feats, self.text_test, sl, rl, B, S, Q, T, way, merge_before, single_direct)
+            out = torch.empty_like(probs)
+            hip.combine_logits(probs, vis, out, B * Q, way, text_coff)
+            return out, None
+        class_logits = torch.empty(B, S + Q, self.text_train.shape[0], device=self.dev, dtype=torch.float32)
+        hip.class_text_logits(feats, self.text_train, self.scale, class_logits, B * (S + Q), T, E)
         logits = self.temporal.forward(feats, self.text_test, sl, rl, B, S, Q, T, way, merge_before, single_direct,
                                        taps=taps)
         if taps is not None:

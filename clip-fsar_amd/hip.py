@@ -33,6 +33,8 @@ SIGNATURES = {
     "cfsar_embed_tokens": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_gather_rows": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_prototypes": [_c_p, _c_p, _c_p] + [_c_int] * 7 + [_c_p],
+    "cfsar_text_match_probs": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
+    "cfsar_combine_logits": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p],
     "cfsar_cos_otam_logits": [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_f, _c_int, _c_p],
 }
 
@@ -179,3 +181,17 @@ def cos_otam_logits(Xq, protos, logits, B, Q, way, T, E, lbda=0.5, single_direct
                                        _dev(logits, torch.float32, "logits"), _opt(dists_out, torch.float32, "dists_out"),
                                        B, Q, way, T, E, float(lbda), int(bool(single_direct)), _stream()),
            "cfsar_cos_otam_logits")
+
+
+def text_match_probs(feats, text_test, support_labels, real_support_labels, scale, probs, B, S, Q, T, E, way):
+    _check(lib().cfsar_text_match_probs(_dev(feats, torch.float32, "feats"), _dev(text_test, torch.float32, "text_test"),
+                                        _dev(support_labels, torch.float32, "support_labels"),
+                                        _dev(real_support_labels, torch.float32, "real_support_labels"),
+                                        _dev(scale, torch.float32, "scale"), _dev(probs, torch.float32, "probs"), B, S, Q, T,
+                                        E, way, text_test.shape[0], _stream()), "cfsar_text_match_probs")
+
+
+def combine_logits(text_probs, visual_logits, out, n_queries, way, text_coff):
+    _check(lib().cfsar_combine_logits(_dev(text_probs, torch.float32, "text_probs"),
+                                      _dev(visual_logits, torch.float32, "visual_logits"), _dev(out, torch.float32, "out"),
+                                      n_queries, way, float(text_coff), _stream()), "cfsar_combine_logits")

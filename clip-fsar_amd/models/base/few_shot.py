@@ -16,7 +16,8 @@ What differs, by design:
     points at a state-dict file; the CLIP text tower is init-time only and is replaced by a
     synthetic [n_classes, E] table unless cfg.VIDEO.HEAD.TEXT_FEATURES_{TRAIN,TEST} point at tensors;
   * "ViT-L/14" is accepted (extension A16: mid_dim 768, context2 by the same formula :2737-2739);
-  * inference only: the training branch (:2776-2832), EVAL_TEXT (:2835-2852) and COMBINE (:2855-2930) raise;
+  * inference only: the training branch (:2776-2832) raises; the EVAL_TEXT (:2835-2852) and COMBINE (:2855-2930) eval
+    branches are built (N4);
   * a leading episode-batch dimension is accepted (support_set [B, S*T, 3, H, W]); the reference's single-episode
     layout is the B = 1 case;
   * there is no CPU path: forward raises unless the inputs live on a HIP device and libclipfsar_hip.so is built.
@@ -155,8 +156,8 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
         cfg = self.args
         if self.training:
             raise NotImplementedError("CNN_OTAM_CLIPFSAR (HIP): the training branch is out of scope; call .eval()")
-        if _flag(cfg.TRAIN, "EVAL_TEXT") or _flag(cfg.TRAIN, "COMBINE"):
-            raise NotImplementedError("TRAIN.EVAL_TEXT / TRAIN.COMBINE eval branches are not built yet (SURVEY.md N4)")
+        mode = "eval_text" if _flag(cfg.TRAIN, "EVAL_TEXT") else ("combine" if _flag(cfg.TRAIN, "COMBINE") else "otam")
+        text_coff = float(cfg.TRAIN.TEXT_COFF) if _flag(cfg.TRAIN, "TEXT_COFF") else 0.9            # :2923-2926
         support_images, support_labels = inputs["support_set"], inputs["support_labels"]
         target_images, support_real_class = inputs["target_set"], inputs["real_support_labels"]
         if not support_images.is_cuda:
@@ -168,7 +169,8 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
         eng = self._get_engine(support_images.device)
         logits, class_logits = eng.forward(
             support_images.float().contiguous(), target_images.float().contiguous(), support_labels, support_real_class,
-            way=way, T=T, merge_before=_flag(cfg.TRAIN, "MERGE_BEFORE"), single_direct=_flag(cfg.TRAIN, "SINGLE_DIRECT"))
+            way=way, T=T, merge_before=_flag(cfg.TRAIN, "MERGE_BEFORE"), single_direct=_flag(cfg.TRAIN, "SINGLE_DIRECT"),
+            mode=mode, text_coff=text_coff)
         if not batched:
-            logits, class_logits = logits[0], class_logits[0]
+            logits, class_logits = logits[0], (class_logits[0] if class_logits is not None else None)
         return {"logits": logits, "class_logits": class_logits}

@@ -105,6 +105,18 @@ int cfsar_embed_tokens(const int32_t* tokens, const float* table, const float* p
 /* ---- N1 row gather: out[i] = x[idx[i]] (EOT-token pooling x[arange, text.argmax(-1)], few_shot.py:804). */
 int cfsar_gather_rows(const float* x, const int32_t* idx, float* out, int n, int D, int rows_in, cfsar_stream_t stream);
 
+/* ---- N4 EVAL_TEXT branch (few_shot.py:2835-2852) and first half of COMBINE (:2855-2870): per query,
+ * softmax_c(scale * cos(mean_T(target feats), class-mean_c(text_test[real_support_labels]))) with both vectors
+ * L2-normalised (no epsilon), classes in ascending support-label order.  probs [B, Q, way]. */
+int cfsar_text_match_probs(const float* feats, const float* text_test, const float* support_labels,
+                           const float* real_support_labels, const float* scale, float* probs, int B, int S, int Q,
+                           int T, int E, int way, int n_test, cfsar_stream_t stream);
+
+/* ---- N4 COMBINE (few_shot.py:2921-2926): out = p_text^coff * softmax_c((8 - cum)/8)^(1 - coff) with cum = -visual_logits
+ * (out is the reference's `logits` = -cum_dists). */
+int cfsar_combine_logits(const float* text_probs, const float* visual_logits, float* out, int n_queries, int way,
+                         float text_coff, cfsar_stream_t stream);
+
 /* ---- A12 prototypes: first T tokens of each support sequence, class-mean over shots unless merged before
  * (few_shot.py:2956-2962).  Xs = support part of the context2 output [B, Sp, T+1, E]; protos [B, way, T, E]. */
 int cfsar_prototypes(const float* Xs, const float* support_labels, float* protos, int B, int S, int Sp, int T, int E,

@@ -194,6 +194,30 @@ def head_forward(episode, sd, text_train, text_test, arch, frames: int, merge_be
     return {"logits": logits, "class_logits": class_logits}
 
 
+# ------------------------------------------------------------------ N4 EVAL_TEXT (:2835-2852) / COMBINE (:2855-2930)
+def text_match_probs(feats_q, text_test, support_labels, real_support_labels, scale):
+    """feats_q [Q,T,E].  Class-mean of text_test[real labels] in ascending label order, both sides L2-normalised,
+    softmax over classes of scale * cosine (:2836-2849)."""
+    txt, _ = class_means(text_test[real_support_labels.long()], support_labels)
+    img = feats_q.mean(dim=1)
+    img = img / img.norm(dim=1, keepdim=True)
+    txt = txt / txt.norm(dim=1, keepdim=True)
+    return torch.softmax(scale * img @ txt.t(), dim=1)
+
+
+def head_forward_text_modes(episode, sd, text_train, text_test, arch, frames: int, mode: str, merge_before: bool = False,
+                            single_direct: bool = False, depth: int = 1, text_coff: float = 0.9):
+    """mode 'eval_text': logits = softmax probabilities; mode 'combine': p_text^coff * softmax((8-cum)/8)^(1-coff)."""
+    T = frames
+    feats_q = vit_forward(episode["target_set"], sd, arch).reshape(-1, T, arch["embed"])
+    p_text = text_match_probs(feats_q, text_test, episode["support_labels"], episode["real_support_labels"], sd["scale"])
+    if mode == "eval_text":
+        return {"logits": p_text, "class_logits": None}
+    vis = head_forward(episode, sd, text_train, text_test, arch, frames, merge_before, single_direct, depth)["logits"]
+    soft = torch.softmax((8.0 + vis) / 8.0, dim=1)                    # (8 - cum)/8 with cum = -vis (:2921)
+    return {"logits": p_text.pow(text_coff) * soft.pow(1.0 - text_coff), "class_logits": None}
+
+
 def top1_correct(logits, target_labels):
     """metrics.topks_correct(...,(1,)) (reference utils/metrics.py:100-138): count of argmax hits."""
     return int((logits.argmax(dim=1) == target_labels.long()).sum())

@@ -186,6 +186,38 @@ def run_text_cases():
     np.savez_compressed(os.path.join(GOLD, "text_cases.npz"), meta=json.dumps(dict(seed=SEED)), **out)
 
 
+
+TEXT_MODE_CASES = {
+    "n4_evaltext_5w2s_T4": dict(arch="ViT-test/16", way=5, shot=2, q=1, T=4, mode="eval_text"),
+    "n4_combine_5w1s_T8": dict(arch="ViT-test/16", way=5, shot=1, q=1, T=8, mode="combine"),
+    "n4_combine_5w3s_T4_mb_c05": dict(arch="ViT-test/16", way=5, shot=3, q=2, T=4, mode="combine", merge_before=True,
+                                      text_coff=0.5),
+}
+
+
+def run_text_mode_cases():
+    """N4: the EVAL_TEXT and COMBINE eval branches of the reference head (few_shot.py:2835-2930)."""
+    for name, p in TEXT_MODE_CASES.items():
+        a = synth.ARCHS[p["arch"]]
+        sd = synth.head_state_dict(p["arch"], seed=SEED)
+        sd["scale"] = np.asarray([4.0], np.float32)               # non-trivial logit scale (exercises `* self.scale`)
+        tt = synth.text_features(N_TRAIN, a["embed"], "train", SEED)
+        te = synth.text_features(N_TEST, a["embed"], "test", SEED)
+        cfg = rh.make_cfg(p["arch"], way=p["way"], shot=p["shot"], frames=p["T"], n_train=N_TRAIN, n_test=N_TEST,
+                          merge_before=p.get("merge_before", False), eval_text=p["mode"] == "eval_text",
+                          combine=p["mode"] == "combine", text_coff=p.get("text_coff"))
+        head = rh.build_reference_head(cfg, a, sd, tt, te)
+        ep = synth.make_episode(way=p["way"], shot=p["shot"], query_per_class=p["q"], frames=p["T"], res=a["res"],
+                                n_test_classes=N_TEST, episode=0, seed=SEED)
+        with torch.no_grad():
+            out = head(rh.episode_to_torch(ep))
+        assert out["class_logits"] is None
+        meta = dict(p)
+        meta.update(n_train=N_TRAIN, n_test=N_TEST, seed=SEED, episode=0, scale=4.0)
+        np.savez_compressed(os.path.join(GOLD, "head_%s.npz" % name), meta=json.dumps(meta), logits=out["logits"].numpy())
+        print("%-28s logits[%.4f..%.4f]" % (name, out["logits"].min(), out["logits"].max()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -196,6 +228,7 @@ def main():
     torch.set_num_threads(os.cpu_count() or 1)
     if args.text_only:
         run_text_cases()
+        run_text_mode_cases()
         return
     if not args.only:
         run_known_answers()

@@ -77,7 +77,7 @@ def to_torch_sd(sd):
 
 
 def make_cfg(arch="ViT-B/16", way=5, shot=1, frames=8, n_train=64, n_test=24, merge_before=False,
-             depth=None, single_direct=False):
+             depth=None, single_direct=False, eval_text=False, combine=False, text_coff=None):
     """SimpleNamespace tree with exactly the attributes the head reads."""
     train = SimpleNamespace(CLASS_NAME=["train class %d" % i for i in range(n_train)], WAY=way, SHOT=shot,
                             BATCH_SIZE=1)
@@ -87,6 +87,12 @@ def make_cfg(arch="ViT-B/16", way=5, shot=1, frames=8, n_train=64, n_test=24, me
         train.TRANSFORMER_DEPTH = depth
     if single_direct:
         train.SINGLE_DIRECT = True
+    if eval_text:
+        train.EVAL_TEXT = True
+    if combine:
+        train.COMBINE = True
+    if text_coff is not None:
+        train.TEXT_COFF = text_coff
     test = SimpleNamespace(CLASS_NAME=["test class %d" % i for i in range(n_test)])
     return SimpleNamespace(
         VIDEO=SimpleNamespace(HEAD=SimpleNamespace(NAME="CNN_OTAM_CLIPFSAR", BACKBONE_NAME=arch),
