@@ -36,9 +36,19 @@ import clip_fsar_amd.synth as synth  # noqa: E402
 
 ARCH = "ViT-B/16"
 WAY, SHOT, QPC, T = 5, 1, 1, 8
+MERGE_BEFORE = False
 N_TRAIN, N_TEST, SEED = 64, 24, 18
-# algorithmic FLOPs (2 per MAC) of the ViT-B/16 tower per frame and per cfg2 episode (80 frames)
+# algorithmic FLOPs (2 per MAC) of the ViT tower per frame (ViT-B/16: 35.127 G, ViT-L/14: 162.026 G)
 GFLOP_PER_FRAME = 35.127
+# --config selects another BASELINE config for reporting (the driver's default stays config[1] = cfg2)
+CONFIGS = {
+    "cfg2": dict(arch="ViT-B/16", shot=1, T=8, merge_before=False, gflop=35.127,
+                 name="BASELINE config[1]: 5-way 1-shot, 1 query/class, 8x224^2 frames, ViT-B/16"),
+    "cfg3": dict(arch="ViT-B/16", shot=5, T=8, merge_before=True, gflop=35.127,
+                 name="BASELINE config[2]: 5-way 5-shot (MERGE_BEFORE), 1 query/class, 8x224^2 frames, ViT-B/16"),
+    "cfg4": dict(arch="ViT-L/14", shot=1, T=16, merge_before=False, gflop=162.026,
+                 name="BASELINE config[3]: 5-way 1-shot, 1 query/class, 16x224^2 frames, ViT-L/14 (extension A16)"),
+}
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
@@ -138,9 +148,15 @@ def main():
     ap.add_argument("--episodes-per-step", type=int, default=8)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic episodes resident in HBM per rank")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
+    global ARCH, SHOT, T, MERGE_BEFORE, GFLOP_PER_FRAME
+    cfgsel = CONFIGS[args.config]
+    ARCH, SHOT, T, MERGE_BEFORE, GFLOP_PER_FRAME = cfgsel["arch"], cfgsel["shot"], cfgsel["T"], cfgsel["merge_before"], cfgsel["gflop"]
+    if args.config != "cfg2":
+        args.no_cpu_baseline = True            # the CPU leg is defined on the headline config only
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -168,7 +184,8 @@ def main():
     sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(ARCH, SEED).items()}
     tt = synth.text_features(N_TRAIN, a["embed"], "train", SEED)
     te = synth.text_features(N_TEST, a["embed"], "test", SEED)
-    eng = ClipFsarEngine(a, sd, tt, te, precision=args.precision, device=dev, max_frames=max(1280, B * 80))
+    frames_per_ep = (WAY * SHOT + WAY * QPC) * T
+    eng = ClipFsarEngine(a, sd, tt, te, precision=args.precision, device=dev, max_frames=max(1280, B * frames_per_ep))
     # synthetic episodes of this rank (episode ids e with e % world == rank), resident in HBM before timing
     pool = [synth.make_episode(WAY, SHOT, QPC, T, a["res"], N_TEST, rank + world * i, SEED) for i in range(args.pool)]
     batches = []
@@ -183,7 +200,7 @@ def main():
 
     def step(i, acc_out):
         b = batches[i % len(batches)]
-        logits, _ = eng.forward(b["sup"], b["tgt"], b["sl"], b["rl"], way=WAY, T=T)
+        logits, _ = eng.forward(b["sup"], b["tgt"], b["sl"], b["rl"], way=WAY, T=T, merge_before=MERGE_BEFORE)
         # A17: per-episode top-1 accuracy (metrics.topks_correct semantics, reference utils/metrics.py:100-138)
         acc_out[i * B:(i + 1) * B] = (logits.argmax(dim=2) == b["tl"].long()).float().mean(dim=1)
 
@@ -219,12 +236,11 @@ def main():
         frames_per_ep = (WAY * SHOT + WAY * QPC) * T
         tflop_per_ep = GFLOP_PER_FRAME * frames_per_ep / 1e3
         out = {
-            "metric": "episodes/sec (5-way 1-shot, 8 frames, ViT-B/16)", "value": round(eps_per_s, 3),
+            "metric": "episodes/sec (5-way %d-shot, %d frames, %s)" % (SHOT, T, ARCH), "value": round(eps_per_s, 3),
             "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config[1]: 5-way 1-shot, 1 query/class, 8x224^2 frames, ViT-B/16, "
-                                   "random-init CLIP weights, synthetic structured frames",
+            "config": {"workload": cfgsel["name"] + ", random-init CLIP weights, synthetic structured frames",
                        "episodes_per_step_per_gpu": B, "frames_per_episode": frames_per_ep,
                        "tflop_per_episode": round(tflop_per_ep, 4), "precision": args.precision,
                        "parallelism": "episodes sharded over %d rank(s); one all-gather of accuracies" % world},

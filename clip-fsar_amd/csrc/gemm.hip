@@ -38,7 +38,9 @@ struct GemmArgs {
     int act;
     int row_group, row_gap, row_off, res_mod, res_off;
     int tiles_n;
+    int ntiles;    // persistent p6: total number of 256x256 tiles
     int stagger;   // p4: first-round phase offset in units of s_sleep(127) (~4 us)
+    unsigned long long* trace;   // dev tool: per-tile phase timestamps (s_memtime), 8 slots per tile; normally NULL
     int dbg;   // ablation bits (env CFSAR_GEMM_DEBUG): 1 = no in-loop DMA, 2 = no in-loop barrier, 4 = no epilogue
 };
 
@@ -139,7 +141,7 @@ __device__ __forceinline__ void mma_slice(f32x16 (&acc)[2][2], const char* sX, c
 // 64-column row segment (128 B bf16 / 256 B f32 stores, 256 B residual loads) instead of 32 rows x 16 B per instruction.
 constexpr int EPI_RS = 272;                     // staged row: 64 fp32 + 16 B pad (conflict-free b128 writes)
 constexpr int EPI_WAVE_BYTES = 64 * EPI_RS;     // 17408 B per wave
-template <typename TO, int ACT, bool HAS_RES, bool REMAP, bool FULL>
+template <typename TO, int ACT, bool HAS_RES, bool REMAP, bool FULL, int NMI = 2>
 __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p, int mbase, int nbase, int lane,
                                              char* wbuf) {
     const int lr = lane & 31, hi = lane >> 5;
@@ -151,10 +153,10 @@ __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p
     const float* resp = p.res;
     TO* outp = reinterpret_cast<TO*>(p.out);
     // (1) issue every residual load of this lane up front (16 x 16 B, whole 256-byte row segments per 16 lanes)
-    float4 rv[16];
-    size_t ooff[16];
+    float4 rv[8 * NMI];
+    size_t ooff[8 * NMI];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < 8 * NMI; ++it) {
         const int m = mbase + it * 4 + rsub;
         const int mc = m < M ? m : M - 1;
         int orow = mc + row_off;
@@ -170,7 +172,7 @@ __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p
     if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + nc);
     // (2) transpose the accumulators through the wave-private LDS region
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -180,7 +182,7 @@ __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private region: in-order DS + this wait suffice
     // (3) row-contiguous epilogue math + stores
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < 8 * NMI; ++it) {
         const int row = it * 4 + rsub;
         const float4 a = *reinterpret_cast<const float4*>(wbuf + row * EPI_RS + cc * 16);
         float v[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
@@ -744,44 +746,17 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p4(GemmArgs p) {
     }
 }
 
-template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
+// PERSIST: launched with 256 workgroups (one per CU); each walks tiles b, b+256, ... -- no workgroup retire/dispatch and
+// store-drain latency between tiles (measured ~4-6 us of a ~34 us K=768 tile in the one-tile-per-workgroup form).
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP, bool PERSIST>
 __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p6(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BK = ROWB4 / (int)sizeof(TI);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
-    const int m0 = tm * BM4, n0 = tn * BN4;
-
-    // staging: each operand tile = 16 instructions of 16 rows x 64 B; wave w issues instructions {w, w+8} of X and of W
-    const char* srcX[2];
-    const char* srcW[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (i * 8 + wave) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ swz4(row);
-        int gm = ((p.dbg & 8) ? 0 : m0) + row;
-        gm = gm < p.M ? gm : p.M - 1;
-        int gn = ((p.dbg & 8) ? 0 : n0) + row;
-        gn = gn < p.N ? gn : p.N - 1;
-        srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
-        srcW[i] = p.W + ((size_t)gn * p.ldw) * sizeof(TI) + chunk * 16;
-    }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
-    auto issue = [&](int stage, int kt) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)stage * (unsigned)STAGE4);
-        const size_t koff = (size_t)kt * ROWB4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) glds16_asm(srcX[i] + koff, base + i * 8192);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) glds16_asm(srcW[i] + koff, base + BM4 * ROWB4 + i * 8192);
-    };
-
     const int wm = wave >> 2, wn = wave & 3;
     const int lr = lane & 31, hi = lane >> 5;
     int offX[4], offW[2], sxX[4], sxW[2];
@@ -797,6 +772,45 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p6(GemmArgs p) {
         offW[i] = BM4 * ROWB4 + rw * ROWB4;
         sxW[i] = swz4(rw);
     }
+    const int nk = p.K / BK;
+    const bool grpB = wave >= 4;
+
+    auto stamp = [&](int lin, int slot) {
+        if (p.trace && tid == 0) p.trace[(size_t)lin * 8 + slot] = __builtin_readcyclecounter();
+    };
+    // staging: each operand tile = 16 instructions of 16 rows x 64 B; wave w issues instructions {w, w+8} of X and of W
+    const char* srcX[2];
+    const char* srcW[2];
+    auto set_src = [&](int lin) {
+        const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (i * 8 + wave) * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ swz4(row);
+            int gm = tm * BM4 + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            int gn = tn * BN4 + row;
+            gn = gn < p.N ? gn : p.N - 1;
+            srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
+            srcW[i] = p.W + ((size_t)gn * p.ldw) * sizeof(TI) + chunk * 16;
+        }
+    };
+    auto issue = [&](int stage, int kt) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)stage * (unsigned)STAGE4);
+        const size_t koff = (size_t)kt * ROWB4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_asm(srcX[i] + koff, base + i * 8192);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_asm(srcW[i] + koff, base + BM4 * ROWB4 + i * 8192);
+    };
+
+    // pre_issued: slices 0..2 of this tile were already issued (persistent form: during / after the previous epilogue)
+    auto do_tile = [&](int lin, int next_lin, bool pre_issued) {
+    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+    const int m0 = tm * BM4, n0 = tn * BN4;
+    stamp(lin, 0);
+    if (!pre_issued) set_src(lin);
+
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -805,7 +819,6 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p6(GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    const int nk = p.K / BK;
     // ---- ping-pong schedule.  Waves 0-3 (group A, top 128 rows) and 4-7 (group B, bottom 128 rows) share the four SIMDs
     // pairwise (wave w and w+4).  Every wave alternates a MEMORY phase (12 ds_read_b128 of slice j's fragments + its 4
     // LDS-DMA issues for slice j+3 + counted waits) and a COMPUTE phase (16 MFMAs), separated by s_barrier; group B runs
@@ -814,7 +827,6 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p6(GemmArgs p) {
     // Invariants (4 stages, DMA distance 3): a wave ends memory phase j only when its own DMA share of slice j+1 has
     // landed (vmcnt(8) leaves slices j+2, j+3 in flight), so after G(2j) every share of slice j is in LDS for A's reads
     // and after G(2j+1) for B's; slice j+3 overwrites the stage of slice j-1, last read by B before G(2j).
-    const bool grpB = wave >= 4;
     uint4 xf[2][4], wf[2][2];
     auto mem_phase = [&](int j) {
         const char* base = smem + (j & 3) * STAGE4;
@@ -856,14 +868,22 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p6(GemmArgs p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 2) issue(2, 2);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!pre_issued) {
+        issue(0, 0);
+        if (nk > 1) issue(1, 1);
+        if (nk > 2) issue(2, 2);
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // slices 0,1 were issued before the previous epilogue's stores, slice 2 after them: leaving only slice 2 in
+        // flight also drains those stores (they have had the whole epilogue to complete)
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                      // G0: slice 0 is in LDS for everyone
     __builtin_amdgcn_sched_barrier(0);
+    stamp(lin, 1);
     if (grpB) {
         __builtin_amdgcn_s_barrier();                  // group B starts one barrier late
         __builtin_amdgcn_sched_barrier(0);
@@ -877,10 +897,34 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p6(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
+    stamp(lin, 2);
     if (p.dbg & 4) {
         if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[3][1][2] + acc[2][0][1];
         return;
     }
+    if constexpr (PERSIST) {
+        // Prefetch the next tile's slices 0 and 1 into stages 0/1 (bytes [0, 64 KiB)) BEFORE the epilogue, whose LDS
+        // staging is confined to [64 KiB, 64 KiB + 8 x 8704 B): the ~13 % pipeline-fill latency of a K = 768 tile hides
+        // behind the epilogue.  The epilogue runs in four 32-row passes per wave.
+        const bool has_next = next_lin < p.ntiles;
+        if (has_next) {
+            set_src(next_lin);
+            issue(0, 0);
+            if (nk > 1) issue(1, 1);
+        }
+        char* wbuf = smem + 65536 + wave * (32 * EPI_RS);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int mb = m0 + wm * 128 + mi * 32, nb = n0 + wn * 64;
+            if (mb + 32 <= p.M && nb + 64 <= p.N) epilogue_lds<TO, ACT, HAS_RES, REMAP, true, 1>(&acc[mi], p, mb, nb, lane, wbuf);
+            else epilogue_lds<TO, ACT, HAS_RES, REMAP, false, 1>(&acc[mi], p, mb, nb, lane, wbuf);
+            if (mi == 1) stamp(lin, 3);
+        }
+        stamp(lin, 4);
+        __syncthreads();                                   // staging reads done: stage 2 may be overwritten
+        if (has_next && nk > 2) issue(2, 2);
+        stamp(lin, 5);
+    } else {
     char* wbuf = smem + wave * EPI_WAVE_BYTES;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -893,6 +937,28 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p6(GemmArgs p) {
             if (full) epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
             else epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
         }
+        stamp(lin, 3 + half);
+    }
+    if (p.trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(lin, 5);
+    }
+    }
+    };   // do_tile
+
+    if constexpr (PERSIST) {
+        // Block b lives on XCD b % 8; inside each chunk of G tiles the workgroups of one XCD take CONSECUTIVE raster
+        // positions, so the tiles an L2 sees at one time share X and W panels.
+        const int G = gridDim.x, b = blockIdx.x, per_xcd = G >> 3;
+        bool pre = false;
+        for (int lin = (b & 7) * per_xcd + (b >> 3); lin < p.ntiles; lin += G) {
+            do_tile(lin, lin + G, pre);
+            pre = true;
+        }
+    } else {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+        do_tile((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3), p.ntiles, false);
     }
 }
 
@@ -923,30 +989,31 @@ int launch_p4(const GemmArgs& a0, hipStream_t s) {
              : launch_p4_inst<__bf16, TO, CFSAR_ACT_NONE, false, false>(a, s);
 }
 
-template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP, bool PERSIST>
 int launch_p6_inst(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p6<TI, TO, ACT, HAS_RES, REMAP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p6<TI, TO, ACT, HAS_RES, REMAP, PERSIST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
         if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    const int tiles_m = (a.M + BM4 - 1) / BM4;
-    hipLaunchKernelGGL((gemm_kernel_p6<TI, TO, ACT, HAS_RES, REMAP>), dim3(tiles_m * a.tiles_n), dim3(NTHREADS2), LDS4, s, a);
+    const int grid = PERSIST ? 256 : a.ntiles;
+    hipLaunchKernelGGL((gemm_kernel_p6<TI, TO, ACT, HAS_RES, REMAP, PERSIST>), dim3(grid), dim3(NTHREADS2), LDS4, s, a);
     return cfsar_check_launch("cfsar_gemm(p6)");
 }
 
-template <typename TO>
+template <typename TO, bool PERSIST>
 int launch_p6(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     a.tiles_n = (a.N + BN4 - 1) / BN4;
+    a.ntiles = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
     const bool r = a.res != nullptr;
     if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF) return -2;
     if (a.act == CFSAR_ACT_QUICKGELU)
-        return r ? -2 : launch_p6_inst<__bf16, TO, CFSAR_ACT_QUICKGELU, false, false>(a, s);
-    return r ? launch_p6_inst<__bf16, TO, CFSAR_ACT_NONE, true, false>(a, s)
-             : launch_p6_inst<__bf16, TO, CFSAR_ACT_NONE, false, false>(a, s);
+        return r ? -2 : launch_p6_inst<__bf16, TO, CFSAR_ACT_QUICKGELU, false, false, PERSIST>(a, s);
+    return r ? launch_p6_inst<__bf16, TO, CFSAR_ACT_NONE, true, false, PERSIST>(a, s)
+             : launch_p6_inst<__bf16, TO, CFSAR_ACT_NONE, false, false, PERSIST>(a, s);
 }
 
 // ============================================================================================================
@@ -1113,6 +1180,10 @@ int launch_p5(const GemmArgs& a0, hipStream_t s) {
 
 }  // namespace
 
+static unsigned long long* g_trace = nullptr;
+// dev tool (not in the public header): device buffer of 8 x u64 per 256x256 tile for the p6 phase timestamps; NULL = off
+extern "C" void cfsar_debug_set_gemm_trace(void* buf) { g_trace = static_cast<unsigned long long*>(buf); }
+
 extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* bias, const float* residual, int M,
                           int N, int K, int lda, int ldw, int ldo, int ldr, int in_dtype, int out_dtype, int act,
                           int row_group, int row_gap, int row_off, int res_mod, int res_off, cfsar_stream_t stream) {
@@ -1145,6 +1216,7 @@ extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* 
     a.dbg = dbg;
     static const int stag = [] { const char* e = getenv("CFSAR_GEMM_STAGGER"); return e ? atoi(e) : -1; }();
     a.stagger = stag;
+    a.trace = g_trace;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // variant: 0 = auto, 1 = v1 (128x128, 2-stage, compiler-managed LDS-DMA), 2 = p3 (256x128, 3-stage, asm LDS-DMA)
     static const int forced = [] { const char* e = getenv("CFSAR_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
@@ -1152,11 +1224,15 @@ extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* 
     const long tiles4 = (long)((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
     // variants: 1 = v1 (128x128), 2 = p3 (256x128, 3-stage), 3 = p4 (256x256, 4-stage), 4 = p5 (256x128, 2 WG/CU),
     // 6 = p6 (256x256 ping-pong).  auto: p6 when >= 2 rounds of 256x256 tiles exist, else p3 / v1.
-    if (in_dtype == CFSAR_BF16 && (forced == 6 || (forced == 0 && tiles4 >= 512))) {
-        const int rc = out_dtype == CFSAR_BF16 ? launch_p6<__bf16>(a, s) : launch_p6<float>(a, s);
+    if (in_dtype == CFSAR_BF16 && forced == 7) {               // 7 = p6 persistent
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p6<__bf16, true>(a, s) : launch_p6<float, true>(a, s);
         if (rc != -2) return rc;
     }
-    const bool use_p4 = in_dtype == CFSAR_BF16 && (forced == 3 || forced == 6 || (forced == 0 && tiles4 >= 512));
+    if (in_dtype == CFSAR_BF16 && (forced == 6 || (forced == 0 && tiles4 >= 512))) {
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p6<__bf16, false>(a, s) : launch_p6<float, false>(a, s);
+        if (rc != -2) return rc;
+    }
+    const bool use_p4 = in_dtype == CFSAR_BF16 && (forced == 3 || forced == 6 || forced == 7 || (forced == 0 && tiles4 >= 512));
     if (use_p4) {
         const int rc = out_dtype == CFSAR_BF16 ? launch_p4<__bf16>(a, s) : launch_p4<float>(a, s);
         if (rc != -2) return rc;
