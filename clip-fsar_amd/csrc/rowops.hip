@@ -50,6 +50,45 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ x, co
     }
 }
 
+// ---- N2 (the step before the path): test-time frame transform of the few-shot dataset, reference
+// datasets/base/ssv2_few_shot.py:614-642 = ToTensorVideo (uint8 THWC -> float CTHW / 255) -> KineticsResizedCropFewshot
+// (datasets/utils/transformations.py:663-716: bilinear resize to (sh, sw), align_corners = False, then a crop window)
+// -> NormalizeVideo(mean, std) -> permute to [T, 3, crop, crop].  One thread per output pixel (all 3 channels).
+__global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __restrict__ src, float* __restrict__ out, int T,
+                                                         int H, int W, int sh, int sw, int crop, int y0, int x0, float m0,
+                                                         float m1, float m2, float is0, float is1, float is2) {
+    const long long total = (long long)T * crop * crop;
+    const float ry = (float)H / (float)sh, rx = (float)W / (float)sw;       // torch: scale = in / out
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % crop);
+        const long long r = idx / crop;
+        const int y = (int)(r % crop);
+        const int t = (int)(r / crop);
+        float fy = ry * ((float)(y + y0) + 0.5f) - 0.5f;                     // area_pixel_compute_source_index
+        float fx = rx * ((float)(x + x0) + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int iy0 = (int)fy, ix0 = (int)fx;
+        const int iy1 = iy0 + (iy0 < H - 1 ? 1 : 0), ix1 = ix0 + (ix0 < W - 1 ? 1 : 0);
+        const float ly = fy - (float)iy0, lx = fx - (float)ix0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const unsigned char* f = src + (long long)t * H * W * 3;
+        const unsigned char* p00 = f + ((long long)iy0 * W + ix0) * 3;
+        const unsigned char* p01 = f + ((long long)iy0 * W + ix1) * 3;
+        const unsigned char* p10 = f + ((long long)iy1 * W + ix0) * 3;
+        const unsigned char* p11 = f + ((long long)iy1 * W + ix1) * 3;
+        const float mean[3] = {m0, m1, m2}, istd[3] = {is0, is1, is2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float inv255 = 1.0f / 255.0f;
+            const float v = hy * (hx * ((float)p00[c] * inv255) + lx * ((float)p01[c] * inv255)) +
+                            ly * (hx * ((float)p10[c] * inv255) + lx * ((float)p11[c] * inv255));
+            out[(((long long)t * 3 + c) * crop + y) * crop + x] = (v - mean[c]) * istd[c];
+        }
+    }
+}
+
 // ---- A3 LayerNorm: one wave per row, row held in registers (<= 16 float4 per lane), two-pass statistics in fp32,
 // wavefront-shuffle reductions, vectorised 16-byte loads / 8- or 16-byte stores.  Each wave handles RPW rows at once so
 // that 2x the loads are in flight per wave (the kernel is HBM-bound: 4 B in + 2 B out per element in bf16 mode).
@@ -174,6 +213,21 @@ extern "C" int cfsar_cls_rows(float* x, const float* cls, const float* pos, int 
     hipLaunchKernelGGL(cls_rows_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, cls, pos, F,
                        ntok, D);
     return cfsar_check_launch("cfsar_cls_rows");
+}
+
+extern "C" int cfsar_preprocess_frames(const uint8_t* frames, float* out, int T, int H, int W, int scale_h, int scale_w,
+                                       int crop, int y0, int x0, const float* mean3, const float* std3,
+                                       cfsar_stream_t stream) {
+    CFSAR_REQUIRE(frames && out && mean3 && std3, "cfsar_preprocess_frames: null pointer");
+    CFSAR_REQUIRE(T > 0 && H > 1 && W > 1 && scale_h >= crop && scale_w >= crop && crop > 0, "cfsar_preprocess_frames: bad geometry");
+    CFSAR_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + crop <= scale_h && x0 + crop <= scale_w, "cfsar_preprocess_frames: crop window out of range");
+    const long long total = (long long)T * crop * crop;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), frames, out, T, H,
+                       W, scale_h, scale_w, crop, y0, x0, mean3[0], mean3[1], mean3[2], 1.0f / std3[0], 1.0f / std3[1],
+                       1.0f / std3[2]);
+    return cfsar_check_launch("cfsar_preprocess_frames");
 }
 
 extern "C" int cfsar_layernorm(const float* x, int64_t in_stride, void* out, int64_t out_stride, int out_dtype,

@@ -22,6 +22,7 @@ _c_int, _c_p, _c_f, _c_i64 = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctyp
 # symbol -> argtypes; must match include/clipfsar_hip.h (tests/test_abi.py cross-checks against the header text)
 SIGNATURES = {
     "cfsar_version": [],
+    "cfsar_preprocess_frames": [_c_p, _c_p] + [_c_int] * 8 + [_c_p, _c_p, _c_p],
     "cfsar_im2col_patches": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_cls_rows": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_layernorm": [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p],
@@ -87,6 +88,19 @@ def _code(dtype):
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ----------------------------------------------------------------------------------------------- N2 frame transform
+def preprocess_frames(frames_u8, out, scale_hw, crop, y0, x0, mean, std):
+    """uint8 device frames [T,H,W,3] -> out [T,3,crop,crop] fp32 (resize, crop window, normalise)."""
+    T, H, W, C = frames_u8.shape
+    assert C == 3
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in std])
+    _check(lib().cfsar_preprocess_frames(_dev(frames_u8, torch.uint8, "frames"), _dev(out, torch.float32, "out"), T, H, W,
+                                         int(scale_hw[0]), int(scale_hw[1]), int(crop), int(y0), int(x0),
+                                         ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p), _stream()),
+           "cfsar_preprocess_frames")
 
 
 # ----------------------------------------------------------------------------------------------- ViT tower ops

@@ -37,6 +37,13 @@ typedef void* cfsar_stream_t;
 int cfsar_version(void);
 const char* cfsar_last_error(void);
 
+/* ---- N2 test-time frame transform (the step BEFORE the path; reference datasets/base/ssv2_few_shot.py:614-642,
+ * datasets/utils/transformations.py:663-716): uint8 frames [T,H,W,3] (device) -> /255 -> bilinear resize to
+ * (scale_h, scale_w) with align_corners=False -> crop window [y0, y0+crop) x [x0, x0+crop) -> (v - mean[c]) / std[c]
+ * -> out [T,3,crop,crop] fp32.  mean3 / std3 are HOST pointers to 3 floats (DATA.MEAN / DATA.STD). */
+int cfsar_preprocess_frames(const uint8_t* frames, float* out, int T, int H, int W, int scale_h, int scale_w, int crop,
+                            int y0, int x0, const float* mean3, const float* std3, cfsar_stream_t stream);
+
 /* ---- A2 patch embedding, stage 1: gather non-overlapping PxP patches of NCHW fp32 frames into GEMM rows.
  * Replaces the im2col implied by nn.Conv2d(3, D, kernel=P, stride=P, bias=False) (few_shot.py:659,672-674).
  * frames [F,3,H,W] fp32 -> out [F*(H/P)*(W/P), k_pad] (dtype out_dtype); column k = c*P*P + dy*P + dx,

@@ -218,6 +218,19 @@ def head_forward_text_modes(episode, sd, text_train, text_test, arch, frames: in
     return {"logits": p_text.pow(text_coff) * soft.pow(1.0 - text_coff), "class_logits": None}
 
 
+# ------------------------------------------------------------------ N2 test-time frame transform
+def preprocess_frames(frames_u8, scale_hw, crop, y0, x0, mean, std):
+    """uint8 [T,H,W,3] -> [T,3,crop,crop].  ToTensorVideo (/255, THWC->CTHW), F.interpolate(size=scale_hw, bilinear,
+    align_corners=False) as KineticsResizedCropFewshot does (datasets/utils/transformations.py:676-688), crop window,
+    NormalizeVideo, permute(1,0,2,3) (datasets/base/ssv2_few_shot.py:439,627-642)."""
+    clip = frames_u8.permute(3, 0, 1, 2).float() / 255.0
+    clip = torch.nn.functional.interpolate(clip, size=(int(scale_hw[0]), int(scale_hw[1])), mode="bilinear")
+    clip = clip[:, :, y0:y0 + crop, x0:x0 + crop]
+    m = torch.tensor(mean).reshape(3, 1, 1, 1)
+    sd = torch.tensor(std).reshape(3, 1, 1, 1)
+    return ((clip - m) / sd).permute(1, 0, 2, 3).contiguous()
+
+
 def top1_correct(logits, target_labels):
     """metrics.topks_correct(...,(1,)) (reference utils/metrics.py:100-138): count of argmax hits."""
     return int((logits.argmax(dim=1) == target_labels.long()).sum())

@@ -218,6 +218,39 @@ def run_text_mode_cases():
         print("%-28s logits[%.4f..%.4f]" % (name, out["logits"].min(), out["logits"].max()))
 
 
+
+PREPROC_CASES = {
+    "square_center": dict(T=2, H=120, W=160, scale=64, crop=56, nsc=1, idx=1),
+    "rect_left": dict(T=2, H=90, W=150, scale=[72, 96], crop=64, nsc=3, idx=0),
+    "rect_right_upscale": dict(T=1, H=48, W=40, scale=[72, 96], crop=64, nsc=3, idx=2),
+}
+
+
+def synth_u8_video(T, H, W, tag):
+    v = synth.pseudo_normal(T * H * W * 3, "u8video/" + tag, SEED)
+    return np.clip(v * 60.0 + 128.0, 0, 255).astype(np.uint8).reshape(T, H, W, 3)
+
+
+def run_preprocess_cases():
+    """N2: the reference's own KineticsResizedCropFewshot (datasets/utils/transformations.py:663-746) between the
+    torchvision ToTensorVideo / NormalizeVideo steps (restated: /255 + permute, (x-mean)/std) and the final permute."""
+    rh.import_reference()
+    import datasets.utils.transformations as RT                       # the reference module
+    out = {}
+    for name, c in PREPROC_CASES.items():
+        vid = synth_u8_video(c["T"], c["H"], c["W"], name)
+        clip = torch.from_numpy(vid).permute(3, 0, 1, 2).float() / 255.0          # ToTensorVideo
+        scale = c["scale"] if isinstance(c["scale"], list) else [c["scale"], c["scale"]]
+        tr = RT.KineticsResizedCropFewshot(short_side_range=scale, crop_size=c["crop"], num_spatial_crops=c["nsc"], idx=c["idx"])
+        clip = tr(clip)
+        m = torch.tensor(synth.CLIP_MEAN).reshape(3, 1, 1, 1)
+        sd = torch.tensor(synth.CLIP_STD).reshape(3, 1, 1, 1)
+        clip = ((clip - m) / sd).permute(1, 0, 2, 3).contiguous()                   # NormalizeVideo + permute(1,0,2,3)
+        out[name] = clip.numpy()
+        print("preproc_%-20s out %s" % (name, tuple(clip.shape)))
+    np.savez_compressed(os.path.join(GOLD, "preprocess_cases.npz"), meta=json.dumps(dict(seed=SEED, cases=PREPROC_CASES)), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -229,6 +262,7 @@ def main():
     if args.text_only:
         run_text_cases()
         run_text_mode_cases()
+        run_preprocess_cases()
         return
     if not args.only:
         run_known_answers()

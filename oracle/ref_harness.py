@@ -54,6 +54,10 @@ def import_reference():
     tv.transforms = _stub(
         "torchvision.transforms", Compose=ident, Resize=ident, CenterCrop=ident, ToTensor=ident,
         Normalize=ident, InterpolationMode=SimpleNamespace(BICUBIC=3))
+    tv.transforms.__path__ = []                          # let `import torchvision.transforms._functional_video` resolve
+    _stub("torchvision.transforms._functional_video")
+    _stub("torchvision.transforms._transforms_video")
+    tv.transforms.Lambda = ident
     _stub("ipdb", set_trace=ident)
     _stub("ftfy", fix_text=lambda s: s)
     _stub("oss2")
