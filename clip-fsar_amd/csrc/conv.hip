@@ -1,0 +1,174 @@
+// N3: data-movement kernels of the CLIP ModifiedResNet ("RN50") tower (reference few_shot.py:182-227, 542-602).
+// Activations are NHWC ([F*H*W, C] row-major) so 1x1 convolutions are plain GEMM rows and 3x3 convolutions become a
+// GEMM after a tap-major gather (column = (ky*3+kx)*C + c).  BatchNorm (eval) is folded into the conv weights / bias on
+// the host, ReLU and the identity add are GEMM epilogues (cfsar_gemm_ex); what remains here is memory-bound.
+#include "common.h"
+
+namespace {
+
+// frames [F,3,H,W] f32 (the episode layout) -> [F,H,W,4-padded? no: 3] in the compute dtype
+template <typename TO>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, TO* __restrict__ out, int C, int H,
+                                                           int W, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        long long r = idx / C;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H);
+        const long long f = r / H;
+        out[idx] = (TO)in[((f * C + c) * H + y) * (long long)W + x];
+    }
+}
+
+// 3x3 / pad 1 / stride s gather: in [F,H,W,C] -> out [F*Ho*Wo, kpad], column (ky*3+kx)*C + c, zero outside the image and in
+// the pad columns.  VEC elements (16 bytes when possible) per thread.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W, int C,
+                                                        int Ho, int Wo, int stride, int kpad, long long total_vec) {
+    const int kv = kpad / VEC;
+    const int kreal = 9 * C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_vec;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long row = idx / kv;
+        const int k = (int)(idx - row * kv) * VEC;
+        T v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = (T)0.0f;
+        if (k < kreal) {
+            const int tap = k / C, c = k - tap * C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int xo = (int)(row % Wo);
+            const long long t = row / Wo;
+            const int yo = (int)(t % Ho);
+            const long long f = t / Ho;
+            const int y = yo * stride + ky - 1, x = xo * stride + kx - 1;
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                const T* src = in + ((f * H + y) * (long long)W + x) * C + c;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[j] = src[j];
+            }
+        }
+        T* dst = out + row * kpad + k;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dst[j] = v[j];
+    }
+}
+
+// AvgPool2d(2) on NHWC
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool2_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W, int C,
+                                                       long long total) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        long long r = idx / C;
+        const int xo = (int)(r % Wo);
+        r /= Wo;
+        const int yo = (int)(r % Ho);
+        const long long f = r / Ho;
+        const T* p = in + ((f * H + 2 * yo) * (long long)W + 2 * xo) * C + c;
+        const float s = ((float)p[0] + (float)p[C]) + ((float)p[(long long)W * C] + (float)p[(long long)W * C + C]);
+        out[idx] = (T)(s * 0.25f);
+    }
+}
+
+// AttentionPool2d token build (few_shot.py:446-448): tokens[f,0] = mean_hw(x[f]) + pos[0]; tokens[f,1+p] = x[f,p] + pos[1+p]
+template <typename T>
+__global__ __launch_bounds__(256) void attnpool_tokens_kernel(const T* __restrict__ x, const float* __restrict__ pos,
+                                                              T* __restrict__ out, int HW, int C) {
+    const int f = blockIdx.x;
+    const T* xf = x + (long long)f * HW * C;
+    T* of = out + (long long)f * (HW + 1) * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) {
+            const float v = (float)xf[(long long)p * C + c];
+            s += v;
+            of[(long long)(p + 1) * C + c] = (T)(v + pos[(long long)(p + 1) * C + c]);
+        }
+        of[c] = (T)(s / (float)HW + pos[c]);
+    }
+}
+
+template <typename F>
+int grid_for(long long total, F) {
+    long long b = (total + 255) / 256;
+    return (int)(b > 256 * 32 ? 256 * 32 : b);
+}
+
+}  // namespace
+
+extern "C" int cfsar_nchw_to_nhwc(const float* frames, void* out, int out_dtype, int F, int C, int H, int W,
+                                  cfsar_stream_t stream) {
+    CFSAR_REQUIRE(frames && out && F > 0 && C > 0 && H > 0 && W > 0, "cfsar_nchw_to_nhwc: bad arguments");
+    const long long total = (long long)F * C * H * W;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dtype == CFSAR_BF16)
+        hipLaunchKernelGGL((nchw_to_nhwc_kernel<__bf16>), dim3(grid_for(total, 0)), dim3(256), 0, s, frames, static_cast<__bf16*>(out), C, H, W, total);
+    else if (out_dtype == CFSAR_F32)
+        hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(grid_for(total, 0)), dim3(256), 0, s, frames, static_cast<float*>(out), C, H, W, total);
+    else
+        return cfsar_fail("cfsar_nchw_to_nhwc: bad dtype %d", out_dtype);
+    return cfsar_check_launch("cfsar_nchw_to_nhwc");
+}
+
+extern "C" int cfsar_im2col3x3_nhwc(const void* in, void* out, int dtype, int F, int H, int W, int C, int stride, int k_pad,
+                                    cfsar_stream_t stream) {
+    CFSAR_REQUIRE(in && out && F > 0 && H > 0 && W > 0 && C > 0, "cfsar_im2col3x3_nhwc: bad arguments");
+    CFSAR_REQUIRE(stride == 1 || stride == 2, "cfsar_im2col3x3_nhwc: stride must be 1 or 2");
+    CFSAR_REQUIRE(k_pad >= 9 * C, "cfsar_im2col3x3_nhwc: k_pad too small");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const long long rows = (long long)F * Ho * Wo;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec8 = (C % 8 == 0) && (k_pad % 8 == 0);
+    const bool vec4 = (C % 4 == 0) && (k_pad % 4 == 0);
+    if (dtype == CFSAR_BF16) {
+        if (vec8) {
+            const long long tv = rows * (k_pad / 8);
+            hipLaunchKernelGGL((im2col3x3_kernel<__bf16, 8>), dim3(grid_for(tv, 0)), dim3(256), 0, s, static_cast<const __bf16*>(in), static_cast<__bf16*>(out), H, W, C, Ho, Wo, stride, k_pad, tv);
+        } else {
+            const long long tv = rows * k_pad;
+            hipLaunchKernelGGL((im2col3x3_kernel<__bf16, 1>), dim3(grid_for(tv, 0)), dim3(256), 0, s, static_cast<const __bf16*>(in), static_cast<__bf16*>(out), H, W, C, Ho, Wo, stride, k_pad, tv);
+        }
+    } else if (dtype == CFSAR_F32) {
+        if (vec4) {
+            const long long tv = rows * (k_pad / 4);
+            hipLaunchKernelGGL((im2col3x3_kernel<float, 4>), dim3(grid_for(tv, 0)), dim3(256), 0, s, static_cast<const float*>(in), static_cast<float*>(out), H, W, C, Ho, Wo, stride, k_pad, tv);
+        } else {
+            const long long tv = rows * k_pad;
+            hipLaunchKernelGGL((im2col3x3_kernel<float, 1>), dim3(grid_for(tv, 0)), dim3(256), 0, s, static_cast<const float*>(in), static_cast<float*>(out), H, W, C, Ho, Wo, stride, k_pad, tv);
+        }
+    } else {
+        return cfsar_fail("cfsar_im2col3x3_nhwc: bad dtype %d", dtype);
+    }
+    return cfsar_check_launch("cfsar_im2col3x3_nhwc");
+}
+
+extern "C" int cfsar_avgpool2x2_nhwc(const void* in, void* out, int dtype, int F, int H, int W, int C, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(in && out && F > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0, "cfsar_avgpool2x2_nhwc: bad arguments");
+    const long long total = (long long)F * (H / 2) * (W / 2) * C;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == CFSAR_BF16)
+        hipLaunchKernelGGL((avgpool2_kernel<__bf16>), dim3(grid_for(total, 0)), dim3(256), 0, s, static_cast<const __bf16*>(in), static_cast<__bf16*>(out), H, W, C, total);
+    else if (dtype == CFSAR_F32)
+        hipLaunchKernelGGL((avgpool2_kernel<float>), dim3(grid_for(total, 0)), dim3(256), 0, s, static_cast<const float*>(in), static_cast<float*>(out), H, W, C, total);
+    else
+        return cfsar_fail("cfsar_avgpool2x2_nhwc: bad dtype %d", dtype);
+    return cfsar_check_launch("cfsar_avgpool2x2_nhwc");
+}
+
+extern "C" int cfsar_attnpool_tokens(const void* x, const float* pos, void* out, int dtype, int F, int HW, int C,
+                                     cfsar_stream_t stream) {
+    CFSAR_REQUIRE(x && pos && out && F > 0 && HW > 0 && C > 0, "cfsar_attnpool_tokens: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == CFSAR_BF16)
+        hipLaunchKernelGGL((attnpool_tokens_kernel<__bf16>), dim3(F), dim3(256), 0, s, static_cast<const __bf16*>(x), pos, static_cast<__bf16*>(out), HW, C);
+    else if (dtype == CFSAR_F32)
+        hipLaunchKernelGGL((attnpool_tokens_kernel<float>), dim3(F), dim3(256), 0, s, static_cast<const float*>(x), pos, static_cast<float*>(out), HW, C);
+    else
+        return cfsar_fail("cfsar_attnpool_tokens: bad dtype %d", dtype);
+    return cfsar_check_launch("cfsar_attnpool_tokens");
+}

@@ -32,7 +32,9 @@ struct GemmArgs {
     const char* W;
     void* out;
     const float* bias;
-    const float* res;
+    const void* res;      // residual, fp32 or (res_bf16) bf16
+    int res_bf16;
+    int relu;             // ReLU applied last (after bias / activation / residual): conv+BN(+identity)+ReLU of the RN50 tower
     int M, N, K;
     int lda, ldw, ldo, ldr;
     int act;
@@ -56,6 +58,14 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
     if (act == CFSAR_ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     return v;
+}
+
+__device__ __forceinline__ float4 load_res4(const void* res, int is_bf16, size_t elem_off) {
+    if (is_bf16) {
+        const bf16x4 r = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(res) + elem_off);
+        return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+    }
+    return *reinterpret_cast<const float4*>(static_cast<const float*>(res) + elem_off);
 }
 
 // ---- epilogue: D[n][m] layout -> lane owns token row m = mbase+32mi+(lane&31) and columns 8g+4hi..+3 of each
@@ -88,8 +98,12 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], const GemmArgs& p,
                     for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
                 }
                 if (p.res) {
-                    const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)rrow * p.ldr + n);
+                    const float4 rv = load_res4(p.res, p.res_bf16, (size_t)rrow * p.ldr + n);
                     v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
                 }
                 if constexpr (sizeof(TO) == 2) {
                     bf16x4 o;
@@ -150,7 +164,8 @@ __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p
     const int n = nbase + cc * 4;
     const bool nvalid = n < N;
     const int nc = nvalid ? n : N - 4;                       // clamped column: loads stay in bounds, stores are predicated
-    const float* resp = p.res;
+    const void* resp = p.res;
+    const int res_bf16 = p.res_bf16, relu = p.relu;
     TO* outp = reinterpret_cast<TO*>(p.out);
     // (1) issue every residual load of this lane up front (16 x 16 B, whole 256-byte row segments per 16 lanes)
     float4 rv[8 * NMI];
@@ -166,7 +181,7 @@ __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p
             rrow = p.res_mod > 0 ? (mc % p.res_mod) + p.res_off : orow;
         }
         ooff[it] = (size_t)orow * ldo + nc;
-        if constexpr (HAS_RES) rv[it] = *reinterpret_cast<const float4*>(resp + (size_t)rrow * ldr + nc);
+        if constexpr (HAS_RES) rv[it] = load_res4(resp, res_bf16, (size_t)rrow * ldr + nc);
     }
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + nc);
@@ -192,6 +207,10 @@ __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p
         }
         if constexpr (HAS_RES) {
             v[0] += rv[it].x; v[1] += rv[it].y; v[2] += rv[it].z; v[3] += rv[it].w;
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
         }
         if (FULL || (nvalid && mbase + row < M)) {       // FULL: straight-line code, counted vmcnt waits
             if constexpr (sizeof(TO) == 2) {
@@ -1184,9 +1203,10 @@ static unsigned long long* g_trace = nullptr;
 // dev tool (not in the public header): device buffer of 8 x u64 per 256x256 tile for the p6 phase timestamps; NULL = off
 extern "C" void cfsar_debug_set_gemm_trace(void* buf) { g_trace = static_cast<unsigned long long*>(buf); }
 
-extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* bias, const float* residual, int M,
-                          int N, int K, int lda, int ldw, int ldo, int ldr, int in_dtype, int out_dtype, int act,
-                          int row_group, int row_gap, int row_off, int res_mod, int res_off, cfsar_stream_t stream) {
+extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const float* bias, const void* residual, int M,
+                             int N, int K, int lda, int ldw, int ldo, int ldr, int in_dtype, int out_dtype, int act,
+                             int row_group, int row_gap, int row_off, int res_mod, int res_off, int res_dtype, int relu,
+                             cfsar_stream_t stream) {
     CFSAR_REQUIRE(A && W && out, "cfsar_gemm: null operand");
     CFSAR_REQUIRE(M > 0 && N > 0 && K > 0, "cfsar_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     CFSAR_REQUIRE(in_dtype == CFSAR_F32 || in_dtype == CFSAR_BF16, "cfsar_gemm: bad in_dtype %d", in_dtype);
@@ -1200,12 +1220,15 @@ extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* 
     CFSAR_REQUIRE((ldo * (out_dtype == CFSAR_BF16 ? 2 : 4)) % 8 == 0, "cfsar_gemm: ldo alignment");
     CFSAR_REQUIRE(!residual || (ldr >= N && ldr % 4 == 0), "cfsar_gemm: bad ldr");
     CFSAR_REQUIRE(act >= 0 && act <= 2, "cfsar_gemm: bad act %d", act);
+    CFSAR_REQUIRE(res_dtype == CFSAR_F32 || res_dtype == CFSAR_BF16, "cfsar_gemm: bad res_dtype %d", res_dtype);
     GemmArgs a;
     a.A = static_cast<const char*>(A);
     a.W = static_cast<const char*>(W);
     a.out = out;
     a.bias = bias;
     a.res = residual;
+    a.res_bf16 = res_dtype == CFSAR_BF16;
+    a.relu = relu;
     a.M = M; a.N = N; a.K = K;
     a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.ldr = ldr;
     a.act = act;
@@ -1253,4 +1276,11 @@ extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* 
     if (in_dtype == CFSAR_BF16)
         return out_dtype == CFSAR_BF16 ? launch<__bf16, __bf16>(a, s) : launch<__bf16, float>(a, s);
     return out_dtype == CFSAR_BF16 ? launch<float, __bf16>(a, s) : launch<float, float>(a, s);
+}
+
+extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* bias, const float* residual, int M,
+                          int N, int K, int lda, int ldw, int ldo, int ldr, int in_dtype, int out_dtype, int act,
+                          int row_group, int row_gap, int row_off, int res_mod, int res_off, cfsar_stream_t stream) {
+    return cfsar_gemm_ex(A, W, out, bias, residual, M, N, K, lda, ldw, ldo, ldr, in_dtype, out_dtype, act, row_group, row_gap,
+                         row_off, res_mod, res_off, CFSAR_F32, 0, stream);
 }

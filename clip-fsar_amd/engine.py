@@ -139,6 +139,146 @@ class HipViT:
         return feats_out
 
 
+class HipResNet:
+    """N3: CLIP ModifiedResNet.forward (reference few_shot.py:581-602) on the HIP kernels.
+
+    NHWC activations; BatchNorm (eval, running statistics) folded into the conv weights and a per-channel bias on the
+    host; 1x1 convs are cfsar_gemm rows, 3x3 convs a tap-major gather + cfsar_gemm; ReLU / identity-add are GEMM
+    epilogues; avgpool anti-aliasing and the attention-pool token build are small NHWC kernels; the attention pool runs
+    through the fp32 short-sequence attention kernel (only the mean token's output row is kept)."""
+
+    def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda"):
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.arch = dict(arch)
+        self.dev = torch.device(device)
+        self.cd = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.kq = 64 if precision == "bf16" else 32
+        self.E = arch["embed"]
+        self.width, self.layers, self.heads = arch["width"], arch["layers"], arch["heads"]
+        if (self.width * 32) % self.heads or (self.width * 32) // self.heads > 128:
+            raise ValueError("attention-pool head_dim must be <= 128")
+
+        def g(name):
+            t = sd[prefix + name]
+            if not isinstance(t, torch.Tensor):
+                t = torch.from_numpy(t)
+            return t.detach().to(device=self.dev, dtype=torch.float32)
+
+        def fold(conv, bn):
+            """conv (no bias) + BatchNorm(eval): W' = W * s, b' = beta - mean * s, s = gamma / sqrt(var + eps)."""
+            w = g(conv + ".weight")
+            s_ = g(bn + ".weight") / torch.sqrt(g(bn + ".running_var") + 1e-5)
+            b = g(bn + ".bias") - g(bn + ".running_mean") * s_
+            w = w * s_.reshape(-1, 1, 1, 1)
+            cout, cin, k, _ = w.shape
+            w2 = w.permute(0, 2, 3, 1).reshape(cout, k * k * cin)                 # tap-major: (ky, kx, cin)
+            kpad = _round_up(w2.shape[1], self.kq)
+            wp = torch.zeros(cout, kpad, device=self.dev, dtype=torch.float32)
+            wp[:, :w2.shape[1]] = w2
+            return wp.to(self.cd).contiguous(), b.contiguous()
+
+        self.stem = [fold("conv1", "bn1"), fold("conv2", "bn2"), fold("conv3", "bn3")]
+        self.blocks = []
+        inplanes = self.width
+        for li, (planes, nb) in enumerate(zip((self.width, self.width * 2, self.width * 4, self.width * 8), self.layers), 1):
+            for bi in range(nb):
+                stride = 2 if (li > 1 and bi == 0) else 1
+                b = "layer%d.%d." % (li, bi)
+                blk = dict(stride=stride, planes=planes, inplanes=inplanes, c1=fold(b + "conv1", b + "bn1"),
+                           c2=fold(b + "conv2", b + "bn2"), c3=fold(b + "conv3", b + "bn3"), down=None)
+                if stride > 1 or inplanes != planes * 4:
+                    blk["down"] = fold(b + "downsample.0", b + "downsample.1")
+                self.blocks.append(blk)
+                inplanes = planes * 4
+        self.C = inplanes
+        self.pos = g("attnpool.positional_embedding").contiguous()
+        self.w_qkv = torch.cat([g("attnpool.q_proj.weight"), g("attnpool.k_proj.weight"), g("attnpool.v_proj.weight")], 0).to(self.cd).contiguous()
+        self.b_qkv = torch.cat([g("attnpool.q_proj.bias"), g("attnpool.k_proj.bias"), g("attnpool.v_proj.bias")], 0).contiguous()
+        self.w_c = g("attnpool.c_proj.weight").contiguous()                     # final projection in fp32
+        self.b_c = g("attnpool.c_proj.bias").contiguous()
+
+    def _conv3x3(self, x, F_, H, W, C, wb, stride):
+        w, b = wb
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        cols = torch.empty(F_ * Ho * Wo, w.shape[1], device=self.dev, dtype=self.cd)
+        hip.im2col3x3(x, cols, F_, H, W, C, stride)
+        out = torch.empty(F_ * Ho * Wo, w.shape[0], device=self.dev, dtype=self.cd)
+        hip.gemm(cols, w, out, bias=b, relu=True)
+        return out, Ho, Wo
+
+    def _pool(self, x, F_, H, W, C):
+        out = torch.empty(F_ * (H // 2) * (W // 2), C, device=self.dev, dtype=self.cd)
+        hip.avgpool2x2(x, out, F_, H, W, C)
+        return out
+
+    def forward(self, frame_sets, feats_out=None, row_maps=None, taps=None):
+        if isinstance(frame_sets, torch.Tensor):
+            frame_sets = [frame_sets]
+        counts = [int(f.shape[0]) for f in frame_sets]
+        F_ = sum(counts)
+        if row_maps is None:
+            row_maps, off = [], 0
+            for c in counts:
+                row_maps.append((0, 0, off))
+                off += c
+        if feats_out is None:
+            feats_out = torch.empty(F_, self.E, device=self.dev, dtype=torch.float32)
+        res = self.arch["res"]
+        x = torch.empty(F_ * res * res, 3, device=self.dev, dtype=self.cd)
+        off = 0
+        for fr, c in zip(frame_sets, counts):
+            if fr.shape[1:] != (3, res, res):
+                raise RuntimeError("frames must be [F,3,%d,%d], got %s" % (res, res, tuple(fr.shape)))
+            hip.nchw_to_nhwc(fr, x[off * res * res:(off + c) * res * res])
+            off += c
+        H = W = res
+        x, H, W = self._conv3x3(x, F_, H, W, 3, self.stem[0], 2)                         # stem (:582-586)
+        x, H, W = self._conv3x3(x, F_, H, W, self.width // 2, self.stem[1], 1)
+        x, H, W = self._conv3x3(x, F_, H, W, self.width // 2, self.stem[2], 1)
+        x = self._pool(x, F_, H, W, self.width)
+        H, W = H // 2, W // 2
+        for blk in self.blocks:                                                          # Bottleneck.forward (:213-226)
+            p_, inp, st = blk["planes"], blk["inplanes"], blk["stride"]
+            M = F_ * H * W
+            o1 = torch.empty(M, p_, device=self.dev, dtype=self.cd)
+            hip.gemm(x, blk["c1"][0], o1, bias=blk["c1"][1], relu=True)
+            o2, _, _ = self._conv3x3(o1, F_, H, W, p_, blk["c2"], 1)
+            xi = x
+            if st > 1:
+                o2 = self._pool(o2, F_, H, W, p_)
+                xi = self._pool(x, F_, H, W, inp)
+                H, W = H // 2, W // 2
+                M = F_ * H * W
+            if blk["down"] is not None:
+                idn = torch.empty(M, 4 * p_, device=self.dev, dtype=self.cd)
+                hip.gemm(xi, blk["down"][0], idn, bias=blk["down"][1])
+            else:
+                idn = xi
+            out = torch.empty(M, 4 * p_, device=self.dev, dtype=self.cd)
+            hip.gemm(o2, blk["c3"][0], out, bias=blk["c3"][1], residual=idn, relu=True)
+            x = out
+        if taps is not None:
+            taps["layer4"] = x.clone()
+        HW, C = H * W, self.C                                                            # AttentionPool2d (:446-538)
+        tok = torch.empty(F_ * (HW + 1), C, device=self.dev, dtype=self.cd)
+        hip.attnpool_tokens(x, self.pos, tok, F_, HW, C)
+        qkv = torch.empty(F_ * (HW + 1), 3 * C, device=self.dev, dtype=torch.float32)
+        hip.gemm(tok, self.w_qkv, qkv, bias=self.b_qkv)
+        att = torch.empty(F_ * (HW + 1), C, device=self.dev, dtype=torch.float32)
+        hd = C // self.heads
+        hip.seq_attention(qkv, att, F_, HW + 1, 0, 0, self.heads, hd, hd ** -0.5)
+        idx = (torch.arange(F_, device=self.dev, dtype=torch.int32) * (HW + 1)).contiguous()   # query = the mean token
+        pooled = torch.empty(F_, C, device=self.dev, dtype=torch.float32)
+        hip.gather_rows(att, idx, pooled)
+        off = 0
+        for c, (rg, gap, roff) in zip(counts, row_maps):
+            hip.gemm(pooled[off:off + c], self.w_c, feats_out, bias=self.b_c, M=c, N=self.E, K=C, ldo=self.E,
+                     row_group=rg, row_gap=gap, row_off=roff)
+            off += c
+        return feats_out
+
+
 class HipTemporalHead:
     """context2 (Transformer_v1) + prototypes + cosine/OTAM -> logits, fp32 (few_shot.py:2937-2990)."""
 
@@ -215,7 +355,8 @@ class ClipFsarEngine:
                  device="cuda", max_frames: int = 1280):
         self.dev = torch.device(device)
         self.arch = dict(arch)
-        self.vit = HipViT(arch, head_sd, prefix="backbone.", precision=precision, device=device)
+        tower = HipResNet if arch.get("kind") == "rn" else HipViT
+        self.vit = tower(arch, head_sd, prefix="backbone.", precision=precision, device=device)
         self.temporal = HipTemporalHead(head_sd, arch["embed"], depth=depth, device=device)
         f32 = lambda t: (t if isinstance(t, torch.Tensor) else torch.from_numpy(t)).detach().to(
             device=self.dev, dtype=torch.float32).contiguous()

@@ -27,6 +27,11 @@ SIGNATURES = {
     "cfsar_cls_rows": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_layernorm": [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p],
     "cfsar_gemm": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 15 + [_c_p],
+    "cfsar_gemm_ex": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 17 + [_c_p],
+    "cfsar_nchw_to_nhwc": [_c_p, _c_p] + [_c_int] * 5 + [_c_p],
+    "cfsar_im2col3x3_nhwc": [_c_p, _c_p] + [_c_int] * 7 + [_c_p],
+    "cfsar_avgpool2x2_nhwc": [_c_p, _c_p] + [_c_int] * 5 + [_c_p],
+    "cfsar_attnpool_tokens": [_c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_p],
     "cfsar_vit_attention": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_class_text_logits": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_build_sequences": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p],
@@ -126,8 +131,8 @@ def layernorm(x, out, weight, bias, rows, D, in_stride=None, out_stride=None, ep
 
 
 def gemm(A, W, out, bias=None, residual=None, act=ACT_NONE, M=None, N=None, K=None, lda=None, ldw=None, ldo=None,
-         ldr=None, row_group=0, row_gap=0, row_off=0, res_mod=0, res_off=0):
-    """out = act(A @ W.T + bias) + residual (see include/clipfsar_hip.h: cfsar_gemm)."""
+         ldr=None, row_group=0, row_gap=0, row_off=0, res_mod=0, res_off=0, relu=False):
+    """out = [relu](act(A @ W.T + bias) + residual) (see include/clipfsar_hip.h: cfsar_gemm / cfsar_gemm_ex)."""
     if A.dtype != W.dtype:
         raise RuntimeError("gemm: A and W dtypes differ (%s vs %s)" % (A.dtype, W.dtype))
     M = A.shape[0] if M is None else M
@@ -137,6 +142,14 @@ def gemm(A, W, out, bias=None, residual=None, act=ACT_NONE, M=None, N=None, K=No
     ldw = W.shape[1] if ldw is None else ldw
     ldo = out.shape[-1] if ldo is None else ldo
     ldr = (residual.shape[-1] if residual is not None else 0) if ldr is None else ldr
+    if relu or (residual is not None and residual.dtype != torch.float32):
+        _check(lib().cfsar_gemm_ex(_dev(A, None, "A"), _dev(W, None, "W"), _dev(out, None, "out"),
+                                   _opt(bias, torch.float32, "bias"), _opt(residual, None, "residual"),
+                                   M, N, K, lda, ldw, ldo, ldr, _code(A.dtype), _code(out.dtype), act,
+                                   row_group, row_gap, row_off, res_mod, res_off,
+                                   _code(residual.dtype) if residual is not None else F32, int(bool(relu)), _stream()),
+               "cfsar_gemm_ex")
+        return
     _check(lib().cfsar_gemm(_dev(A, None, "A"), _dev(W, None, "W"), _dev(out, None, "out"),
                             _opt(bias, torch.float32, "bias"), _opt(residual, torch.float32, "residual"),
                             M, N, K, lda, ldw, ldo, ldr, _code(A.dtype), _code(out.dtype), act,
@@ -209,3 +222,27 @@ def combine_logits(text_probs, visual_logits, out, n_queries, way, text_coff):
     _check(lib().cfsar_combine_logits(_dev(text_probs, torch.float32, "text_probs"),
                                       _dev(visual_logits, torch.float32, "visual_logits"), _dev(out, torch.float32, "out"),
                                       n_queries, way, float(text_coff), _stream()), "cfsar_combine_logits")
+
+
+# ----------------------------------------------------------------------------------------------- N3 RN50 tower helpers
+def nchw_to_nhwc(frames, out):
+    F_, C, H, W = frames.shape
+    _check(lib().cfsar_nchw_to_nhwc(_dev(frames, torch.float32, "frames"), _dev(out, None, "out"), _code(out.dtype), F_, C, H,
+                                    W, _stream()), "cfsar_nchw_to_nhwc")
+
+
+def im2col3x3(x, out, F_, H, W, C, stride):
+    if x.dtype != out.dtype:
+        raise RuntimeError("im2col3x3: dtype mismatch")
+    _check(lib().cfsar_im2col3x3_nhwc(_dev(x, None, "x"), _dev(out, None, "out"), _code(x.dtype), F_, H, W, C, stride,
+                                      out.shape[1], _stream()), "cfsar_im2col3x3_nhwc")
+
+
+def avgpool2x2(x, out, F_, H, W, C):
+    _check(lib().cfsar_avgpool2x2_nhwc(_dev(x, None, "x"), _dev(out, x.dtype, "out"), _code(x.dtype), F_, H, W, C, _stream()),
+           "cfsar_avgpool2x2_nhwc")
+
+
+def attnpool_tokens(x, pos, out, F_, HW, C):
+    _check(lib().cfsar_attnpool_tokens(_dev(x, None, "x"), _dev(pos, torch.float32, "pos"), _dev(out, x.dtype, "out"),
+                                       _code(x.dtype), F_, HW, C, _stream()), "cfsar_attnpool_tokens")

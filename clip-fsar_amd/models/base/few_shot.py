@@ -46,7 +46,11 @@ def _nested_params(module: nn.Module, flat: dict):
             if p not in m._modules:
                 m.add_module(p, nn.Module())
             m = m._modules[p]
-        m.register_parameter(parts[-1], nn.Parameter(torch.as_tensor(value).clone().float(), requires_grad=False))
+        t = torch.as_tensor(value).clone()
+        if parts[-1] in ("running_mean", "running_var", "num_batches_tracked"):     # BatchNorm buffers of the RN tower
+            m.register_buffer(parts[-1], t if parts[-1] == "num_batches_tracked" else t.float())
+        else:
+            m.register_parameter(parts[-1], nn.Parameter(t.float(), requires_grad=False))
 
 
 class CNN_FSHead(nn.Module):
@@ -63,14 +67,11 @@ class CNN_FSHead(nn.Module):
 
 @HEAD_REGISTRY.register()
 class CNN_OTAM_CLIPFSAR(CNN_FSHead):
-    SUPPORTED = ("ViT-B/16", "ViT-L/14")
+    SUPPORTED = ("RN50", "ViT-B/16", "ViT-L/14")
 
     def __init__(self, cfg):
         super().__init__(cfg)
         name = cfg.VIDEO.HEAD.BACKBONE_NAME
-        if name == "RN50":
-            raise NotImplementedError("BACKBONE_NAME 'RN50' (ModifiedResNet tower) is not built yet (SURVEY.md 8(f) N3); "
-                                      "use 'ViT-B/16'")
         if name not in synth.ARCHS:
             raise ValueError("unsupported BACKBONE_NAME %r (supported: %s)" % (name, ", ".join(self.SUPPORTED)))
         self.arch_name = name
@@ -84,12 +85,12 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
         self.precision = str(getattr(cfg.VIDEO.HEAD, "PRECISION", "bf16"))
 
         # ---- parameters under the reference's names
-        vis = synth.vit_state_dict(name, seed)
+        vis = synth.visual_state_dict(name, seed)
         wpath = getattr(cfg.VIDEO.HEAD, "CLIP_VISUAL_WEIGHTS", None)
         if wpath:
             loaded = torch.load(wpath, map_location="cpu")
             loaded = {k[len("visual."):] if k.startswith("visual.") else k: v for k, v in loaded.items()}
-            vis = {k: loaded[k].float().numpy() for k in vis}
+            vis = {k: (loaded[k].float().numpy() if loaded[k].is_floating_point() else loaded[k].numpy()) for k in vis}
         self.backbone = nn.Module()
         _nested_params(self.backbone, vis)
         self.context2 = nn.Module()
@@ -125,7 +126,7 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
         src = cfg.VIDEO.HEAD.TEXT_TOWER
         seed = int(getattr(cfg, "RANDOM_SEED", 18))
         if src == "synthetic":
-            tsd = ctext.text_tower_state_dict(width=512 if self.mid_dim == 512 else 768, layers=12, embed=self.mid_dim,
+            tsd = ctext.text_tower_state_dict(width=768 if self.mid_dim == 768 else 512, layers=12, embed=self.mid_dim,
                                               seed=seed)
         else:
             tsd = {k: v for k, v in torch.load(src, map_location="cpu").items() if not k.startswith("visual.")}
@@ -141,7 +142,7 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
     # ------------------------------------------------------------------ engine (device-side packed weights)
     def _get_engine(self, device):
         from ...engine import ClipFsarEngine        # imported lazily: constructing the head needs no GPU
-        key = (str(device), self.precision, tuple(p._version for p in self.parameters()))
+        key = (str(device), self.precision, tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers()))
         if self.text_features_train is None or self.text_features_test is None:
             self._encode_text_tables(device)
         if self._engine is None or self._engine_key != key:

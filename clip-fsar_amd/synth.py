@@ -33,6 +33,9 @@ ARCHS = {
     "ViT-test/16": dict(width=128, layers=2, heads=2, patch=16, res=64, embed=64),
     "ViT-test197/16": dict(width=128, layers=2, heads=2, patch=16, res=224, embed=64),
     "ViT-test257/14": dict(width=128, layers=2, heads=2, patch=14, res=224, embed=64),
+    # N3: CLIP ModifiedResNet towers (few_shot.py:542-602; RN50 hyper-parameters per `build_model` :859-866, :720-728)
+    "RN50": dict(kind="rn", layers=(3, 4, 6, 3), width=64, res=224, embed=1024, heads=32),
+    "RN-test": dict(kind="rn", layers=(1, 1, 1, 1), width=64, res=64, embed=64, heads=32),
 }
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # reference yaml DATA.MEAN (K100 1-shot :49)
@@ -131,6 +134,56 @@ def vit_state_dict(arch: str, seed: int = 18, prefix: str = "") -> "OrderedDict[
     return sd
 
 
+def rn_state_dict(arch: str, seed: int = 18, prefix: str = "") -> "OrderedDict[str, np.ndarray]":
+    """Random-init CLIP ModifiedResNet with the reference's parameter / buffer names (few_shot.py:182-227 Bottleneck,
+    :435-444 AttentionPool2d, :542-579 ModifiedResNet): He-scaled convs, non-trivial BatchNorm affine and running stats
+    (eval mode uses the running stats)."""
+    a = ARCHS[arch]
+    width, layers, E = a["width"], a["layers"], a["embed"]
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def put(key, shape, std, mean=0.0):
+        sd[prefix + key] = tensor(shape, arch + "/" + key, std=std, mean=mean, seed=seed)
+
+    def conv(key, cout, cin, k):
+        put(key + ".weight", (cout, cin, k, k), (2.0 / (cin * k * k)) ** 0.5)
+
+    def bn(key, c, gamma=1.0):
+        put(key + ".weight", (c,), 0.1, gamma)
+        put(key + ".bias", (c,), 0.1)
+        put(key + ".running_mean", (c,), 0.1)
+        sd[prefix + key + ".running_var"] = (np.abs(tensor((c,), arch + "/" + key + ".rv", std=0.2, seed=seed)) + 0.6).astype(np.float32)
+        sd[prefix + key + ".num_batches_tracked"] = np.asarray(0, np.int64)
+
+    conv("conv1", width // 2, 3, 3); bn("bn1", width // 2)
+    conv("conv2", width // 2, width // 2, 3); bn("bn2", width // 2)
+    conv("conv3", width, width // 2, 3); bn("bn3", width)
+    inplanes = width
+    for li, (planes, blocks) in enumerate(zip((width, width * 2, width * 4, width * 8), layers), start=1):
+        for bi in range(blocks):
+            stride = 2 if (li > 1 and bi == 0) else 1
+            b = "layer%d.%d." % (li, bi)
+            conv(b + "conv1", planes, inplanes, 1); bn(b + "bn1", planes)
+            conv(b + "conv2", planes, planes, 3); bn(b + "bn2", planes)
+            conv(b + "conv3", planes * 4, planes, 1); bn(b + "bn3", planes * 4, gamma=0.25)
+            if stride > 1 or inplanes != planes * 4:
+                conv(b + "downsample.0", planes * 4, inplanes, 1); bn(b + "downsample.1", planes * 4, gamma=0.6)
+            inplanes = planes * 4
+    C = width * 32
+    sp = (a["res"] // 32) ** 2 + 1
+    put("attnpool.positional_embedding", (sp, C), C ** -0.5)
+    for n in ("k_proj", "q_proj", "v_proj"):
+        put("attnpool.%s.weight" % n, (C, C), C ** -0.5)
+        put("attnpool.%s.bias" % n, (C,), 0.05)
+    put("attnpool.c_proj.weight", (E, C), C ** -0.5)
+    put("attnpool.c_proj.bias", (E,), 0.05)
+    return sd
+
+
+def visual_state_dict(arch: str, seed: int = 18, prefix: str = ""):
+    return rn_state_dict(arch, seed, prefix) if ARCHS[arch].get("kind") == "rn" else vit_state_dict(arch, seed, prefix)
+
+
 def context2_state_dict(dim: int, heads: int = 8, dim_head: int | None = None, mlp_dim: int = 2048,
                         depth: int = 1, seed: int = 18, prefix: str = "") -> "OrderedDict[str, np.ndarray]":
     """Temporal transformer ``Transformer_v1`` weights (few_shot.py:979-989; Attention_qkv
@@ -165,7 +218,7 @@ def head_state_dict(arch: str, seed: int = 18, depth: int = 1, mlp_dim: int = 20
     E = ARCHS[arch]["embed"]
     sd = OrderedDict()
     sd["scale"] = np.ones((1,), np.float32)                      # few_shot.py:2733-2734
-    sd.update(vit_state_dict(arch, seed, prefix="backbone."))
+    sd.update(visual_state_dict(arch, seed, prefix="backbone."))
     sd.update(context2_state_dict(E, 8, E // 8, mlp_dim, depth, seed, prefix="context2."))
     return sd
 
@@ -186,14 +239,18 @@ def _perm(n: int, name: str, seed: int) -> np.ndarray:
 
 
 def make_episode(way: int = 5, shot: int = 1, query_per_class: int = 1, frames: int = 8, res: int = 224,
-                 n_test_classes: int = 24, episode: int = 0, seed: int = 18, dtype=np.float32):
+                 n_test_classes: int = 24, episode: int = 0, seed: int = 18, dtype=np.float32,
+                 lowfreq: float = 0.0):
     """One synthetic episode with the layout of Ssv2_few_shot.__getitem__
     (datasets/base/ssv2_few_shot.py:275-285) after the loader batch dim is stripped
     (runs/test_net_few_shot.py:62).
 
     Frames are *structured* (SURVEY.md 8(d)): a per-real-class base pattern + per-video
     + per-frame noise in CLIP-normalised pixel space, so that logits carry signal.
-    Videos are shuffled independently in the support and target lists (:267-273)."""
+    Videos are shuffled independently in the support and target lists (:267-273).
+
+    ``lowfreq`` > 0 adds a per-class coarse pattern (8x8 cells per channel, nearest-upsampled): a convolutional tower
+    with global pooling averages white noise away, so the RN50 cases need class signal below the stem's cut-off."""
     es = seed * 1000003 + episode
     S, Q, T = way * shot, way * query_per_class, frames
     classes = _perm(n_test_classes, "ep/classes", es)[:way]          # batch_class_list
@@ -201,6 +258,11 @@ def make_episode(way: int = 5, shot: int = 1, query_per_class: int = 1, frames: 
 
     def video(real_cls: int, vid_tag: str) -> np.ndarray:
         base = pseudo_normal(npx, "frame/class%d" % real_cls, seed)           # same across episodes
+        if lowfreq:
+            cell = -(-res // 8)
+            coarse = pseudo_normal(3 * 64, "frame/class_lowfreq%d" % real_cls, seed).reshape(3, 8, 8)
+            coarse = np.repeat(np.repeat(coarse, cell, 1), cell, 2)[:, :res, :res]
+            base = base + lowfreq * coarse.reshape(-1)
         vn = pseudo_normal(npx, "frame/video/" + vid_tag, es)
         out = np.empty((T, npx), dtype=np.float64)
         for t in range(T):

@@ -74,6 +74,25 @@ int cfsar_gemm(const void* A, const void* W, void* out, const float* bias, const
                int K, int lda, int ldw, int ldo, int ldr, int in_dtype, int out_dtype, int act, int row_group,
                int row_gap, int row_off, int res_mod, int res_off, cfsar_stream_t stream);
 
+/* Same as cfsar_gemm with two extras used by the RN50 tower (N3): the residual may be bf16 (res_dtype) and, when
+ * relu != 0, max(.,0) is applied LAST (after bias, activation and residual): conv+BN(+identity)+ReLU, few_shot.py:213-226. */
+int cfsar_gemm_ex(const void* A, const void* W, void* out, const float* bias, const void* residual, int M, int N,
+                  int K, int lda, int ldw, int ldo, int ldr, int in_dtype, int out_dtype, int act, int row_group,
+                  int row_gap, int row_off, int res_mod, int res_off, int res_dtype, int relu, cfsar_stream_t stream);
+
+/* ---- N3 ModifiedResNet ("RN50") tower helpers (few_shot.py:182-227, 542-602); activations are NHWC.
+ * cfsar_nchw_to_nhwc: frames [F,C,H,W] f32 -> [F,H,W,C] (out_dtype).
+ * cfsar_im2col3x3_nhwc: 3x3 / pad 1 / stride 1|2 gather, in [F,H,W,C] -> out [F*Ho*Wo, k_pad], column (ky*3+kx)*C + c,
+ *   zeros outside the image and in pad columns (nn.Conv2d(k=3, padding=1) as a GEMM with tap-major weights).
+ * cfsar_avgpool2x2_nhwc: nn.AvgPool2d(2).
+ * cfsar_attnpool_tokens: AttentionPool2d token build (:446-448): [mean_hw(x) ; x] + positional_embedding. */
+int cfsar_nchw_to_nhwc(const float* frames, void* out, int out_dtype, int F, int C, int H, int W, cfsar_stream_t stream);
+int cfsar_im2col3x3_nhwc(const void* in, void* out, int dtype, int F, int H, int W, int C, int stride, int k_pad,
+                         cfsar_stream_t stream);
+int cfsar_avgpool2x2_nhwc(const void* in, void* out, int dtype, int F, int H, int W, int C, cfsar_stream_t stream);
+int cfsar_attnpool_tokens(const void* x, const float* pos, void* out, int dtype, int F, int HW, int C,
+                          cfsar_stream_t stream);
+
 /* ---- A5 scaled-dot-product attention of nn.MultiheadAttention for the ViT (no mask, no dropout), head_dim 64.
  * qkv [F*ntok, 3*D] packed as [q | k | v], head h at columns h*64 of each third; out [F*ntok, D].
  * dtype bf16: MFMA kernel (K and V^T of one (frame, head) staged in LDS, single-pass softmax in registers);

@@ -95,6 +95,55 @@ def vit_forward(frames, sd, arch, prefix: str = "backbone.", chunk: int = 40, ta
     return torch.cat(outs, 0)
 
 
+# ------------------------------------------------------------------ N3 ModifiedResNet (:182-227, :435-539, :542-602)
+def _conv_bn(x, sd, conv, bn, padding=0, stride=1, relu=True):
+    x = torch.nn.functional.conv2d(x, sd[conv + ".weight"], None, stride=stride, padding=padding)
+    x = torch.nn.functional.batch_norm(x, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"],
+                                       sd[bn + ".bias"], training=False, eps=1e-5)
+    return torch.relu(x) if relu else x
+
+
+def resnet_forward(frames, sd, arch, prefix: str = "backbone.", chunk: int = 40):
+    """CLIP ModifiedResNet eval forward: 3-conv stem + avgpool (:582-587), Bottlenecks with avgpool anti-aliasing
+    (:213-226), AttentionPool2d with the mean token as the only query (:515-538, spatial=False)."""
+    outs = []
+    width, layers, heads = arch["width"], arch["layers"], arch["heads"]
+    P = prefix
+    for s0 in range(0, frames.shape[0], chunk):
+        x = frames[s0:s0 + chunk]
+        x = _conv_bn(x, sd, P + "conv1", P + "bn1", padding=1, stride=2)
+        x = _conv_bn(x, sd, P + "conv2", P + "bn2", padding=1)
+        x = _conv_bn(x, sd, P + "conv3", P + "bn3", padding=1)
+        x = torch.nn.functional.avg_pool2d(x, 2)
+        inplanes = width
+        for li, (planes, blocks) in enumerate(zip((width, width * 2, width * 4, width * 8), layers), start=1):
+            for bi in range(blocks):
+                stride = 2 if (li > 1 and bi == 0) else 1
+                b = "%slayer%d.%d." % (P, li, bi)
+                out = _conv_bn(x, sd, b + "conv1", b + "bn1")
+                out = _conv_bn(out, sd, b + "conv2", b + "bn2", padding=1)
+                if stride > 1:
+                    out = torch.nn.functional.avg_pool2d(out, stride)
+                out = _conv_bn(out, sd, b + "conv3", b + "bn3", relu=False)
+                idn = x
+                if stride > 1 or inplanes != planes * 4:
+                    idn = torch.nn.functional.avg_pool2d(x, stride) if stride > 1 else x
+                    idn = _conv_bn(idn, sd, b + "downsample.0", b + "downsample.1", relu=False)
+                x = torch.relu(out + idn)
+                inplanes = planes * 4
+        F_, C = x.shape[0], x.shape[1]
+        t = x.flatten(start_dim=2).permute(0, 2, 1)                                   # [F, HW, C]
+        t = torch.cat([t.mean(dim=1, keepdim=True), t], dim=1) + sd[P + "attnpool.positional_embedding"]
+        hd = C // heads
+        q = (t[:, :1] @ sd[P + "attnpool.q_proj.weight"].t() + sd[P + "attnpool.q_proj.bias"]).reshape(F_, 1, heads, hd).transpose(1, 2)
+        k = (t @ sd[P + "attnpool.k_proj.weight"].t() + sd[P + "attnpool.k_proj.bias"]).reshape(F_, -1, heads, hd).transpose(1, 2)
+        v = (t @ sd[P + "attnpool.v_proj.weight"].t() + sd[P + "attnpool.v_proj.bias"]).reshape(F_, -1, heads, hd).transpose(1, 2)
+        att = torch.softmax((q @ k.transpose(-1, -2)) * (hd ** -0.5), dim=-1)
+        o = (att @ v).transpose(1, 2).reshape(F_, C)
+        outs.append(o @ sd[P + "attnpool.c_proj.weight"].t() + sd[P + "attnpool.c_proj.bias"])
+    return torch.cat(outs, 0)
+
+
 # ------------------------------------------------------------------ A11 Transformer_v1 (:971-999,:1035-1073,:1643-1654)
 def context2_forward(x, sd, heads: int = 8, prefix: str = "context2.", depth: int = 1):
     """x [B,L,E] used as q=k=v.  Layer 0: ONE shared LayerNorm for q,k,v (:971-977); to_q/k/v
@@ -165,8 +214,9 @@ def head_forward(episode, sd, text_train, text_test, arch, frames: int, merge_be
     """episode: the A0 dict of torch tensors.  Returns {'logits' [Q,way], 'class_logits' [(S+Q),n_train]}."""
     T = frames
     sup_lab = episode["support_labels"]
-    feats_s = vit_forward(episode["support_set"], sd, arch)                      # :2761
-    feats_q = vit_forward(episode["target_set"], sd, arch)                       # :2762
+    tower = resnet_forward if arch.get("kind") == "rn" else vit_forward
+    feats_s = tower(episode["support_set"], sd, arch)                            # :2761
+    feats_q = tower(episode["target_set"], sd, arch)                             # :2762
     E = feats_s.shape[-1]
     Fs = feats_s.reshape(-1, T, E)                                               # :2765
     Fq = feats_q.reshape(-1, T, E)                                               # :2764

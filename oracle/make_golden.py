@@ -40,6 +40,9 @@ HEAD_CASES = {
     "t_5w2s_T4_sd": dict(arch="ViT-test/16", way=5, shot=2, q=1, T=4, single_direct=True),
     "t197_5w1s_T2": dict(arch="ViT-test197/16", way=5, shot=1, q=1, T=2),
     "t257_5w1s_T2": dict(arch="ViT-test257/14", way=5, shot=1, q=1, T=2),
+    # N3: ModifiedResNet towers (small test tower; the real RN50 through the reference head's own "RN50" branch)
+    "rn_t_5w2s_T4": dict(arch="RN-test", way=5, shot=2, q=1, T=4, lowfreq=2.0),
+    "rn50_5w1s_T2": dict(arch="RN50", way=5, shot=1, q=1, T=2, large=True, lowfreq=2.0),
     # BASELINE.json configs at full size
     "cfg2_B16_5w1s_T8": dict(arch="ViT-B/16", way=5, shot=1, q=1, T=8, large=True),
     "cfg3_B16_5w5s_T8_mb": dict(arch="ViT-B/16", way=5, shot=5, q=1, T=8, merge_before=True, large=True),
@@ -61,7 +64,7 @@ def run_head_case(name, p):
     head = rh.build_reference_head(cfg, a, sd, tt, te)
     fs = rh.import_reference()
     ep = synth.make_episode(way=p["way"], shot=p["shot"], query_per_class=p["q"], frames=p["T"], res=a["res"],
-                            n_test_classes=N_TEST, episode=0, seed=SEED)
+                            n_test_classes=N_TEST, episode=0, seed=SEED, lowfreq=p.get("lowfreq", 0.0))
     taps = {"vit": [], "ctx": []}
     h1 = head.backbone.register_forward_hook(lambda m, i, o: taps["vit"].append(o.detach().clone()))
     h2 = head.context2.register_forward_hook(lambda m, i, o: taps["ctx"].append(o.detach().clone()))

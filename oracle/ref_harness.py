@@ -137,19 +137,23 @@ def build_reference_head(cfg, arch_params, head_sd_np, text_train, text_test):
     fs = import_reference()
     a = arch_params
     E = a["embed"]
-    vit = fs.VisionTransformer(input_resolution=a["res"], patch_size=a["patch"], width=a["width"],
-                               layers=a["layers"], heads=a["heads"], output_dim=E).float()
+    if a.get("kind") == "rn":
+        vit = fs.ModifiedResNet(layers=a["layers"], output_dim=E, heads=a["heads"], input_resolution=a["res"],
+                                width=a["width"]).float()
+    else:
+        vit = fs.VisionTransformer(input_resolution=a["res"], patch_size=a["patch"], width=a["width"],
+                                   layers=a["layers"], heads=a["heads"], output_dim=E).float()
     old_load, old_tok = fs.load, fs.tokenize
     fs.load = lambda name, device="cpu", cfg=None, jit=False: (_FakeCLIP(vit, E), None)
     fs.tokenize = lambda texts, *a_, **k_: torch.zeros(len(texts), 77, dtype=torch.long)
     real_name = cfg.VIDEO.HEAD.BACKBONE_NAME
     try:
-        cfg.VIDEO.HEAD.BACKBONE_NAME = "ViT-B/16"
+        cfg.VIDEO.HEAD.BACKBONE_NAME = "RN50" if E == 1024 else "ViT-B/16"      # the head's own RN50 branch (:2699-2704)
         head = fs.CNN_OTAM_CLIPFSAR(cfg)
     finally:
         cfg.VIDEO.HEAD.BACKBONE_NAME = real_name
         fs.load, fs.tokenize = old_load, old_tok
-    if E != 512:
+    if E not in (512, 1024):
         head.mid_dim = E
         depth = int(getattr(cfg.TRAIN, "TRANSFORMER_DEPTH", 0) or 1)
         head.context2 = fs.Transformer_v1(dim=E, heads=8, dim_head_k=E // 8, dropout_atte=0.2, depth=depth)

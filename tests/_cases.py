@@ -11,7 +11,7 @@ import clip_fsar_amd.synth as synth
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SMALL_CASES = ["t_5w1s_T8", "t_5w5s_T8_mb", "t_5w5s_q2_T8", "t_5w3s_T16_mb_d2", "t_5w2s_T4_sd", "t197_5w1s_T2",
-               "t257_5w1s_T2"]
+               "t257_5w1s_T2", "rn_t_5w2s_T4"]
 
 
 def load_golden(name):
@@ -30,7 +30,8 @@ def case_inputs(meta, episode=None):
     te = torch.from_numpy(synth.text_features(meta["n_test"], a["embed"], "test", meta["seed"]))
     ep = synth.make_episode(way=meta["way"], shot=meta["shot"], query_per_class=meta["q"], frames=meta["T"],
                             res=a["res"], n_test_classes=meta["n_test"],
-                            episode=meta["episode"] if episode is None else episode, seed=meta["seed"])
+                            episode=meta["episode"] if episode is None else episode, seed=meta["seed"],
+                            lowfreq=meta.get("lowfreq", 0.0))
     ep = {k: torch.from_numpy(v) for k, v in ep.items()}
     return a, sd, tt, te, ep
 

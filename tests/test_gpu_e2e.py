@@ -108,7 +108,8 @@ def test_cfg2_full_size_fp32_and_bf16():
     assert maxdiff(lb[0], g["logits"]) < 0.05
 
 
-@pytest.mark.parametrize("name,tol_feat", [("cfg3_B16_5w5s_T8_mb", 2e-3), ("cfg4_L14_5w1s_T16", 4e-3)])
+@pytest.mark.parametrize("name,tol_feat", [("cfg3_B16_5w5s_T8_mb", 2e-3), ("cfg4_L14_5w1s_T16", 4e-3),
+                                           ("rn50_5w1s_T2", 2e-3)])
 def test_cfg3_cfg4_full_size(name, tol_feat):
     """BASELINE config 3 (5-way 5-shot, MERGE_BEFORE as in the shipped 5-shot yaml) and config 4 (ViT-L/14, 16 frames:
     extension A16, oracle = the reference's own classes composed by the harness)."""

@@ -53,8 +53,10 @@ def test_builder_and_model_surface():
     model.train()
     with pytest.raises(NotImplementedError):
         model({"support_set": torch.zeros(1), "support_labels": None, "target_set": None, "real_support_labels": None})
-    with pytest.raises(NotImplementedError):
-        build_model(_cfg(arch="RN50"))
+    rn, _ = build_model(_cfg(arch="RN50"))                       # N3: the CLIP ModifiedResNet tower is built
+    assert rn.head.mid_dim == 1024 and "backbone.layer4.2.bn3.running_var" in rn.head.state_dict()
+    with pytest.raises(ValueError, match="unsupported BACKBONE_NAME"):
+        build_model(_cfg(arch="RN101"))
 
 
 def test_state_dict_names_and_shapes_match_reference():
