@@ -48,6 +48,10 @@ CONFIGS = {
                  name="BASELINE config[2]: 5-way 5-shot (MERGE_BEFORE), 1 query/class, 8x224^2 frames, ViT-B/16"),
     "cfg4": dict(arch="ViT-L/14", shot=1, T=16, merge_before=False, gflop=162.026,
                  name="BASELINE config[3]: 5-way 1-shot, 1 query/class, 16x224^2 frames, ViT-L/14 (extension A16)"),
+    # N3: the backbone of every shipped reference config (configs/projects/CLIPFSAR/*: BACKBONE_NAME "RN50").
+    # 11.997 GFLOP/frame = 2 x (5.367 GMAC convs + 0.631 GMAC attention pool), DESIGN.md (d).
+    "rn50": dict(arch="RN50", shot=1, T=8, merge_before=False, gflop=11.997,
+                 name="reference shipped backbone: 5-way 1-shot, 1 query/class, 8x224^2 frames, CLIP RN50"),
 }
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 

@@ -148,7 +148,7 @@ extern "C" int cfsar_im2col3x3_nhwc(const void* in, void* out, int dtype, int F,
 }
 
 extern "C" int cfsar_avgpool2x2_nhwc(const void* in, void* out, int dtype, int F, int H, int W, int C, cfsar_stream_t stream) {
-    CFSAR_REQUIRE(in && out && F > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0, "cfsar_avgpool2x2_nhwc: bad arguments");
+    CFSAR_REQUIRE(in && out && F > 0 && H > 1 && W > 1 && C > 0, "cfsar_avgpool2x2_nhwc: bad arguments");
     const long long total = (long long)F * (H / 2) * (W / 2) * C;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == CFSAR_BF16)

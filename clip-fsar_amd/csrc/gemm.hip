@@ -17,6 +17,9 @@
 //   * workgroup id -> tile mapping is XCD-aware (bijective remap: each XCD's L2 sees a contiguous band of tiles).
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -1200,8 +1203,584 @@ int launch_p5(const GemmArgs& a0, hipStream_t s) {
 }  // namespace
 
 static unsigned long long* g_trace = nullptr;
+static int g_variant_override = -1, g_dbg_override = -1;   // dev tool: in-process A/B (tools/gemm_ab.py)
+// ============================================================================================================
+// v6 ("p8"): 256(M) x 256(N) tile, 256 threads = ONE wave per SIMD (4 waves as 2 x 2, each wave 128 x 128 = 4x4 MFMA
+// 32x32 tiles, 256 accumulator registers out of the 512-entry unified VGPR/AGPR file).  Same 4-stage / 64-byte-slice
+// LDS ring and asm LDS-DMA as p4, but every fragment read from LDS now feeds FOUR MFMAs instead of 2.67 (LDS->VGPR
+// bytes per FLOP -33 % vs the 128x64 wave tile) and a single wave owns the SIMD's matrix pipe: its 16 independent
+// accumulator chains issue back to back while the ds_reads of the next 16-wide K sub-step and the DMA of slice kt+3
+// are in flight (software pipelining inside one wave instead of two waves taking turns).
+// ============================================================================================================
+template <typename TO, int ACT, bool HAS_RES>
+__global__ __launch_bounds__(256) void gemm_kernel_p8(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __bf16 TI;
+    constexpr int BK = ROWB4 / (int)sizeof(TI);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+    const int m0 = tm * BM4, n0 = tn * BN4;
+
+    // staging: each operand tile = 16 instructions of 16 rows x 64 B; wave w issues instructions {w, w+4, w+8, w+12}
+    const char* srcX[4];
+    const char* srcW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 4 + wave) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ swz4(row);
+        int gm = ((p.dbg & 8) ? 0 : m0) + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        int gn = ((p.dbg & 8) ? 0 : n0) + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
+        srcW[i] = p.W + ((size_t)gn * p.ldw) * sizeof(TI) + chunk * 16;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+    auto issue = [&](int kt) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)(kt & 3) * (unsigned)STAGE4);
+        const size_t koff = (size_t)kt * ROWB4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_asm(srcX[i] + koff, base + i * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_asm(srcW[i] + koff, base + BM4 * ROWB4 + i * 4096);
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, hi = lane >> 5;
+    int offX[4], offW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rx = wm * 128 + i * 32 + lr;
+        offX[i] = rx * ROWB4 + ((hi ^ swz4(rx)) << 4);                    // sub-step 0; sub-step 1 = ^ 32 (chunk ^ 2)
+        const int rw = wn * 128 + i * 32 + lr;
+        offW[i] = BM4 * ROWB4 + rw * ROWB4 + ((hi ^ swz4(rw)) << 4);
+    }
+    f32x16 acc[2][4][2];                                                   // [n half][mi][ni within the half]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.0f;
+
+    const int nk = p.K / BK;
+    uint4 xfA[4], wfA[4], xfB[4], wfB[4];
+    // One DMA instruction / one fragment read at a time, so that they can be interleaved 1:1 with the MFMAs below.
+    auto issue_one = [&](int kt, int j) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)(kt & 3) * (unsigned)STAGE4);
+        const size_t koff = (size_t)kt * ROWB4;
+        if (j < 4) glds16_asm(srcX[j] + koff, base + j * 4096);
+        else glds16_asm(srcW[j - 4] + koff, base + BM4 * ROWB4 + (j - 4) * 4096);
+    };
+    // read order = order of first use by the MFMA sequence (ni-major): x0 w0 x1 x2 x3 w1 w2 w3
+    auto load_one = [&](int kt, int s2, int j, uint4 (&xf)[4], uint4 (&wf)[4]) {
+        const char* base = smem + (kt & 3) * STAGE4;
+        const int x2 = s2 << 5;
+        constexpr int isx[8] = {1, 0, 1, 1, 1, 0, 0, 0};
+        constexpr int idx[8] = {0, 0, 1, 2, 3, 1, 2, 3};
+        if (isx[j]) xf[idx[j]] = *reinterpret_cast<const uint4*>(base + (offX[idx[j]] ^ x2));
+        else wf[idx[j]] = *reinterpret_cast<const uint4*>(base + (offW[idx[j]] ^ x2));
+    };
+    auto mfma_one = [&](int j, uint4 (&xf)[4], uint4 (&wf)[4]) {
+        const int ni = j >> 2, mi = j & 3;
+        acc[ni >> 1][mi][ni & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]), acc[ni >> 1][mi][ni & 1], 0, 0, 0);
+    };
+    // One K slice = 32 MFMAs per wave (2 sub-steps x 16).  Sub-step 0 carries the 8 fragment reads of sub-step 1 and the
+    // wave's 8 DMA instructions of slice kt+3; sub-step 1 carries the 8 fragment reads of slice kt+1 / sub-step 0: the
+    // matrix pipe is fed every 32 cycles while at most one other instruction group issues between two MFMAs.
+    // ISSUE / NEXT / VM8 are compile-time so that the steady-state loop has no branch: a conditional ds_read would force
+    // hipcc to the conservative lgkmcnt and stall every MFMA on the reads issued just before it.
+    auto step = [&](int kt, auto ISSUE, auto NEXT, auto VM8) {
+        if constexpr (decltype(VM8)::value) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(p.dbg & 2)) __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            mfma_one(j, xfA, wfA);
+            if (j < 8) load_one(kt, 1, j, xfB, wfB);
+            else if constexpr (decltype(ISSUE)::value) {
+                if (!(p.dbg & 1)) issue_one(kt + 3, j - 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            mfma_one(j, xfB, wfB);
+            if constexpr (decltype(NEXT)::value) {
+                if (j < 8) load_one(kt + 1, 0, j, xfA, wfA);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    issue(0);
+    issue(1);
+    issue(2);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) load_one(0, 0, j, xfA, wfA);
+    // Invariant at the barrier of step kt: slices <= kt+1 have landed for every wave (a wave leaves only its 8
+    // instructions of slice kt+2 in flight); slice kt+3 then goes into the stage of slice kt-1, last read one step ago.
+    int kt = 0;
+    for (; kt < nk - 3; ++kt) step(kt, T_{}, T_{}, T_{});
+    step(kt, F_{}, T_{}, T_{});          // nk-3: slices nk-2, nk-1 still to land
+    step(kt + 1, F_{}, T_{}, F_{});      // nk-2
+    step(kt + 2, F_{}, F_{}, F_{});      // nk-1
+    __syncthreads();
+    if (p.dbg & 4) {
+        if (acc[0][0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][1][3] + acc[0][3][1][2] + acc[1][2][0][1];
+        return;
+    }
+    char* wbuf = smem + wave * EPI_WAVE_BYTES;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 128 + nh * 64;
+            const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
+            if (full) epilogue_lds<TO, ACT, HAS_RES, false, true>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+            else epilogue_lds<TO, ACT, HAS_RES, false, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+        }
+}
+
+template <typename TO, int ACT, bool HAS_RES>
+int launch_p8_inst(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p8<TO, ACT, HAS_RES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel_p8<TO, ACT, HAS_RES>), dim3(a.ntiles), dim3(256), LDS4, s, a);
+    return cfsar_check_launch("cfsar_gemm(p8)");
+}
+
+template <typename TO>
+int launch_p8(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_n = (a.N + BN4 - 1) / BN4;
+    a.ntiles = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
+    const bool r = a.res != nullptr;
+    if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF || a.K < 96) return -2;   // >= 3 K slices
+    if (a.act == CFSAR_ACT_QUICKGELU) return r ? -2 : launch_p8_inst<TO, CFSAR_ACT_QUICKGELU, false>(a, s);
+    return r ? launch_p8_inst<TO, CFSAR_ACT_NONE, true>(a, s) : launch_p8_inst<TO, CFSAR_ACT_NONE, false>(a, s);
+}
+
+// ============================================================================================================
+// v7 ("p9"): p8's geometry (256x256 tile, ONE wave per SIMD, 128x128 wave tiles, 1:1 MFMA/filler interleave) with
+// REGISTER-STAGED operands: global_load_dwordx4 -> VGPR -> ds_write_b128 instead of LDS-DMA.  Measured on MI355X
+// (profiles/r01_gemm_ablation.md): an LDS-DMA instruction costs its wave ~60-100 issue cycles (> the 32-cycle shadow of
+// one MFMA) and the DMA path streams 64-71 GB/s per CU from L2 against ~100 GB/s for plain vector loads; with eight DMA
+// pieces per 64-byte slice p8 loses ~330 of every ~1 350 cycles to them.  Here every filler (16 ds_read_b128, 8
+// global_load_dwordx4, 8 ds_write_b128 per slice and wave) sits in the shadow of one of the slice's 32 MFMAs.
+// Pipeline: THREE LDS stages (96 KiB) + TWO register sets.  Iteration kt computes slice kt from stage kt%3, loads
+// slice kt+3 from global memory into G[(kt+1)&1], and writes slice kt+2 (loaded one iteration ago into G[kt&1]) to
+// stage (kt+2)%3, whose last reader was iteration kt-1.  hipcc counts vmcnt/lgkmcnt itself (no conditionals in the
+// steady state).  Needs an even number (>= 4) of 64-byte K slices.
+// ============================================================================================================
+constexpr int NSTAGE9 = 3;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: loads/stores stay SSA values (no memcpy)
+// compile-time loop: indices are constants in the AST, so the register arrays below are split by the FIRST SROA pass
+// (a `#pragma unroll` loop index is still dynamic there and leaves them to the size-limited alloca promotion -> scratch)
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+template <typename TO, int ACT, bool HAS_RES>
+__global__ __launch_bounds__(256) void gemm_kernel_p9(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __bf16 TI;
+    constexpr int BK = ROWB4 / (int)sizeof(TI);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+    const int m0 = tm * BM4, n0 = tn * BN4;
+
+    // staging: each operand tile = 16 pieces of 16 rows x 64 B (1 KiB per wave-instruction); wave w owns pieces
+    // {w, w+4, w+8, w+12}; the XOR swizzle is applied to the global chunk a lane fetches, the LDS image is lane-linear
+    unsigned offX[4], offWg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 4 + wave) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ swz4(row);
+        int gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        int gn = n0 + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        offX[i] = (unsigned)gm * (unsigned)p.lda * 2u + chunk * 16;
+        offWg[i] = (unsigned)gn * (unsigned)p.ldw * 2u + chunk * 16;
+    }
+    const int wr_off = wave * 1024 + lane * 16;          // + piece i * 4096 (+ BM4*ROWB4 for W) inside a stage
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, hi = lane >> 5;
+    int rdX[4], rdW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rx = wm * 128 + i * 32 + lr;
+        rdX[i] = rx * ROWB4 + ((hi ^ swz4(rx)) << 4);                     // sub-step 0; sub-step 1 = ^ 32
+        const int rw = wn * 128 + i * 32 + lr;
+        rdW[i] = BM4 * ROWB4 + rw * ROWB4 + ((hi ^ swz4(rw)) << 4);
+    }
+    f32x16 acc[2][4][2];                                                   // [n half][mi][ni within the half]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.0f;
+
+    const int nk = p.K / BK;
+    u32x4 G0[8], G1[8];                 // two register sets of 8 pieces (4 of X, 4 of W)
+    uint4 xfA[4], wfA[4], xfB[4], wfB[4];
+    auto gload_one = [&](int kt, auto J, u32x4 (&g)[8]) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < 4) g[j] = *reinterpret_cast<const u32x4*>(p.A + (size_t)kt * ROWB4 + offX[j]);
+        else g[j] = *reinterpret_cast<const u32x4*>(p.W + (size_t)kt * ROWB4 + offWg[j - 4]);
+    };
+    auto swrite_one = [&](int stage, auto J, const u32x4 (&g)[8]) {
+        constexpr int j = decltype(J)::value;
+        char* dst = smem + stage * STAGE4 + wr_off + (j < 4 ? j * 4096 : BM4 * ROWB4 + (j - 4) * 4096);
+        *reinterpret_cast<u32x4*>(dst) = g[j];
+    };
+    // read order = order of first use by the MFMA sequence (ni-major): x0 w0 x1 x2 x3 w1 w2 w3
+    auto load_one = [&](int stage, int s2, auto J, uint4 (&xf)[4], uint4 (&wf)[4]) {
+        constexpr int j = decltype(J)::value;
+        const char* base = smem + stage * STAGE4;
+        const int x2 = s2 << 5;
+        constexpr int isx[8] = {1, 0, 1, 1, 1, 0, 0, 0};
+        constexpr int idx[8] = {0, 0, 1, 2, 3, 1, 2, 3};
+        if constexpr (isx[j] != 0) xf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdX[idx[j]] ^ x2));
+        else wf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdW[idx[j]] ^ x2));
+    };
+    auto mfma_one = [&](auto J, uint4 (&xf)[4], uint4 (&wf)[4]) {
+        constexpr int j = decltype(J)::value;
+        constexpr int ni = j >> 2, mi = j & 3;
+        acc[ni >> 1][mi][ni & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]), acc[ni >> 1][mi][ni & 1], 0, 0, 0);
+    };
+    // stages: s0 = kt%3 (compute), s1 = (kt+1)%3 (next fragments), s2 = (kt+2)%3 (being written)
+    auto step = [&](int kt, int s0, int s1, int s2, auto PAR, auto LOAD, auto WRITE, auto NEXT) {
+        constexpr int par = decltype(PAR)::value;
+        __syncthreads();                                    // hipcc adds lgkmcnt(0): this wave's ds_writes of slice kt+1
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<16>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfA, wfA);
+            if constexpr (j < 8) load_one(s0, 1, J, xfB, wfB);
+            else if constexpr (decltype(LOAD)::value) {
+                if constexpr (par == 0) gload_one(kt + 3, std::integral_constant<int, j - 8>{}, G1);
+                else gload_one(kt + 3, std::integral_constant<int, j - 8>{}, G0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<16>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfB, wfB);
+            if constexpr (j < 8) {
+                if constexpr (decltype(NEXT)::value) load_one(s1, 0, J, xfA, wfA);
+            } else if constexpr (decltype(WRITE)::value) {
+                if constexpr (par == 0) swrite_one(s2, std::integral_constant<int, j - 8>{}, G0);
+                else swrite_one(s2, std::integral_constant<int, j - 8>{}, G1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    // prologue: slices 0 and 1 -> LDS stages 0 and 1, slice 2 -> G[0]
+    static_for<8>([&](auto J) { gload_one(0, J, G0); });
+    static_for<8>([&](auto J) { gload_one(1, J, G1); });
+    static_for<8>([&](auto J) { swrite_one(0, J, G0); });
+    static_for<8>([&](auto J) { gload_one(2, J, G0); });
+    static_for<8>([&](auto J) { swrite_one(1, J, G1); });
+    __syncthreads();
+    static_for<8>([&](auto J) { load_one(0, 0, J, xfA, wfA); });
+    int kt = 0, s0 = 0, s1 = 1, s2 = 2;
+    auto rot = [&]() { const int t = s0; s0 = s1; s1 = s2; s2 = t; };
+    for (; kt < nk - 4; kt += 2) {                           // nk even: steady steps 0 .. nk-4, in pairs + one
+        step(kt, s0, s1, s2, P0{}, T_{}, T_{}, T_{}); rot();
+        step(kt + 1, s0, s1, s2, P1{}, T_{}, T_{}, T_{}); rot();
+    }
+    step(kt, s0, s1, s2, P0{}, T_{}, T_{}, T_{}); rot();      // kt = nk-4: loads the last slice (nk-1)
+    step(kt + 1, s0, s1, s2, P1{}, F_{}, T_{}, T_{}); rot();  // nk-3: writes the last slice
+    step(kt + 2, s0, s1, s2, P0{}, F_{}, F_{}, T_{}); rot();  // nk-2
+    step(kt + 3, s0, s1, s2, P1{}, F_{}, F_{}, F_{});         // nk-1
+    __syncthreads();
+    if (p.dbg & 4) {
+        if (acc[0][0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][1][3] + acc[0][3][1][2] + acc[1][2][0][1];
+        return;
+    }
+    char* wbuf = smem + wave * EPI_WAVE_BYTES;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 128 + nh * 64;
+            const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
+            if (full) epilogue_lds<TO, ACT, HAS_RES, false, true>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+            else epilogue_lds<TO, ACT, HAS_RES, false, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+        }
+}
+
+template <typename TO, int ACT, bool HAS_RES>
+int launch_p9_inst(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p9<TO, ACT, HAS_RES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel_p9<TO, ACT, HAS_RES>), dim3(a.ntiles), dim3(256), LDS4, s, a);
+    return cfsar_check_launch("cfsar_gemm(p9)");
+}
+
+template <typename TO>
+int launch_p9(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_n = (a.N + BN4 - 1) / BN4;
+    a.ntiles = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
+    const bool r = a.res != nullptr;
+    const int nk = a.K / 32;
+    if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF || nk < 4 || (nk & 1)) return -2;
+    // 32-bit operand offsets
+    if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32)) return -2;
+    if (a.act == CFSAR_ACT_QUICKGELU) return r ? -2 : launch_p9_inst<TO, CFSAR_ACT_QUICKGELU, false>(a, s);
+    return r ? launch_p9_inst<TO, CFSAR_ACT_NONE, true>(a, s) : launch_p9_inst<TO, CFSAR_ACT_NONE, false>(a, s);
+}
+
+// ============================================================================================================
+// v8 ("p10"): p9 with WHOLE CACHE LINES per request.  Measured (tools/ubench/vgpr_l2.hip): the L2 -> CU path delivers
+// ~100 GB/s per CU for 8 rows x 128 B per wave-instruction but only ~61 GB/s for the 16 rows x 64 B pieces that 64-byte K
+// slices imply (the L2 serves requests, not bytes): every 64-byte-slice kernel above runs its operand stream at > 50 %
+// of that ceiling.  Here K advances in 128-byte tiles (64 bf16): TWO 64 KiB LDS stages of 128-byte rows
+// (chunk ^= (row >> 1) & 7), register staging with ONE 64-register set split into an X half and a W half:
+//     sub-step 0: MFMA(k 0-15)   | reads(k 16-31) | ds_write X(kt+1)
+//     sub-step 1: MFMA(k 16-31)  | reads(k 32-47) | global_load X(kt+2)
+//     sub-step 2: MFMA(k 32-47)  | reads(k 48-63) | ds_write W(kt+1)
+//     sub-step 3: MFMA(k 48-63)  | global_load W(kt+2) | barrier | reads(kt+1, k 0-15)
+// Each half lives 3 sub-steps (~1 500 cycles) in registers between its load and its LDS write; ONE barrier per 128-byte
+// K tile orders both hazards (RAW: stage kt+1 complete before its first fragment read; WAR: stage kt's last fragment
+// reads (sub-step 2) before X(kt+2) overwrites it in the next tile's sub-step 0).  Any K that is a multiple of 64.
+// ============================================================================================================
+constexpr int ROWB10 = 128;
+constexpr int STAGE10 = (BM4 + BN4) * ROWB10;       // 64 KiB
+template <typename TO, int ACT, bool HAS_RES>
+__global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+    const int m0 = tm * BM4, n0 = tn * BN4;
+
+    // staging: an operand tile = 32 pieces of 8 rows x 128 B (1 KiB per wave-instruction); wave w owns pieces
+    // {w, w+4, ..., w+28}; a lane fetches global chunk (lane&7) ^ swz(row) and writes LDS lane-linearly
+    unsigned offX[8], offWg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);
+        int gm = ((p.dbg & 8) ? 0 : m0) + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        int gn = ((p.dbg & 8) ? 0 : n0) + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        offX[i] = (unsigned)gm * (unsigned)p.lda * 2u + chunk * 16;
+        offWg[i] = (unsigned)gn * (unsigned)p.ldw * 2u + chunk * 16;
+    }
+    const int wr_off = wave * 1024 + lane * 16;          // + piece i * 4096 (+ BM4*ROWB10 for W) inside a stage
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, hi = lane >> 5;
+    int rdX[4], rdW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rx = wm * 128 + i * 32 + lr;
+        rdX[i] = rx * ROWB10 + ((hi ^ swz(rx)) << 4);                      // sub-step ss: ^ (ss << 5)
+        const int rw = wn * 128 + i * 32 + lr;
+        rdW[i] = BM4 * ROWB10 + rw * ROWB10 + ((hi ^ swz(rw)) << 4);
+    }
+    f32x16 acc[2][4][2];                                                   // [n half][mi][ni within the half]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.0f;
+
+    const int nk = p.K / 64;
+    u32x4 GX[8], GW[8];
+    uint4 xfA[4], wfA[4], xfB[4], wfB[4];
+    auto gloadX = [&](int kt, auto J) {
+        GX[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.A + (size_t)kt * ROWB10 + offX[decltype(J)::value]);
+    };
+    auto gloadW = [&](int kt, auto J) {
+        GW[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.W + (size_t)kt * ROWB10 + offWg[decltype(J)::value]);
+    };
+    auto swriteX = [&](int stage, auto J) {
+        *reinterpret_cast<u32x4*>(smem + stage * STAGE10 + wr_off + decltype(J)::value * 4096) = GX[decltype(J)::value];
+    };
+    auto swriteW = [&](int stage, auto J) {
+        *reinterpret_cast<u32x4*>(smem + stage * STAGE10 + BM4 * ROWB10 + wr_off + decltype(J)::value * 4096) = GW[decltype(J)::value];
+    };
+    // read order = order of first use by the MFMA sequence (ni-major): x0 w0 x1 x2 x3 w1 w2 w3
+    auto load_one = [&](int stage, int ss, auto J, uint4 (&xf)[4], uint4 (&wf)[4]) {
+        constexpr int j = decltype(J)::value;
+        const char* base = smem + stage * STAGE10;
+        const int x2 = ss << 5;
+        constexpr int isx[8] = {1, 0, 1, 1, 1, 0, 0, 0};
+        constexpr int idx[8] = {0, 0, 1, 2, 3, 1, 2, 3};
+        if constexpr (isx[j] != 0) xf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdX[idx[j]] ^ x2));
+        else wf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdW[idx[j]] ^ x2));
+    };
+    auto mfma_one = [&](auto J, uint4 (&xf)[4], uint4 (&wf)[4]) {
+        constexpr int j = decltype(J)::value;
+        constexpr int ni = j >> 2, mi = j & 3;
+        acc[ni >> 1][mi][ni & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]), acc[ni >> 1][mi][ni & 1], 0, 0, 0);
+    };
+    // one 128-byte K tile; cur / nxt = LDS stage of tile kt / kt+1.  WRITE: tile kt+1 exists (its registers are written
+    // to LDS and its first fragments are prefetched); LOAD: tile kt+2 exists
+    auto tile = [&](int kt, int cur, int nxt, auto LOAD, auto WRITE) {
+        constexpr bool load = decltype(LOAD)::value, write = decltype(WRITE)::value;
+        static_for<16>([&](auto J) {                                    // sub-step 0
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfA, wfA);
+            if constexpr (j < 8) load_one(cur, 1, J, xfB, wfB);
+            else if constexpr (write) swriteX(nxt, std::integral_constant<int, j - 8>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<16>([&](auto J) {                                    // sub-step 1
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfB, wfB);
+            if constexpr (j < 8) load_one(cur, 2, J, xfA, wfA);
+            else if constexpr (load) gloadX(kt + 2, std::integral_constant<int, j - 8>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<16>([&](auto J) {                                    // sub-step 2
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfA, wfA);
+            if constexpr (j < 8) load_one(cur, 3, J, xfB, wfB);
+            else if constexpr (write) swriteW(nxt, std::integral_constant<int, j - 8>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<16>([&](auto J) {                                    // sub-step 3
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfB, wfB);
+            if constexpr (j < 8) {
+                if constexpr (load) gloadW(kt + 2, J);
+            } else if constexpr (write) load_one(nxt, 0, std::integral_constant<int, j - 8>{}, xfA, wfA);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j == 7 && write) {
+                if (!(p.dbg & 2)) __syncthreads();                      // hipcc adds lgkmcnt(0): this wave's ds_writes
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    // prologue: tile 0 -> stage 0 through the registers, tile 1 -> registers
+    static_for<8>([&](auto J) { gloadX(0, J); });
+    static_for<8>([&](auto J) { gloadW(0, J); });
+    static_for<8>([&](auto J) { swriteX(0, J); });
+    static_for<8>([&](auto J) { swriteW(0, J); });
+    if (nk > 1) {
+        static_for<8>([&](auto J) { gloadX(1, J); });
+        static_for<8>([&](auto J) { gloadW(1, J); });
+    }
+    __syncthreads();
+    static_for<8>([&](auto J) { load_one(0, 0, J, xfA, wfA); });
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) tile(kt, kt & 1, (kt + 1) & 1, T_{}, T_{});
+    if (nk > 1) {
+        tile(kt, kt & 1, (kt + 1) & 1, F_{}, T_{});
+        ++kt;
+    }
+    tile(kt, kt & 1, (kt + 1) & 1, F_{}, F_{});
+    __syncthreads();
+    if (p.dbg & 4) {
+        if (acc[0][0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][1][3] + acc[0][3][1][2] + acc[1][2][0][1];
+        return;
+    }
+    char* wbuf = smem + wave * EPI_WAVE_BYTES;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 128 + nh * 64;
+            const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
+            if constexpr (sizeof(TO) == 2 && !HAS_RES) {
+                if ((p.dbg & 64) && !p.relu) {                          // A/B: packed bf16 staging + 16-byte stores
+                    if (full) epilogue_lds_bf16<ACT, true>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+                    else epilogue_lds_bf16<ACT, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+                    continue;
+                }
+            }
+            if (full) epilogue_lds<TO, ACT, HAS_RES, false, true>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+            else epilogue_lds<TO, ACT, HAS_RES, false, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+        }
+}
+
+template <typename TO, int ACT, bool HAS_RES>
+int launch_p10_inst(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p10<TO, ACT, HAS_RES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel_p10<TO, ACT, HAS_RES>), dim3(a.ntiles), dim3(256), LDS4, s, a);
+    return cfsar_check_launch("cfsar_gemm(p10)");
+}
+
+template <typename TO>
+int launch_p10(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_n = (a.N + BN4 - 1) / BN4;
+    a.ntiles = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
+    const bool r = a.res != nullptr;
+    if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF || a.K % 64 != 0) return -2;
+    if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32)) return -2;   // 32-bit offsets
+    if (a.act == CFSAR_ACT_QUICKGELU) return r ? -2 : launch_p10_inst<TO, CFSAR_ACT_QUICKGELU, false>(a, s);
+    return r ? launch_p10_inst<TO, CFSAR_ACT_NONE, true>(a, s) : launch_p10_inst<TO, CFSAR_ACT_NONE, false>(a, s);
+}
+
 // dev tool (not in the public header): device buffer of 8 x u64 per 256x256 tile for the p6 phase timestamps; NULL = off
 extern "C" void cfsar_debug_set_gemm_trace(void* buf) { g_trace = static_cast<unsigned long long*>(buf); }
+// dev tool (not in the public header): override CFSAR_GEMM_VARIANT / CFSAR_GEMM_DEBUG at run time; -1 = use the environment
+extern "C" void cfsar_debug_set_gemm_variant(int variant, int dbg) { g_variant_override = variant; g_dbg_override = dbg; }
 
 extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const float* bias, const void* residual, int M,
                              int N, int K, int lda, int ldw, int ldo, int ldr, int in_dtype, int out_dtype, int act,
@@ -1236,17 +1815,33 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     a.res_mod = res_mod; a.res_off = res_off;
     a.tiles_n = (N + BN - 1) / BN;
     static const int dbg = [] { const char* e = getenv("CFSAR_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
-    a.dbg = dbg;
+    a.dbg = g_dbg_override >= 0 ? g_dbg_override : dbg;
     static const int stag = [] { const char* e = getenv("CFSAR_GEMM_STAGGER"); return e ? atoi(e) : -1; }();
     a.stagger = stag;
     a.trace = g_trace;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // variant: 0 = auto, 1 = v1 (128x128, 2-stage, compiler-managed LDS-DMA), 2 = p3 (256x128, 3-stage, asm LDS-DMA)
-    static const int forced = [] { const char* e = getenv("CFSAR_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+    static const int forced_env = [] { const char* e = getenv("CFSAR_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+    const int forced = g_variant_override >= 0 ? g_variant_override : forced_env;
     // p4 needs enough 256x256 tiles to fill the 256 CUs for >= 2 rounds
     const long tiles4 = (long)((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
     // variants: 1 = v1 (128x128), 2 = p3 (256x128, 3-stage), 3 = p4 (256x256, 4-stage), 4 = p5 (256x128, 2 WG/CU),
     // 6 = p6 (256x256 ping-pong).  auto: p6 when >= 2 rounds of 256x256 tiles exist, else p3 / v1.
+    // 10 = p10 (one wave per SIMD, register-staged whole-line operand requests).  auto: p10 for the epilogues without an
+    // activation (QKV, out_proj, c_proj, RN50 convs: +2...+6 % over p6 at M = 126080, tools/gemm_ab.py); the QuickGELU
+    // epilogue (c_fc) keeps p6, whose second wave per SIMD hides part of the 2-transcendentals-per-element VALU time.
+    if (in_dtype == CFSAR_BF16 && (forced == 10 || (forced == 0 && tiles4 >= 512 && act == CFSAR_ACT_NONE))) {
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p10<__bf16>(a, s) : launch_p10<float>(a, s);
+        if (rc != -2) return rc;
+    }
+    if (in_dtype == CFSAR_BF16 && forced == 9) {               // 9 = p9 (p8 geometry, register-staged operands)
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p9<__bf16>(a, s) : launch_p9<float>(a, s);
+        if (rc != -2) return rc;
+    }
+    if (in_dtype == CFSAR_BF16 && forced == 8) {               // 8 = p8 (one wave per SIMD, 128x128 wave tiles)
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p8<__bf16>(a, s) : launch_p8<float>(a, s);
+        if (rc != -2) return rc;
+    }
     if (in_dtype == CFSAR_BF16 && forced == 7) {               // 7 = p6 persistent
         const int rc = out_dtype == CFSAR_BF16 ? launch_p6<__bf16, true>(a, s) : launch_p6<float, true>(a, s);
         if (rc != -2) return rc;
@@ -1264,7 +1859,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
         const int rc = out_dtype == CFSAR_BF16 ? launch_p5<__bf16>(a, s) : launch_p5<float>(a, s);
         if (rc != -2) return rc;
     }
-    const bool use_p3 = forced == 2 || forced == 3 || forced == 4 || forced == 6 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
+    const bool use_p3 = forced == 2 || forced == 3 || forced == 4 || forced == 6 || forced == 8 || forced == 9 || forced == 10 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
     if (use_p3) {
         int rc;
         if (in_dtype == CFSAR_BF16)

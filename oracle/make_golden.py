@@ -254,14 +254,33 @@ def run_preprocess_cases():
     np.savez_compressed(os.path.join(GOLD, "preprocess_cases.npz"), meta=json.dumps(dict(seed=SEED, cases=PREPROC_CASES)), **out)
 
 
+def run_state_dict_keys():
+    """Parameter/buffer names and shapes of the reference head for the two shipped backbones (the checkpoint surface,
+    utils/checkpoint.py:329): tests/golden/state_dict_keys_{B16,RN50}.json."""
+    for arch, tag in (("ViT-B/16", "B16"), ("RN50", "RN50")):
+        a = synth.ARCHS[arch]
+        sd = synth.head_state_dict(arch, seed=SEED, depth=1)
+        cfg = rh.make_cfg(arch, way=5, shot=1, frames=8, n_train=N_TRAIN, n_test=N_TEST)
+        head = rh.build_reference_head(cfg, a, sd, synth.text_features(N_TRAIN, a["embed"], "train", SEED),
+                                       synth.text_features(N_TEST, a["embed"], "test", SEED))
+        keys = {k: list(v.shape) for k, v in head.state_dict().items()}
+        with open(os.path.join(GOLD, "state_dict_keys_%s.json" % tag), "w") as f:
+            json.dump(keys, f, indent=0, sort_keys=True)
+        print("state_dict_keys_%s.json: %d entries" % (tag, len(keys)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--keys-only", action="store_true")
     ap.add_argument("--only", nargs="*", default=None)
     ap.add_argument("--skip-large", action="store_true")
     ap.add_argument("--text-only", action="store_true")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
+    if args.keys_only:
+        run_state_dict_keys()
+        return
     if args.text_only:
         run_text_cases()
         run_text_mode_cases()
@@ -271,6 +290,7 @@ def main():
         run_known_answers()
         run_vit_taps()
         run_text_cases()
+        run_state_dict_keys()
     for name, p in HEAD_CASES.items():
         if args.only and name not in args.only:
             continue

@@ -229,3 +229,118 @@ def test_otam_known_answers(hip):
     dconst = 1.0 - 1.0 / 1.01
     ref = orc.otam_cum_dist(torch.full((1, 1, T, T), dconst))
     assert abs(float(logits.cpu()) + float(ref)) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- N3: RN50 tower ops
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gemm_ex_relu_and_bf16_residual(hip, dtype):
+    """cfsar_gemm_ex: relu applied LAST, residual in the activation dtype (Bottleneck: relu(bn3(conv3) + identity),
+    few_shot.py:213-226)."""
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    for (M, N, K) in [(196 * 3, 256, 64), (49 * 5, 2048, 512), (1000, 64, 576)]:
+        A = _rand(M, K, seed=1).to(td)
+        W = _rand(N, K, seed=2, scale=K ** -0.5).to(td)
+        bias = _rand(N, seed=3)
+        res = _rand(M, N, seed=4).to(td)
+        ref = torch.relu(A.float() @ W.float().t() + bias + res.float())
+        out = torch.empty(M, N, device="cuda", dtype=td)
+        hip.gemm(A.cuda(), W.cuda(), out, bias=bias.cuda(), residual=res.cuda(), relu=True)
+        tol = 2e-4 if dtype == "f32" else 2e-2
+        assert maxdiff(out.float().cpu(), ref) < tol * max(1.0, float(ref.abs().max()))
+        assert float(out.float().min()) >= 0.0
+        out2 = torch.empty(M, N, device="cuda", dtype=td)
+        hip.gemm(A.cuda(), W.cuda(), out2, bias=bias.cuda(), relu=True)
+        ref2 = torch.relu(A.float() @ W.float().t() + bias)
+        assert maxdiff(out2.float().cpu(), ref2) < tol * max(1.0, float(ref2.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("stride,C,H", [(1, 64, 14), (2, 3, 32), (1, 32, 9), (2, 8, 7)])
+def test_conv3x3_as_im2col_gemm(hip, dtype, stride, C, H):
+    """nchw_to_nhwc + im2col3x3_nhwc + GEMM with tap-major weights == nn.Conv2d(3, padding=1, stride) (bit-exact
+    gather: the only arithmetic is in the GEMM)."""
+    import torch.nn.functional as F
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    Fn, W_, Co = 3, H + 2, 32
+    x = _rand(Fn, C, H, W_, seed=5)
+    w = _rand(Co, C, 3, 3, seed=6, scale=(9 * C) ** -0.5)
+    xd = torch.empty(Fn, H, W_, C, device="cuda", dtype=td)
+    hip.nchw_to_nhwc(x.cuda(), xd)
+    assert torch.equal(xd.float().cpu(), x.to(td).float().permute(0, 2, 3, 1))
+    Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
+    kq = 64 if dtype == "bf16" else 32
+    kpad = -(-9 * C // kq) * kq
+    cols = torch.full((Fn * Ho * Wo, kpad), float("nan"), device="cuda", dtype=td)
+    hip.im2col3x3(xd, cols, Fn, H, W_, C, stride)
+    # gather reference (exact)
+    xp = F.pad(x.to(td).float().permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))
+    ref_cols = torch.zeros(Fn, Ho, Wo, kpad)
+    for ky in range(3):
+        for kx in range(3):
+            ref_cols[..., (ky * 3 + kx) * C:(ky * 3 + kx + 1) * C] = \
+                xp[:, ky:ky + (Ho - 1) * stride + 1:stride, kx:kx + (Wo - 1) * stride + 1:stride, :]
+    assert torch.equal(cols.float().cpu().reshape(Fn, Ho, Wo, kpad), ref_cols)
+    wt = torch.zeros(Co, kpad)
+    wt[:, :9 * C] = w.permute(0, 2, 3, 1).reshape(Co, 9 * C)
+    out = torch.empty(Fn * Ho * Wo, Co, device="cuda", dtype=torch.float32)
+    hip.gemm(cols, wt.to(td).cuda(), out)
+    ref = F.conv2d(x.to(td).float(), w.to(td).float(), stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    assert maxdiff(out.cpu(), ref) < (2e-4 if dtype == "f32" else 2e-2) * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_avgpool_and_attnpool_tokens(hip, dtype):
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    Fn, H, W_, C = 3, 14, 14, 64
+    x = _rand(Fn, H, W_, C, seed=7).to(td)
+    out = torch.empty(Fn, H // 2, W_ // 2, C, device="cuda", dtype=td)
+    hip.avgpool2x2(x.cuda(), out, Fn, H, W_, C)
+    ref = x.float().reshape(Fn, H // 2, 2, W_ // 2, 2, C).mean((2, 4))
+    assert maxdiff(out.float().cpu(), ref) < (1e-6 if dtype == "f32" else 1e-2)
+    # odd sizes floor like nn.AvgPool2d(2)
+    xo = _rand(2, 7, 9, 8, seed=8).to(td)
+    oo = torch.empty(2, 3, 4, 8, device="cuda", dtype=td)
+    hip.avgpool2x2(xo.cuda(), oo, 2, 7, 9, 8)
+    assert maxdiff(oo.float().cpu(), xo.float()[:, :6, :8].reshape(2, 3, 2, 4, 2, 8).mean((2, 4))) < (1e-6 if dtype == "f32" else 1e-2)
+    # AttentionPool2d tokens (few_shot.py:446-448): [mean ; x] + pos
+    HW = 49
+    t = _rand(Fn, HW, C, seed=9).to(td)
+    pos = _rand(HW + 1, C, seed=10)
+    tok = torch.empty(Fn, HW + 1, C, device="cuda", dtype=td)
+    hip.attnpool_tokens(t.cuda(), pos.cuda(), tok, Fn, HW, C)
+    ref_tok = torch.cat([t.float().mean(1, keepdim=True), t.float()], 1) + pos
+    assert maxdiff(tok.float().cpu(), ref_tok) < (2e-6 if dtype == "f32" else 3e-2)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10])
+def test_gemm_every_kernel_variant(hip, variant):
+    """Each bf16 GEMM kernel kept in gemm.hip (v1 / p3 / p4 / p5 / p6 / p6-persistent / p8 / p9 / p10; the auto policy only
+    picks p10, p6, p3 and v1) against the fp32 product of the bf16-rounded operands, on ragged M and N edges, through the
+    fused epilogues the ViT and RN50 towers use.  Variants are forced with the dev hook cfsar_debug_set_gemm_variant."""
+    import ctypes
+    L = hip.lib()
+    L.cfsar_debug_set_gemm_variant.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.cfsar_debug_set_gemm_variant.restype = None
+    try:
+        L.cfsar_debug_set_gemm_variant(variant, 0)
+        for (M, N, K) in [(777, 516, 768), (1300, 768, 3072), (515, 260, 192)]:
+            A = _rand(M, K, seed=11).to(torch.bfloat16)
+            W = _rand(N, K, seed=12, scale=K ** -0.5).to(torch.bfloat16)
+            bias = _rand(N, seed=13)
+            ref0 = A.float() @ W.float().t() + bias
+            Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+            scale = max(1.0, float(ref0.abs().max()))
+            out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            hip.gemm(Ad, Wd, out, bias=bd)                                                   # QKV-like
+            assert maxdiff(out.float().cpu(), ref0) < 2e-2 * scale, ("plain", variant, M, N, K)
+            hip.gemm(Ad, Wd, out, bias=bd, act=hip.ACT_QUICKGELU)                            # c_fc-like
+            assert maxdiff(out.float().cpu(), orc.quick_gelu(ref0)) < 4e-2 * scale, ("gelu", variant, M, N, K)
+            x = _rand(M, N, seed=14).cuda()
+            xr = x.clone()
+            hip.gemm(Ad, Wd, x, bias=bd, residual=x)                                         # residual stream, in place
+            assert maxdiff(x.cpu(), ref0 + xr.cpu()) < 2e-2 * scale, ("residual", variant, M, N, K)
+            rb = _rand(M, N, seed=15).to(torch.bfloat16)
+            hip.gemm(Ad, Wd, out, bias=bd, residual=rb.cuda(), relu=True)                    # RN50 bottleneck tail
+            assert maxdiff(out.float().cpu(), torch.relu(ref0 + rb.float())) < 2e-2 * scale, ("relu", variant, M, N, K)
+    finally:
+        L.cfsar_debug_set_gemm_variant(-1, -1)

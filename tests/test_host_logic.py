@@ -71,6 +71,11 @@ def test_state_dict_names_and_shapes_match_reference():
     assert len(ours) == 164
     # text tables are plain attributes, not in the state dict (few_shot.py:2714-2728)
     assert head.text_features_train.shape == (64, 512) and head.text_features_test.shape == (24, 512)
+    # RN50 (every shipped config's backbone): conv/BN parameters AND BatchNorm buffers under the reference's names
+    ref_rn = json.load(open(os.path.join(GOLD, "state_dict_keys_RN50.json")))
+    head_rn = HEAD_REGISTRY.get("CNN_OTAM_CLIPFSAR")(_cfg(arch="RN50"))
+    assert {k: list(v.shape) for k, v in head_rn.state_dict().items()} == ref_rn
+    assert len(ref_rn) == 351 and head_rn.text_features_test.shape == (24, 1024)
     # depth flag (absent-by-default hasattr semantics)
     head2 = HEAD_REGISTRY.get("CNN_OTAM_CLIPFSAR")(_cfg(TRANSFORMER_DEPTH=2))
     assert any(k.startswith("context2.layers.1.") for k in head2.state_dict())
