@@ -47,6 +47,7 @@ struct GemmArgs {
     int stagger;   // p4: first-round phase offset in units of s_sleep(127) (~4 us)
     unsigned long long* trace;   // dev tool: per-tile phase timestamps (s_memtime), 8 slots per tile; normally NULL
     int dbg;   // ablation bits (env CFSAR_GEMM_DEBUG): 1 = no in-loop DMA, 2 = no in-loop barrier, 4 = no epilogue
+    int conv_H, conv_W, conv_lgC;   // implicit 3x3 / pad 1 / stride 1 conv (p10 CONV): A = NHWC input [F,H,W,C], C = 1 << conv_lgC
 };
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
@@ -158,9 +159,101 @@ __device__ __forceinline__ void mma_slice(f32x16 (&acc)[2][2], const char* sX, c
 // 64-column row segment (128 B bf16 / 256 B f32 stores, 256 B residual loads) instead of 32 rows x 16 B per instruction.
 constexpr int EPI_RS = 272;                     // staged row: 64 fp32 + 16 B pad (conflict-free b128 writes)
 constexpr int EPI_WAVE_BYTES = 64 * EPI_RS;     // 17408 B per wave
-template <typename TO, int ACT, bool HAS_RES, bool REMAP, bool FULL, int NMI = 2>
+// bf16 output, 16 bytes per lane: after the same fp32 LDS transpose a lane owns EIGHT consecutive columns of a row, so the
+// residual load (bf16: one dwordx4) and the store (one dwordx4) move whole 128-byte row segments per 8 lanes, 8 rows per
+// wave-instruction -- half the VMEM instructions of the 4-column form.  The RN50 bottleneck tails (K = 64...512, bf16
+// residual + ReLU) are bound by exactly those instructions.
+template <int ACT, bool HAS_RES, bool FULL, int NMI>
+__device__ __forceinline__ void epilogue_lds_x8(f32x16 (*acc)[2], const GemmArgs& p, int mbase, int nbase, int lane,
+                                                char* wbuf) {
+    const int lr = lane & 31, hi = lane >> 5;
+    const int rsub = lane >> 3, cc = lane & 7;
+    const int M = p.M, N = p.N, ldo = p.ldo, ldr = p.ldr, row_off = p.row_off;
+    const int n = nbase + cc * 8;
+    const int nc = n + 8 <= N ? n : N - 8;                   // clamped column for loads; stores are predicated
+    const int nvalid = FULL ? 8 : (n + 8 <= N ? 8 : (n + 4 <= N ? 4 : 0));
+    const void* resp = p.res;
+    const int res_bf16 = p.res_bf16, relu = p.relu;
+    __bf16* outp = reinterpret_cast<__bf16*>(p.out);
+    constexpr int NIT = 4 * NMI;
+    uint4 rb[HAS_RES ? NIT : 1];                              // bf16 residual: 8 values; fp32 residual: loaded in the row loop
+    size_t ooff[NIT], roff[HAS_RES ? NIT : 1];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int m = mbase + it * 8 + rsub;
+        const int mc = m < M ? m : M - 1;
+        ooff[it] = (size_t)(mc + row_off) * ldo + nc;
+        if constexpr (HAS_RES) {
+            roff[it] = (size_t)(mc + row_off) * ldr + nc;
+            if (res_bf16) rb[it] = *reinterpret_cast<const uint4*>(static_cast<const __bf16*>(resp) + roff[it]);
+        }
+    }
+    float4 bv0 = make_float4(0.f, 0.f, 0.f, 0.f), bv1 = bv0;
+    if (p.bias) {
+        bv0 = *reinterpret_cast<const float4*>(p.bias + nc);
+        bv1 = *reinterpret_cast<const float4*>(p.bias + nc + 4);
+    }
+#pragma unroll
+    for (int mi = 0; mi < NMI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(wbuf + (mi * 32 + lr) * EPI_RS + (ni * 32 + 8 * g + 4 * hi) * 4) =
+                    make_float4(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = it * 8 + rsub;
+        // the staged row holds the tile's columns [nbase, nbase+64); a clamped (ragged) lane re-reads valid columns
+        const int cl = nc - nbase;
+        const float4 a0 = *reinterpret_cast<const float4*>(wbuf + row * EPI_RS + cl * 4);
+        const float4 a1 = *reinterpret_cast<const float4*>(wbuf + row * EPI_RS + cl * 4 + 16);
+        float v[8] = {a0.x + bv0.x, a0.y + bv0.y, a0.z + bv0.z, a0.w + bv0.w, a1.x + bv1.x, a1.y + bv1.y, a1.z + bv1.z, a1.w + bv1.w};
+        if constexpr (ACT != CFSAR_ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], ACT);
+        }
+        if constexpr (HAS_RES) {
+            if (res_bf16) {
+                const bf16x8 r8 = __builtin_bit_cast(bf16x8, rb[it]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
+            } else {
+                const float4 r0 = *reinterpret_cast<const float4*>(static_cast<const float*>(resp) + roff[it]);
+                const float4 r1 = *reinterpret_cast<const float4*>(static_cast<const float*>(resp) + roff[it] + 4);
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            }
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.0f);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
+        if (FULL || (nvalid == 8 && mbase + row < M)) {
+            *reinterpret_cast<bf16x8*>(outp + ooff[it]) = o;
+        } else if (nvalid == 4 && mbase + row < M) {          // ragged right edge (N % 8 == 4): the clamped lane owns columns
+            bf16x4 o4;                                        // [N-8, N); its last four are the tile's last four
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o4[j] = o[4 + j];
+            *reinterpret_cast<bf16x4*>(outp + ooff[it] + 4) = o4;
+        }
+    }
+}
+
+// X8 = false: the one-wave-per-SIMD kernels (p8-p10) hold 256 accumulator registers through the epilogue and spill with
+// the wider form
+template <typename TO, int ACT, bool HAS_RES, bool REMAP, bool FULL, int NMI = 2, bool X8 = true>
 __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p, int mbase, int nbase, int lane,
                                              char* wbuf) {
+    if constexpr (sizeof(TO) == 2 && !REMAP && X8) {
+        if (!(p.dbg & 128) && (p.ldo & 7) == 0 && (!HAS_RES || (p.ldr & 7) == 0) && p.N >= 8) {
+            epilogue_lds_x8<ACT, HAS_RES, FULL, NMI>(acc, p, mbase, nbase, lane, wbuf);
+            return;
+        }
+    }
     const int lr = lane & 31, hi = lane >> 5;
     const int rsub = lane >> 4, cc = lane & 15;
     const int M = p.M, N = p.N, ldo = p.ldo, ldr = p.ldr, row_off = p.row_off;
@@ -1350,8 +1443,8 @@ __global__ __launch_bounds__(256) void gemm_kernel_p8(GemmArgs p) {
         for (int half = 0; half < 2; ++half) {
             const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 128 + nh * 64;
             const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
-            if (full) epilogue_lds<TO, ACT, HAS_RES, false, true>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
-            else epilogue_lds<TO, ACT, HAS_RES, false, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+            if (full) epilogue_lds<TO, ACT, HAS_RES, false, true, 2, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+            else epilogue_lds<TO, ACT, HAS_RES, false, false, 2, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
         }
 }
 
@@ -1543,8 +1636,8 @@ __global__ __launch_bounds__(256) void gemm_kernel_p9(GemmArgs p) {
         for (int half = 0; half < 2; ++half) {
             const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 128 + nh * 64;
             const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
-            if (full) epilogue_lds<TO, ACT, HAS_RES, false, true>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
-            else epilogue_lds<TO, ACT, HAS_RES, false, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+            if (full) epilogue_lds<TO, ACT, HAS_RES, false, true, 2, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+            else epilogue_lds<TO, ACT, HAS_RES, false, false, 2, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
         }
 }
 
@@ -1591,14 +1684,20 @@ int launch_p9(const GemmArgs& a0, hipStream_t s) {
 // ============================================================================================================
 constexpr int ROWB10 = 128;
 constexpr int STAGE10 = (BM4 + BN4) * ROWB10;       // 64 KiB
-template <typename TO, int ACT, bool HAS_RES>
+// CONV: the X operand is gathered on the fly from an NHWC activation tensor (implicit GEMM for nn.Conv2d(3, padding=1),
+// few_shot.py:196): row m = output pixel (f, y, x), K index kk = tap * C + c with tap = ky * 3 + kx; a lane's 16-byte chunk
+// (8 channels) of K tile kt comes from pixel (y + ky - 1, x + kx - 1) or is zero outside the image -- no im2col matrix.
+template <typename TO, int ACT, bool HAS_RES, bool PERSIST, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    // PERSIST: one workgroup per CU walks the virtual block ids b, b + grid, ... (same XCD every time: grid % 8 == 0)
+    const int nwg = PERSIST ? p.ntiles : (int)gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    for (int b = blockIdx.x; b < nwg; b += PERSIST ? (int)gridDim.x : nwg) {
+    const int xcd = b & 7;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
     const int m0 = tm * BM4, n0 = tn * BN4;
@@ -1606,6 +1705,10 @@ __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
     // staging: an operand tile = 32 pieces of 8 rows x 128 B (1 KiB per wave-instruction); wave w owns pieces
     // {w, w+4, ..., w+28}; a lane fetches global chunk (lane&7) ^ swz(row) and writes LDS lane-linearly
     unsigned offX[8], offWg[8];
+    unsigned cmask[CONV ? 4 : 1] = {};     // CONV: two 16-bit masks per register; bit t = tap t reads inside the image
+    // CONV: first K element (0, 8, ..., 56) of this lane's chunk inside a K tile -- swz(row) = (wave*4 + lane/16) & 7 is
+    // the same for all 8 pieces of a lane, so tap and channel offset of a K tile are per lane, not per piece
+    const int cchunk = ((lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7)) * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = (i * 4 + wave) * 8 + (lane >> 3);
@@ -1614,7 +1717,19 @@ __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
         gm = gm < p.M ? gm : p.M - 1;
         int gn = ((p.dbg & 8) ? 0 : n0) + row;
         gn = gn < p.N ? gn : p.N - 1;
-        offX[i] = (unsigned)gm * (unsigned)p.lda * 2u + chunk * 16;
+        if constexpr (CONV) {
+            const int x = gm % p.conv_W, y = (gm / p.conv_W) % p.conv_H;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (yy >= 0 && yy < p.conv_H && xx >= 0 && xx < p.conv_W) mk |= 1u << t;
+            }
+            cmask[i >> 1] |= mk << ((i & 1) * 16);
+            offX[i] = ((unsigned)gm << p.conv_lgC) * 2u;                   // centre pixel, channel 0
+        } else {
+            offX[i] = (unsigned)gm * (unsigned)p.lda * 2u + chunk * 16;
+        }
         offWg[i] = (unsigned)gn * (unsigned)p.ldw * 2u + chunk * 16;
     }
     const int wr_off = wave * 1024 + lane * 16;          // + piece i * 4096 (+ BM4*ROWB10 for W) inside a stage
@@ -1643,7 +1758,20 @@ __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
     u32x4 GX[8], GW[8];
     uint4 xfA[4], wfA[4], xfB[4], wfB[4];
     auto gloadX = [&](int kt, auto J) {
-        GX[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.A + (size_t)kt * ROWB10 + offX[decltype(J)::value]);
+        constexpr int j = decltype(J)::value;
+        if constexpr (CONV) {
+            const int kk = kt * 64 + cchunk;                                             // (hipcc hoists this block per K tile)
+            const int tap = kk >> p.conv_lgC, cc = kk & ((1 << p.conv_lgC) - 1);
+            const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;                           // tap / 3, tap % 3 for tap < 16
+            const int delta = ((((dy - 1) * p.conv_W + (dx - 1)) << p.conv_lgC) + cc) * 2;
+            const bool ok = (cmask[j >> 1] >> ((j & 1) * 16 + tap)) & 1u;
+            const unsigned off = ok ? offX[j] + (unsigned)delta : 0u;
+            u32x4 v = *reinterpret_cast<const u32x4*>(p.A + off);
+            const unsigned keep = ok ? 0xffffffffu : 0u;
+            GX[j] = v & keep;
+        } else {
+            GX[j] = *reinterpret_cast<const u32x4*>(p.A + (size_t)kt * ROWB10 + offX[j]);
+        }
     };
     auto gloadW = [&](int kt, auto J) {
         GW[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.W + (size_t)kt * ROWB10 + offWg[decltype(J)::value]);
@@ -1731,7 +1859,8 @@ __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
     __syncthreads();
     if (p.dbg & 4) {
         if (acc[0][0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][1][3] + acc[0][3][1][2] + acc[1][2][0][1];
-        return;
+        if constexpr (PERSIST) continue;
+        else return;
     }
     char* wbuf = smem + wave * EPI_WAVE_BYTES;
 #pragma unroll
@@ -1747,25 +1876,38 @@ __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
                     continue;
                 }
             }
-            if (full) epilogue_lds<TO, ACT, HAS_RES, false, true>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
-            else epilogue_lds<TO, ACT, HAS_RES, false, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+            if constexpr (ACT != CFSAR_ACT_NONE) {                     // activation temporaries: 32 rows per pass (no spills)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int mq = mb + q2 * 32;
+                    if (mq + 32 <= p.M && nb + 64 <= p.N)
+                        epilogue_lds<TO, ACT, HAS_RES, false, true, 1, false>(&acc[nh][2 * half + q2], p, mq, nb, lane, wbuf);
+                    else
+                        epilogue_lds<TO, ACT, HAS_RES, false, false, 1, false>(&acc[nh][2 * half + q2], p, mq, nb, lane, wbuf);
+                }
+                continue;
+            }
+            if (full) epilogue_lds<TO, ACT, HAS_RES, false, true, 2, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
+            else epilogue_lds<TO, ACT, HAS_RES, false, false, 2, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
         }
+    if constexpr (PERSIST) __syncthreads();            // the epilogue staging aliases LDS stage 0 of the next tile
+    }
 }
 
-template <typename TO, int ACT, bool HAS_RES>
+template <typename TO, int ACT, bool HAS_RES, bool PERSIST, bool CONV = false>
 int launch_p10_inst(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p10<TO, ACT, HAS_RES>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p10<TO, ACT, HAS_RES, PERSIST, CONV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
         if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel_p10<TO, ACT, HAS_RES>), dim3(a.ntiles), dim3(256), LDS4, s, a);
+    hipLaunchKernelGGL((gemm_kernel_p10<TO, ACT, HAS_RES, PERSIST, CONV>), dim3(PERSIST ? 256 : a.ntiles), dim3(256), LDS4, s, a);
     return cfsar_check_launch("cfsar_gemm(p10)");
 }
 
-template <typename TO>
+template <typename TO, bool PERSIST>
 int launch_p10(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     a.tiles_n = (a.N + BN4 - 1) / BN4;
@@ -1773,8 +1915,8 @@ int launch_p10(const GemmArgs& a0, hipStream_t s) {
     const bool r = a.res != nullptr;
     if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF || a.K % 64 != 0) return -2;
     if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32)) return -2;   // 32-bit offsets
-    if (a.act == CFSAR_ACT_QUICKGELU) return r ? -2 : launch_p10_inst<TO, CFSAR_ACT_QUICKGELU, false>(a, s);
-    return r ? launch_p10_inst<TO, CFSAR_ACT_NONE, true>(a, s) : launch_p10_inst<TO, CFSAR_ACT_NONE, false>(a, s);
+    if (a.act == CFSAR_ACT_QUICKGELU) return r ? -2 : launch_p10_inst<TO, CFSAR_ACT_QUICKGELU, false, PERSIST>(a, s);
+    return r ? launch_p10_inst<TO, CFSAR_ACT_NONE, true, PERSIST>(a, s) : launch_p10_inst<TO, CFSAR_ACT_NONE, false, PERSIST>(a, s);
 }
 
 // dev tool (not in the public header): device buffer of 8 x u64 per 256x256 tile for the p6 phase timestamps; NULL = off
@@ -1819,6 +1961,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     static const int stag = [] { const char* e = getenv("CFSAR_GEMM_STAGGER"); return e ? atoi(e) : -1; }();
     a.stagger = stag;
     a.trace = g_trace;
+    a.conv_H = a.conv_W = a.conv_lgC = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // variant: 0 = auto, 1 = v1 (128x128, 2-stage, compiler-managed LDS-DMA), 2 = p3 (256x128, 3-stage, asm LDS-DMA)
     static const int forced_env = [] { const char* e = getenv("CFSAR_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
@@ -1830,8 +1973,16 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     // 10 = p10 (one wave per SIMD, register-staged whole-line operand requests).  auto: p10 for the epilogues without an
     // activation (QKV, out_proj, c_proj, RN50 convs: +2...+6 % over p6 at M = 126080, tools/gemm_ab.py); the QuickGELU
     // epilogue (c_fc) keeps p6, whose second wave per SIMD hides part of the 2-transcendentals-per-element VALU time.
-    if (in_dtype == CFSAR_BF16 && (forced == 10 || (forced == 0 && tiles4 >= 512 && act == CFSAR_ACT_NONE))) {
-        const int rc = out_dtype == CFSAR_BF16 ? launch_p10<__bf16>(a, s) : launch_p10<float>(a, s);
+    // ... and the skinny / short-K bf16-out GEMMs of the RN50 tower (N <= 256 or K < 512, often with a bf16 residual) go to
+    // p3: its 256x128 tile wastes less of a narrow N, two waves per SIMD overlap the HBM-bound epilogue, and the
+    // 16-byte-per-lane bf16 epilogue fits its register budget (tools/rn_gemm_ab.py).
+    const bool p10_shape = out_dtype == CFSAR_F32 || (N >= 512 && K >= 512 && !residual);
+    if (in_dtype == CFSAR_BF16 && (forced == 10 || (forced == 0 && tiles4 >= 512 && act == CFSAR_ACT_NONE && p10_shape))) {
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p10<__bf16, false>(a, s) : launch_p10<float, false>(a, s);
+        if (rc != -2) return rc;
+    }
+    if (in_dtype == CFSAR_BF16 && forced == 11) {              // 11 = p10 persistent (one workgroup per CU)
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p10<__bf16, true>(a, s) : launch_p10<float, true>(a, s);
         if (rc != -2) return rc;
     }
     if (in_dtype == CFSAR_BF16 && forced == 9) {               // 9 = p9 (p8 geometry, register-staged operands)
@@ -1846,11 +1997,11 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
         const int rc = out_dtype == CFSAR_BF16 ? launch_p6<__bf16, true>(a, s) : launch_p6<float, true>(a, s);
         if (rc != -2) return rc;
     }
-    if (in_dtype == CFSAR_BF16 && (forced == 6 || (forced == 0 && tiles4 >= 512))) {
+    if (in_dtype == CFSAR_BF16 && (forced == 6 || (forced == 0 && tiles4 >= 512 && (act != CFSAR_ACT_NONE || p10_shape)))) {
         const int rc = out_dtype == CFSAR_BF16 ? launch_p6<__bf16, false>(a, s) : launch_p6<float, false>(a, s);
         if (rc != -2) return rc;
     }
-    const bool use_p4 = in_dtype == CFSAR_BF16 && (forced == 3 || forced == 6 || forced == 7 || (forced == 0 && tiles4 >= 512));
+    const bool use_p4 = in_dtype == CFSAR_BF16 && (forced == 3 || forced == 6 || forced == 7);
     if (use_p4) {
         const int rc = out_dtype == CFSAR_BF16 ? launch_p4<__bf16>(a, s) : launch_p4<float>(a, s);
         if (rc != -2) return rc;
@@ -1859,7 +2010,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
         const int rc = out_dtype == CFSAR_BF16 ? launch_p5<__bf16>(a, s) : launch_p5<float>(a, s);
         if (rc != -2) return rc;
     }
-    const bool use_p3 = forced == 2 || forced == 3 || forced == 4 || forced == 6 || forced == 8 || forced == 9 || forced == 10 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
+    const bool use_p3 = forced == 2 || forced == 3 || forced == 4 || forced == 6 || forced == 8 || forced == 9 || forced == 10 || forced == 11 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
     if (use_p3) {
         int rc;
         if (in_dtype == CFSAR_BF16)
@@ -1878,4 +2029,46 @@ extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* 
                           int row_group, int row_gap, int row_off, int res_mod, int res_off, cfsar_stream_t stream) {
     return cfsar_gemm_ex(A, W, out, bias, residual, M, N, K, lda, ldw, ldo, ldr, in_dtype, out_dtype, act, row_group, row_gap,
                          row_off, res_mod, res_off, CFSAR_F32, 0, stream);
+}
+
+// Implicit-GEMM 3x3 convolution (pad 1, stride 1) on NHWC bf16 activations: out[f,y,x,:] = [relu](W . patch(f,y,x) + bias
+// (+ residual)); W is [Cout, ldw] tap-major ((ky*3+kx)*C + c), zero-padded to ldw = round_up(9*C, 64).  See the header.
+extern "C" int cfsar_conv3x3_nhwc(const void* in, const void* W, void* out, const float* bias, const void* residual, int F,
+                                  int H, int Wd, int C, int Cout, int ldw, int ldo, int ldr, int out_dtype, int res_dtype,
+                                  int relu, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(in && W && out, "cfsar_conv3x3_nhwc: null operand");
+    CFSAR_REQUIRE(F > 0 && H > 0 && Wd > 0 && Cout > 0 && Cout % 4 == 0, "cfsar_conv3x3_nhwc: bad shape");
+    CFSAR_REQUIRE(C >= 8 && (C & (C - 1)) == 0, "cfsar_conv3x3_nhwc: C=%d must be a power of two >= 8", C);
+    CFSAR_REQUIRE(ldw % 64 == 0 && ldw >= 9 * C && ldw < 16 * C + 64, "cfsar_conv3x3_nhwc: ldw=%d must be round_up(9*C, 64)", ldw);
+    CFSAR_REQUIRE(out_dtype == CFSAR_F32 || out_dtype == CFSAR_BF16, "cfsar_conv3x3_nhwc: bad out_dtype %d", out_dtype);
+    CFSAR_REQUIRE(res_dtype == CFSAR_F32 || res_dtype == CFSAR_BF16, "cfsar_conv3x3_nhwc: bad res_dtype %d", res_dtype);
+    CFSAR_REQUIRE(ldo >= Cout && (!residual || (ldr >= Cout && ldr % 4 == 0)), "cfsar_conv3x3_nhwc: bad ldo/ldr");
+    const long long M = (long long)F * H * Wd;
+    CFSAR_REQUIRE(M * C * 2 < (1ll << 32) && (long long)Cout * ldw * 2 < (1ll << 32), "cfsar_conv3x3_nhwc: tensor too large for 32-bit offsets");
+    GemmArgs a;
+    a.A = static_cast<const char*>(in);
+    a.W = static_cast<const char*>(W);
+    a.out = out;
+    a.bias = bias;
+    a.res = residual;
+    a.res_bf16 = res_dtype == CFSAR_BF16;
+    a.relu = relu;
+    a.M = (int)M; a.N = Cout; a.K = ldw;
+    a.lda = C; a.ldw = ldw; a.ldo = ldo; a.ldr = ldr;
+    a.act = CFSAR_ACT_NONE;
+    a.row_group = a.row_gap = a.row_off = a.res_mod = a.res_off = 0;
+    a.tiles_n = (Cout + BN4 - 1) / BN4;
+    a.ntiles = (int)((M + BM4 - 1) / BM4) * a.tiles_n;
+    a.stagger = -1;
+    a.trace = nullptr;
+    a.dbg = 0;
+    a.conv_H = H; a.conv_W = Wd;
+    a.conv_lgC = 0;
+    while ((1 << a.conv_lgC) < C) ++a.conv_lgC;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dtype == CFSAR_BF16)
+        return residual ? launch_p10_inst<__bf16, CFSAR_ACT_NONE, true, false, true>(a, s)
+                        : launch_p10_inst<__bf16, CFSAR_ACT_NONE, false, false, true>(a, s);
+    return residual ? launch_p10_inst<float, CFSAR_ACT_NONE, true, false, true>(a, s)
+                    : launch_p10_inst<float, CFSAR_ACT_NONE, false, false, true>(a, s);
 }

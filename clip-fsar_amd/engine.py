@@ -147,6 +147,8 @@ class HipResNet:
     epilogues; avgpool anti-aliasing and the attention-pool token build are small NHWC kernels; the attention pool runs
     through the fp32 short-sequence attention kernel (only the mean token's output row is kept)."""
 
+    IMPLICIT_MIN_TILES = 128          # 256x256 output tiles below which the implicit-GEMM conv would leave CUs idle
+
     def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda"):
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
@@ -200,6 +202,13 @@ class HipResNet:
 
     def _conv3x3(self, x, F_, H, W, C, wb, stride):
         w, b = wb
+        # implicit GEMM (no im2col matrix) when the tile grid fills the chip; the stem's first conv (C = 3, stride 2)
+        # and small launches keep the explicit gather + GEMM
+        if (stride == 1 and self.cd == torch.bfloat16 and C >= 8 and (C & (C - 1)) == 0
+                and ((F_ * H * W + 255) // 256) * ((w.shape[0] + 255) // 256) >= self.IMPLICIT_MIN_TILES):
+            out = torch.empty(F_ * H * W, w.shape[0], device=self.dev, dtype=self.cd)
+            hip.conv3x3(x, w, out, F_, H, W, C, bias=b, relu=True)
+            return out, H, W
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         cols = torch.empty(F_ * Ho * Wo, w.shape[1], device=self.dev, dtype=self.cd)
         hip.im2col3x3(x, cols, F_, H, W, C, stride)

@@ -32,6 +32,7 @@ SIGNATURES = {
     "cfsar_im2col3x3_nhwc": [_c_p, _c_p] + [_c_int] * 7 + [_c_p],
     "cfsar_avgpool2x2_nhwc": [_c_p, _c_p] + [_c_int] * 5 + [_c_p],
     "cfsar_attnpool_tokens": [_c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_p],
+    "cfsar_conv3x3_nhwc": [_c_p] * 5 + [_c_int] * 11 + [_c_p],
     "cfsar_vit_attention": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_class_text_logits": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_build_sequences": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p],
@@ -241,6 +242,17 @@ def im2col3x3(x, out, F_, H, W, C, stride):
 def avgpool2x2(x, out, F_, H, W, C):
     _check(lib().cfsar_avgpool2x2_nhwc(_dev(x, None, "x"), _dev(out, x.dtype, "out"), _code(x.dtype), F_, H, W, C, _stream()),
            "cfsar_avgpool2x2_nhwc")
+
+
+def conv3x3(x, w, out, F_, H, W, C, bias=None, residual=None, relu=False):
+    """Implicit-GEMM 3x3 / pad 1 / stride 1 conv on bf16 NHWC activations (include/clipfsar_hip.h: cfsar_conv3x3_nhwc)."""
+    if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+        raise RuntimeError("conv3x3: bf16 activations and weights only")
+    _check(lib().cfsar_conv3x3_nhwc(_dev(x, None, "x"), _dev(w, None, "w"), _dev(out, None, "out"),
+                                    _opt(bias, torch.float32, "bias"), _opt(residual, None, "residual"), F_, H, W, C,
+                                    w.shape[0], w.shape[1], out.shape[-1], residual.shape[-1] if residual is not None else 0,
+                                    _code(out.dtype), _code(residual.dtype) if residual is not None else F32,
+                                    int(bool(relu)), _stream()), "cfsar_conv3x3_nhwc")
 
 
 def attnpool_tokens(x, pos, out, F_, HW, C):

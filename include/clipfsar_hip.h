@@ -93,6 +93,15 @@ int cfsar_avgpool2x2_nhwc(const void* in, void* out, int dtype, int F, int H, in
 int cfsar_attnpool_tokens(const void* x, const float* pos, void* out, int dtype, int F, int HW, int C,
                           cfsar_stream_t stream);
 
+/* nn.Conv2d(C, Cout, 3, padding=1, bias=False) + folded BatchNorm (+ identity) + ReLU of the RN50 tower (few_shot.py:196,
+ * 213-226) as ONE implicit-GEMM launch on bf16 NHWC activations: the 3x3 patches are gathered inside the GEMM's operand
+ * staging (no im2col matrix in HBM).  in [F,H,W,C] bf16, C a power of two >= 8; W [Cout, ldw] bf16, tap-major columns
+ * (ky*3+kx)*C + c, zero-padded to ldw = round_up(9*C, 64); out [F*H*W, ldo] (out_dtype); bias fp32 [Cout] or NULL;
+ * residual [F*H*W, ldr] (res_dtype) or NULL; relu != 0 applies max(., 0) last. */
+int cfsar_conv3x3_nhwc(const void* in, const void* W, void* out, const float* bias, const void* residual, int F, int H,
+                       int Wd, int C, int Cout, int ldw, int ldo, int ldr, int out_dtype, int res_dtype, int relu,
+                       cfsar_stream_t stream);
+
 /* ---- A5 scaled-dot-product attention of nn.MultiheadAttention for the ViT (no mask, no dropout), head_dim 64.
  * qkv [F*ntok, 3*D] packed as [q | k | v], head h at columns h*64 of each third; out [F*ntok, D].
  * dtype bf16: MFMA kernel (K and V^T of one (frame, head) staged in LDS, single-pass softmax in registers);

@@ -312,7 +312,7 @@ def test_avgpool_and_attnpool_tokens(hip, dtype):
     assert maxdiff(tok.float().cpu(), ref_tok) < (2e-6 if dtype == "f32" else 3e-2)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11])
 def test_gemm_every_kernel_variant(hip, variant):
     """Each bf16 GEMM kernel kept in gemm.hip (v1 / p3 / p4 / p5 / p6 / p6-persistent / p8 / p9 / p10; the auto policy only
     picks p10, p6, p3 and v1) against the fp32 product of the bf16-rounded operands, on ragged M and N edges, through the
@@ -344,3 +344,30 @@ def test_gemm_every_kernel_variant(hip, variant):
             assert maxdiff(out.float().cpu(), torch.relu(ref0 + rb.float())) < 2e-2 * scale, ("relu", variant, M, N, K)
     finally:
         L.cfsar_debug_set_gemm_variant(-1, -1)
+
+
+@pytest.mark.parametrize("C,H,W_,Co,res", [(32, 12, 10, 64, False), (64, 9, 14, 64, False), (128, 7, 7, 128, True), (8, 5, 6, 260, True)])
+def test_conv3x3_implicit_gemm(hip, C, H, W_, Co, res):
+    """cfsar_conv3x3_nhwc (patch gather inside the GEMM operand staging) == nn.Conv2d(3, padding=1) + bias (+ residual) +
+    ReLU on bf16-rounded operands; ragged M (F*H*W not a multiple of 256), ragged N, image borders, K padding."""
+    import torch.nn.functional as F
+    Fn = 5
+    x = _rand(Fn, C, H, W_, seed=21).to(torch.bfloat16)
+    w = _rand(Co, C, 3, 3, seed=22, scale=(9 * C) ** -0.5).to(torch.bfloat16)
+    bias = _rand(Co, seed=23)
+    kpad = -(-9 * C // 64) * 64
+    wt = torch.zeros(Co, kpad, dtype=torch.bfloat16)
+    wt[:, :9 * C] = w.permute(0, 2, 3, 1).reshape(Co, 9 * C)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()                                       # NHWC
+    ref = F.conv2d(x.float(), w.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co) + bias
+    r = _rand(Fn * H * W_, Co, seed=24).to(torch.bfloat16) if res else None
+    if res:
+        ref = ref + r.float()
+    ref = torch.relu(ref)
+    out = torch.full((Fn * H * W_, Co), float("nan"), device="cuda", dtype=torch.bfloat16)
+    hip.conv3x3(xd, wt.cuda(), out, Fn, H, W_, C, bias=bias.cuda(), residual=r.cuda() if res else None, relu=True)
+    assert maxdiff(out.float().cpu(), ref) < 2e-2 * max(1.0, float(ref.abs().max()))
+    out32 = torch.empty(Fn * H * W_, Co, device="cuda", dtype=torch.float32)
+    hip.conv3x3(xd, wt.cuda(), out32, Fn, H, W_, C, bias=bias.cuda())
+    ref2 = F.conv2d(x.float(), w.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co) + bias
+    assert maxdiff(out32.cpu(), ref2) < 2e-3 * max(1.0, float(ref2.abs().max()))
