@@ -93,6 +93,48 @@ __global__ __launch_bounds__(256) void attnpool_tokens_kernel(const T* __restric
     }
 }
 
+
+// AttentionPool2d attention for the ONE query the pool keeps (the mean token, few_shot.py:450-469: multi_head_attention_forward
+// over [mean ; x], output row 0): one wave per (frame, head).  scores_t = scale * q . k_t (lane = token, chunks of 64),
+// softmax over the T tokens (fp32, wave reductions), out_d = sum_t p_t v_td (lane = d).  q [F, C], kv [F*T, 2C] = [k | v].
+__global__ __launch_bounds__(64) void attnpool_attend_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                             float* __restrict__ out, int T, int heads, int hd, float scale) {
+    __shared__ float sc[512];
+    __shared__ float qs[128];
+    const int f = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int lane = threadIdx.x;
+    const int C = heads * hd;
+    for (int d = lane; d < hd; d += 64) qs[d] = q[(long long)f * C + h * hd + d] * scale;
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = lane; t < T; t += 64) {
+        const float* kr = kv + ((long long)f * T + t) * 2 * C + h * hd;
+        float s = 0.f;
+        for (int d = 0; d < hd; d += 4) {
+            const float4 k4 = *reinterpret_cast<const float4*>(kr + d);
+            s += qs[d] * k4.x + qs[d + 1] * k4.y + qs[d + 2] * k4.z + qs[d + 3] * k4.w;
+        }
+        sc[t] = s;
+        mx = fmaxf(mx, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int t = lane; t < T; t += 64) {
+        const float e = __expf(sc[t] - mx);
+        sc[t] = e;
+        sum += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    for (int d = lane; d < hd; d += 64) {
+        const float* vr = kv + (long long)f * T * 2 * C + C + h * hd + d;
+        float a = 0.f;
+        for (int t = 0; t < T; ++t) a += sc[t] * vr[(long long)t * 2 * C];
+        out[(long long)f * C + h * hd + d] = a * inv;
+    }
+}
+
 template <typename F>
 int grid_for(long long total, F) {
     long long b = (total + 255) / 256;
@@ -171,4 +213,13 @@ extern "C" int cfsar_attnpool_tokens(const void* x, const float* pos, void* out,
     else
         return cfsar_fail("cfsar_attnpool_tokens: bad dtype %d", dtype);
     return cfsar_check_launch("cfsar_attnpool_tokens");
+}
+
+extern "C" int cfsar_attnpool_attend(const float* q, const float* kv, float* out, int F, int T, int heads, int head_dim,
+                                     float scale, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(q && kv && out && F > 0 && T > 0 && heads > 0, "cfsar_attnpool_attend: bad arguments");
+    CFSAR_REQUIRE(T <= 512 && head_dim > 0 && head_dim <= 128 && head_dim % 4 == 0, "cfsar_attnpool_attend: T=%d (<= 512), head_dim=%d (<= 128, %% 4)", T, head_dim);
+    hipLaunchKernelGGL(attnpool_attend_kernel, dim3(F * heads), dim3(64), 0, static_cast<hipStream_t>(stream), q, kv, out, T,
+                       heads, head_dim, scale);
+    return cfsar_check_launch("cfsar_attnpool_attend");
 }

@@ -144,8 +144,8 @@ class HipResNet:
 
     NHWC activations; BatchNorm (eval, running statistics) folded into the conv weights and a per-channel bias on the
     host; 1x1 convs are cfsar_gemm rows, 3x3 convs a tap-major gather + cfsar_gemm; ReLU / identity-add are GEMM
-    epilogues; avgpool anti-aliasing and the attention-pool token build are small NHWC kernels; the attention pool runs
-    through the fp32 short-sequence attention kernel (only the mean token's output row is kept)."""
+    epilogues; avgpool anti-aliasing and the attention-pool token build are small NHWC kernels; the attention pool computes k/v
+    for every token but q and the softmax only for the one query it keeps (the mean token)."""
 
     IMPLICIT_MIN_TILES = 128          # 256x256 output tiles below which the implicit-GEMM conv would leave CUs idle
 
@@ -195,8 +195,10 @@ class HipResNet:
                 inplanes = planes * 4
         self.C = inplanes
         self.pos = g("attnpool.positional_embedding").contiguous()
-        self.w_qkv = torch.cat([g("attnpool.q_proj.weight"), g("attnpool.k_proj.weight"), g("attnpool.v_proj.weight")], 0).to(self.cd).contiguous()
-        self.b_qkv = torch.cat([g("attnpool.q_proj.bias"), g("attnpool.k_proj.bias"), g("attnpool.v_proj.bias")], 0).contiguous()
+        self.w_q = g("attnpool.q_proj.weight").to(self.cd).contiguous()
+        self.b_q = g("attnpool.q_proj.bias").contiguous()
+        self.w_kv = torch.cat([g("attnpool.k_proj.weight"), g("attnpool.v_proj.weight")], 0).to(self.cd).contiguous()
+        self.b_kv = torch.cat([g("attnpool.k_proj.bias"), g("attnpool.v_proj.bias")], 0).contiguous()
         self.w_c = g("attnpool.c_proj.weight").contiguous()                     # final projection in fp32
         self.b_c = g("attnpool.c_proj.bias").contiguous()
 
@@ -272,14 +274,14 @@ class HipResNet:
         HW, C = H * W, self.C                                                            # AttentionPool2d (:446-538)
         tok = torch.empty(F_ * (HW + 1), C, device=self.dev, dtype=self.cd)
         hip.attnpool_tokens(x, self.pos, tok, F_, HW, C)
-        qkv = torch.empty(F_ * (HW + 1), 3 * C, device=self.dev, dtype=torch.float32)
-        hip.gemm(tok, self.w_qkv, qkv, bias=self.b_qkv)
-        att = torch.empty(F_ * (HW + 1), C, device=self.dev, dtype=torch.float32)
+        T = HW + 1
+        kv = torch.empty(F_ * T, 2 * C, device=self.dev, dtype=torch.float32)            # k and v of every token
+        hip.gemm(tok, self.w_kv, kv, bias=self.b_kv)
+        q = torch.empty(F_, C, device=self.dev, dtype=torch.float32)                      # q of the mean token only
+        hip.gemm(tok, self.w_q, q, bias=self.b_q, M=F_, N=C, K=C, lda=T * C)
         hd = C // self.heads
-        hip.seq_attention(qkv, att, F_, HW + 1, 0, 0, self.heads, hd, hd ** -0.5)
-        idx = (torch.arange(F_, device=self.dev, dtype=torch.int32) * (HW + 1)).contiguous()   # query = the mean token
         pooled = torch.empty(F_, C, device=self.dev, dtype=torch.float32)
-        hip.gather_rows(att, idx, pooled)
+        hip.attnpool_attend(q, kv, pooled, F_, T, self.heads, hd, hd ** -0.5)
         off = 0
         for c, (rg, gap, roff) in zip(counts, row_maps):
             hip.gemm(pooled[off:off + c], self.w_c, feats_out, bias=self.b_c, M=c, N=self.E, K=C, ldo=self.E,

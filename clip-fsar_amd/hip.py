@@ -33,6 +33,7 @@ SIGNATURES = {
     "cfsar_avgpool2x2_nhwc": [_c_p, _c_p] + [_c_int] * 5 + [_c_p],
     "cfsar_attnpool_tokens": [_c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_p],
     "cfsar_conv3x3_nhwc": [_c_p] * 5 + [_c_int] * 11 + [_c_p],
+    "cfsar_attnpool_attend": [_c_p, _c_p, _c_p] + [_c_int] * 4 + [ctypes.c_float, _c_p],
     "cfsar_vit_attention": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_class_text_logits": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_build_sequences": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p],
@@ -242,6 +243,11 @@ def im2col3x3(x, out, F_, H, W, C, stride):
 def avgpool2x2(x, out, F_, H, W, C):
     _check(lib().cfsar_avgpool2x2_nhwc(_dev(x, None, "x"), _dev(out, x.dtype, "out"), _code(x.dtype), F_, H, W, C, _stream()),
            "cfsar_avgpool2x2_nhwc")
+
+
+def attnpool_attend(q, kv, out, F_, T, heads, head_dim, scale):
+    _check(lib().cfsar_attnpool_attend(_dev(q, torch.float32, "q"), _dev(kv, torch.float32, "kv"), _dev(out, torch.float32, "out"),
+                                       F_, T, heads, head_dim, float(scale), _stream()), "cfsar_attnpool_attend")
 
 
 def conv3x3(x, w, out, F_, H, W, C, bias=None, residual=None, relu=False):

@@ -93,6 +93,12 @@ int cfsar_avgpool2x2_nhwc(const void* in, void* out, int dtype, int F, int H, in
 int cfsar_attnpool_tokens(const void* x, const float* pos, void* out, int dtype, int F, int HW, int C,
                           cfsar_stream_t stream);
 
+/* AttentionPool2d attention for the single query it keeps (the mean token; few_shot.py:450-469): q [F, C] fp32 (q_proj of
+ * token 0, bias included, NOT yet scaled), kv [F*T, 2C] fp32 = [k_proj | v_proj] of all T = HW+1 tokens, out [F, C] fp32 =
+ * softmax(scale * q k^T) v per head (C = heads * head_dim, head_dim <= 128, T <= 512); c_proj follows as a cfsar_gemm. */
+int cfsar_attnpool_attend(const float* q, const float* kv, float* out, int F, int T, int heads, int head_dim, float scale,
+                          cfsar_stream_t stream);
+
 /* nn.Conv2d(C, Cout, 3, padding=1, bias=False) + folded BatchNorm (+ identity) + ReLU of the RN50 tower (few_shot.py:196,
  * 213-226) as ONE implicit-GEMM launch on bf16 NHWC activations: the 3x3 patches are gathered inside the GEMM's operand
  * staging (no im2col matrix in HBM).  in [F,H,W,C] bf16, C a power of two >= 8; W [Cout, ldw] bf16, tap-major columns

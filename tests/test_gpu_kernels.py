@@ -371,3 +371,19 @@ def test_conv3x3_implicit_gemm(hip, C, H, W_, Co, res):
     hip.conv3x3(xd, wt.cuda(), out32, Fn, H, W_, C, bias=bias.cuda())
     ref2 = F.conv2d(x.float(), w.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co) + bias
     assert maxdiff(out32.cpu(), ref2) < 2e-3 * max(1.0, float(ref2.abs().max()))
+
+
+@pytest.mark.parametrize("T,heads,hd", [(50, 32, 64), (5, 4, 8), (82, 2, 128)])
+def test_attnpool_attend_single_query(hip, T, heads, hd):
+    """cfsar_attnpool_attend == row 0 of softmax(scale q k^T) v per head (the only row AttentionPool2d returns,
+    few_shot.py:450-469), fp32."""
+    Fn, C = 3, heads * hd
+    q = _rand(Fn, C, seed=31)
+    kv = _rand(Fn * T, 2 * C, seed=32)
+    k = kv[:, :C].reshape(Fn, T, heads, hd).permute(0, 2, 1, 3)
+    v = kv[:, C:].reshape(Fn, T, heads, hd).permute(0, 2, 1, 3)
+    qh = q.reshape(Fn, heads, 1, hd) * hd ** -0.5
+    ref = (torch.softmax(qh @ k.transpose(-1, -2), -1) @ v).reshape(Fn, C)
+    out = torch.empty(Fn, C, device="cuda")
+    hip.attnpool_attend(q.cuda(), kv.cuda(), out, Fn, T, heads, hd, hd ** -0.5)
+    assert maxdiff(out.cpu(), ref) < 2e-5
