@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch
 from _cases import SMALL_CASES, case_inputs, load_golden, maxdiff, run_engine
-cases = SMALL_CASES + ["cfg2_B16_5w1s_T8", "cfg3_B16_5w5s_T8_mb", "cfg4_L14_5w1s_T16"]
+cases = SMALL_CASES + ["cfg2_B16_5w1s_T8", "cfg3_B16_5w5s_T8_mb", "cfg4_L14_5w1s_T16", "rn50_5w1s_T2"]
 print("| case | logits spread | fp32: max abs dlogits | fp32: max abs dfeats | bf16: max abs dlogits | bf16 argmax agrees |")
 print("|---|---|---|---|---|---|")
 for name in cases:
