@@ -565,7 +565,11 @@ __device__ __forceinline__ void glds16_asm(const char* src, unsigned lds_addr) {
         : "memory");
 }
 
-template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
+// CONV (bf16): the X operand is gathered on the fly from an NHWC tensor (implicit GEMM for nn.Conv2d(3, padding=1), see
+// gemm_kernel_p10): per K slice every lane picks the pixel of its chunk's tap, or a 16-byte block of zeros outside the image
+// (LDS-DMA takes per-lane source addresses).  This is the conv kernel for Cout <= 128 (256x128 tile; p10 for wider ones).
+__device__ const uint4 g_zero_chunk[2] = {};
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP, bool CONV = false>
 __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BK = ROWB / (int)sizeof(TI);
@@ -581,13 +585,28 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
     // staging: X tile = 32 instructions of 8 rows, W tile = 16; wave w issues X instr {w, w+8, w+16, w+24}, W {w, w+8}
     const char* srcX[4];
     const char* srcW[2];
+    unsigned cmask[CONV ? 2 : 1] = {};     // CONV: two 16-bit tap-validity masks per register
+    // CONV: swz(row) = (wave*4 + lane/16) & 7 for every piece of a lane -> one chunk position / tap per lane and K slice
+    const int cchunk = ((lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7)) * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (i * 8 + wave) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ swz(row);
         int gm = m0 + row;
         gm = gm < p.M ? gm : p.M - 1;
-        srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
+        if constexpr (CONV) {
+            const int x = gm % p.conv_W, y = (gm / p.conv_W) % p.conv_H;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (yy >= 0 && yy < p.conv_H && xx >= 0 && xx < p.conv_W) mk |= 1u << t;
+            }
+            cmask[i >> 1] |= mk << ((i & 1) * 16);
+            srcX[i] = p.A + (((size_t)gm << p.conv_lgC) * 2);              // centre pixel, channel 0
+        } else {
+            srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -602,8 +621,21 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
     auto issue = [&](int stage, int kt) {
         const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)stage * (unsigned)STAGE2);
         const size_t koff = (size_t)kt * ROWB;
+        if constexpr (CONV) {
+            const int kk = kt * 64 + cchunk;
+            const int tap = kk >> p.conv_lgC, cc = kk & ((1 << p.conv_lgC) - 1);
+            const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;                           // tap / 3, tap % 3 for tap < 16
+            const long long delta = (long long)(((((dy - 1) * p.conv_W + (dx - 1)) << p.conv_lgC) + cc) * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16_asm(srcX[i] + koff, base + i * 8192);
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (cmask[i >> 1] >> ((i & 1) * 16 + tap)) & 1u;
+                const char* src = ok ? srcX[i] + delta : reinterpret_cast<const char*>(g_zero_chunk);
+                glds16_asm(src, base + i * 8192);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16_asm(srcX[i] + koff, base + i * 8192);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16_asm(srcW[i] + koff, base + BM2 * ROWB + i * 8192);
     };
@@ -660,17 +692,17 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
     }
 }
 
-template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP, bool CONV = false>
 int launch_p3_inst(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP, CONV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
         if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles_m = (a.M + BM2 - 1) / BM2;
-    hipLaunchKernelGGL((gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP>), dim3(tiles_m * a.tiles_n), dim3(NTHREADS2),
+    hipLaunchKernelGGL((gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP, CONV>), dim3(tiles_m * a.tiles_n), dim3(NTHREADS2),
                        NSTAGE2 * STAGE2, s, a);
     return cfsar_check_launch("cfsar_gemm(p3)");
 }
@@ -2066,6 +2098,12 @@ extern "C" int cfsar_conv3x3_nhwc(const void* in, const void* W, void* out, cons
     a.conv_lgC = 0;
     while ((1 << a.conv_lgC) < C) ++a.conv_lgC;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const int conv_variant = [] { const char* e = getenv("CFSAR_CONV_VARIANT"); return e ? atoi(e) : 0; }();
+    if (out_dtype == CFSAR_BF16 && (conv_variant == 3 || (conv_variant == 0 && Cout <= 128))) {   // narrow outputs: 256x128 tile
+        a.tiles_n = (Cout + BN2 - 1) / BN2;
+        return residual ? launch_p3_inst<__bf16, __bf16, CFSAR_ACT_NONE, true, false, true>(a, s)
+                        : launch_p3_inst<__bf16, __bf16, CFSAR_ACT_NONE, false, false, true>(a, s);
+    }
     if (out_dtype == CFSAR_BF16)
         return residual ? launch_p10_inst<__bf16, CFSAR_ACT_NONE, true, false, true>(a, s)
                         : launch_p10_inst<__bf16, CFSAR_ACT_NONE, false, false, true>(a, s);

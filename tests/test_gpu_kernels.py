@@ -346,7 +346,7 @@ def test_gemm_every_kernel_variant(hip, variant):
         L.cfsar_debug_set_gemm_variant(-1, -1)
 
 
-@pytest.mark.parametrize("C,H,W_,Co,res", [(32, 12, 10, 64, False), (64, 9, 14, 64, False), (128, 7, 7, 128, True), (8, 5, 6, 260, True)])
+@pytest.mark.parametrize("C,H,W_,Co,res", [(32, 12, 10, 64, False), (32, 11, 13, 32, True), (64, 9, 14, 64, False), (128, 7, 7, 128, True), (8, 5, 6, 260, True), (64, 10, 9, 256, False)])
 def test_conv3x3_implicit_gemm(hip, C, H, W_, Co, res):
     """cfsar_conv3x3_nhwc (patch gather inside the GEMM operand staging) == nn.Conv2d(3, padding=1) + bias (+ residual) +
     ReLU on bf16-rounded operands; ragged M (F*H*W not a multiple of 256), ragged N, image borders, K padding."""
@@ -387,3 +387,27 @@ def test_attnpool_attend_single_query(hip, T, heads, hd):
     out = torch.empty(Fn, C, device="cuda")
     hip.attnpool_attend(q.cuda(), kv.cuda(), out, Fn, T, heads, hd, hd ** -0.5)
     assert maxdiff(out.cpu(), ref) < 2e-5
+
+
+def test_vit_attention_pipelined_variant(hip, monkeypatch):
+    """The 4-heads-per-workgroup LDS-DMA form of the bf16 attention kernel (CFSAR_ATTN_VARIANT=2, read once per process ->
+    run in a subprocess) == the fp32 softmax(q k^T / 8) v on bf16-rounded inputs."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import torch, sys
+        sys.path.insert(0, %r)
+        from clip_fsar_amd import hip
+        F_, N, D, H = 3, 197, 768, 12
+        g = torch.Generator().manual_seed(5)
+        qkv = torch.randn(F_ * N, 3 * D, generator=g).to(torch.bfloat16)
+        o = torch.empty(F_ * N, D, device="cuda", dtype=torch.bfloat16)
+        hip.vit_attention(qkv.cuda(), o, F_, N, D, H)
+        x = qkv.float().reshape(F_, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+        ref = (torch.softmax(x[0] @ x[1].transpose(-1, -2) / 8.0, -1) @ x[2]).permute(0, 2, 1, 3).reshape(F_ * N, D)
+        d = float((o.float().cpu() - ref).abs().max())
+        assert d < 2e-2, d
+        print("ok", d)
+    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CFSAR_ATTN_VARIANT="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
