@@ -135,6 +135,69 @@ __global__ __launch_bounds__(64) void attnpool_attend_kernel(const float* __rest
     }
 }
 
+// Stem conv1 of the ModifiedResNet (few_shot.py:558-560, 582-586): nn.Conv2d(3, Cout, 3, stride 2, padding 1) + folded
+// BatchNorm + ReLU, straight from the fp32 NCHW frames to NHWC activations -- no layout pass, no im2col matrix (K = 27 is
+// far too short for the matrix cores; the layer is HBM-bound: 385 MB in, 514 MB out at 640 frames).  One thread per output
+// pixel: 27 inputs in registers, weights [27][COUT] broadcast from LDS, fp32 FMAs, COUT outputs stored as 16-byte vectors.
+template <typename TO, int COUT>
+__global__ __launch_bounds__(256) void stem_conv1_kernel(const float* __restrict__ frames, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, TO* __restrict__ out, int H, int W,
+                                                         int Ho, int Wo, long long npix, int relu) {
+    __shared__ float sw[27 * COUT];
+    __shared__ float sb[COUT];
+    // w is [COUT][3][3][3] (PyTorch layout: o, c, ky, kx) -> sw[(c*9 + ky*3 + kx) * COUT + o]
+    for (int i = threadIdx.x; i < 27 * COUT; i += 256) sw[(i % 27) * COUT + i / 27] = w[i];
+    for (int i = threadIdx.x; i < COUT; i += 256) sb[i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= npix) return;
+    const int xo = (int)(pix % Wo);
+    const long long t = pix / Wo;
+    const int yo = (int)(t % Ho);
+    const long long f = t / Ho;
+    float in[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = 2 * yo + ky - 1, xx = 2 * xo + kx - 1;
+                float v = 0.f;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = frames[((f * 3 + c) * H + yy) * (long long)W + xx];
+                in[c * 9 + ky * 3 + kx] = v;
+            }
+    TO* op = out + pix * COUT;
+#pragma unroll
+    for (int o0 = 0; o0 < COUT; o0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = sb[o0 + j];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const float4 w0 = *reinterpret_cast<const float4*>(&sw[k * COUT + o0]);
+            const float4 w1 = *reinterpret_cast<const float4*>(&sw[k * COUT + o0 + 4]);
+            acc[0] = fmaf(in[k], w0.x, acc[0]); acc[1] = fmaf(in[k], w0.y, acc[1]);
+            acc[2] = fmaf(in[k], w0.z, acc[2]); acc[3] = fmaf(in[k], w0.w, acc[3]);
+            acc[4] = fmaf(in[k], w1.x, acc[4]); acc[5] = fmaf(in[k], w1.y, acc[5]);
+            acc[6] = fmaf(in[k], w1.z, acc[6]); acc[7] = fmaf(in[k], w1.w, acc[7]);
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+        }
+        if constexpr (sizeof(TO) == 2) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[j];
+            *reinterpret_cast<bf16x8*>(op + o0) = o;
+        } else {
+            *reinterpret_cast<float4*>(op + o0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(op + o0 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    }
+}
+
 template <typename F>
 int grid_for(long long total, F) {
     long long b = (total + 255) / 256;
@@ -222,4 +285,30 @@ extern "C" int cfsar_attnpool_attend(const float* q, const float* kv, float* out
     hipLaunchKernelGGL(attnpool_attend_kernel, dim3(F * heads), dim3(64), 0, static_cast<hipStream_t>(stream), q, kv, out, T,
                        heads, head_dim, scale);
     return cfsar_check_launch("cfsar_attnpool_attend");
+}
+
+template <typename TO>
+static int launch_stem(const float* frames, const float* w, const float* bias, void* out, int F, int H, int W, int Cout, int relu,
+                       hipStream_t s) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long npix = (long long)F * Ho * Wo;
+    const dim3 grid((unsigned)((npix + 255) / 256));
+    TO* o = static_cast<TO*>(out);
+    switch (Cout) {
+        case 8: hipLaunchKernelGGL((stem_conv1_kernel<TO, 8>), grid, dim3(256), 0, s, frames, w, bias, o, H, W, Ho, Wo, npix, relu); break;
+        case 16: hipLaunchKernelGGL((stem_conv1_kernel<TO, 16>), grid, dim3(256), 0, s, frames, w, bias, o, H, W, Ho, Wo, npix, relu); break;
+        case 32: hipLaunchKernelGGL((stem_conv1_kernel<TO, 32>), grid, dim3(256), 0, s, frames, w, bias, o, H, W, Ho, Wo, npix, relu); break;
+        case 64: hipLaunchKernelGGL((stem_conv1_kernel<TO, 64>), grid, dim3(256), 0, s, frames, w, bias, o, H, W, Ho, Wo, npix, relu); break;
+        default: return cfsar_fail("cfsar_stem_conv3x3_s2: Cout=%d not in {8, 16, 32, 64}", Cout);
+    }
+    return cfsar_check_launch("cfsar_stem_conv3x3_s2");
+}
+
+extern "C" int cfsar_stem_conv3x3_s2(const float* frames, const float* w, const float* bias, void* out, int out_dtype, int F,
+                                     int H, int W, int Cout, int relu, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(frames && w && out && F > 0 && H > 0 && W > 0, "cfsar_stem_conv3x3_s2: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dtype == CFSAR_BF16) return launch_stem<__bf16>(frames, w, bias, out, F, H, W, Cout, relu, s);
+    if (out_dtype == CFSAR_F32) return launch_stem<float>(frames, w, bias, out, F, H, W, Cout, relu, s);
+    return cfsar_fail("cfsar_stem_conv3x3_s2: bad out_dtype %d", out_dtype);
 }

@@ -181,6 +181,13 @@ class HipResNet:
             return wp.to(self.cd).contiguous(), b.contiguous()
 
         self.stem = [fold("conv1", "bn1"), fold("conv2", "bn2"), fold("conv3", "bn3")]
+        # bf16 mode: conv1 runs as a direct fp32 kernel on the NCHW frames (K = 27 is too short for the matrix cores and the
+        # layer is HBM-bound); the fp32 validation mode keeps the gather + exact-fp32 MFMA GEMM
+        self.stem_direct = None
+        if self.cd == torch.bfloat16 and (self.width // 2) in (8, 16, 32, 64):
+            s1 = g("bn1.weight") / torch.sqrt(g("bn1.running_var") + 1e-5)
+            self.stem_direct = ((g("conv1.weight") * s1.reshape(-1, 1, 1, 1)).contiguous(),
+                                (g("bn1.bias") - g("bn1.running_mean") * s1).contiguous())
         self.blocks = []
         inplanes = self.width
         for li, (planes, nb) in enumerate(zip((self.width, self.width * 2, self.width * 4, self.width * 8), self.layers), 1):
@@ -236,15 +243,26 @@ class HipResNet:
         if feats_out is None:
             feats_out = torch.empty(F_, self.E, device=self.dev, dtype=torch.float32)
         res = self.arch["res"]
-        x = torch.empty(F_ * res * res, 3, device=self.dev, dtype=self.cd)
-        off = 0
-        for fr, c in zip(frame_sets, counts):
+        for fr in frame_sets:
             if fr.shape[1:] != (3, res, res):
                 raise RuntimeError("frames must be [F,3,%d,%d], got %s" % (res, res, tuple(fr.shape)))
-            hip.nchw_to_nhwc(fr, x[off * res * res:(off + c) * res * res])
-            off += c
         H = W = res
-        x, H, W = self._conv3x3(x, F_, H, W, 3, self.stem[0], 2)                         # stem (:582-586)
+        if self.stem_direct is not None:
+            # stem conv1 (:582-586) straight from the fp32 NCHW frames: no layout pass, no im2col matrix
+            Ho = (res - 1) // 2 + 1
+            x = torch.empty(F_ * Ho * Ho, self.width // 2, device=self.dev, dtype=self.cd)
+            off = 0
+            for fr, c in zip(frame_sets, counts):
+                hip.stem_conv(fr, self.stem_direct[0], self.stem_direct[1], x[off * Ho * Ho:(off + c) * Ho * Ho], relu=True)
+                off += c
+            H = W = Ho
+        else:
+            x = torch.empty(F_ * res * res, 3, device=self.dev, dtype=self.cd)
+            off = 0
+            for fr, c in zip(frame_sets, counts):
+                hip.nchw_to_nhwc(fr, x[off * res * res:(off + c) * res * res])
+                off += c
+            x, H, W = self._conv3x3(x, F_, H, W, 3, self.stem[0], 2)                     # stem (:582-586)
         x, H, W = self._conv3x3(x, F_, H, W, self.width // 2, self.stem[1], 1)
         x, H, W = self._conv3x3(x, F_, H, W, self.width // 2, self.stem[2], 1)
         x = self._pool(x, F_, H, W, self.width)

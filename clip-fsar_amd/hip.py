@@ -34,6 +34,7 @@ SIGNATURES = {
     "cfsar_attnpool_tokens": [_c_p, _c_p, _c_p] + [_c_int] * 4 + [_c_p],
     "cfsar_conv3x3_nhwc": [_c_p] * 5 + [_c_int] * 11 + [_c_p],
     "cfsar_attnpool_attend": [_c_p, _c_p, _c_p] + [_c_int] * 4 + [ctypes.c_float, _c_p],
+    "cfsar_stem_conv3x3_s2": [_c_p] * 4 + [_c_int] * 6 + [_c_p],
     "cfsar_vit_attention": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_class_text_logits": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_build_sequences": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p],
@@ -243,6 +244,16 @@ def im2col3x3(x, out, F_, H, W, C, stride):
 def avgpool2x2(x, out, F_, H, W, C):
     _check(lib().cfsar_avgpool2x2_nhwc(_dev(x, None, "x"), _dev(out, x.dtype, "out"), _code(x.dtype), F_, H, W, C, _stream()),
            "cfsar_avgpool2x2_nhwc")
+
+
+def stem_conv(frames, w, bias, out, relu=True):
+    """RN50 stem conv1 (3 -> Cout, 3x3, stride 2, pad 1) + folded BN + ReLU from fp32 NCHW frames to NHWC `out`."""
+    F_, C, H, W = frames.shape
+    if C != 3:
+        raise RuntimeError("stem_conv: 3 input channels expected")
+    _check(lib().cfsar_stem_conv3x3_s2(_dev(frames, torch.float32, "frames"), _dev(w, torch.float32, "w"),
+                                       _opt(bias, torch.float32, "bias"), _dev(out, None, "out"), _code(out.dtype), F_, H, W,
+                                       w.shape[0], int(bool(relu)), _stream()), "cfsar_stem_conv3x3_s2")
 
 
 def attnpool_attend(q, kv, out, F_, T, heads, head_dim, scale):

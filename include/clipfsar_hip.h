@@ -93,6 +93,13 @@ int cfsar_avgpool2x2_nhwc(const void* in, void* out, int dtype, int F, int H, in
 int cfsar_attnpool_tokens(const void* x, const float* pos, void* out, int dtype, int F, int HW, int C,
                           cfsar_stream_t stream);
 
+/* Stem conv1 of the ModifiedResNet (few_shot.py:558-560, 582-586): nn.Conv2d(3, Cout, 3, stride=2, padding=1, bias=False) +
+ * folded BatchNorm (+ ReLU when relu != 0), straight from fp32 NCHW frames [F,3,H,W] to NHWC activations
+ * out [F, Ho, Wo, Cout] (out_dtype), Ho = (H-1)/2+1.  w fp32 [Cout, 3, 3, 3] (PyTorch layout, BN scale folded in), bias fp32
+ * [Cout] or NULL; Cout in {8, 16, 32, 64}.  fp32 arithmetic. */
+int cfsar_stem_conv3x3_s2(const float* frames, const float* w, const float* bias, void* out, int out_dtype, int F, int H,
+                          int W, int Cout, int relu, cfsar_stream_t stream);
+
 /* AttentionPool2d attention for the single query it keeps (the mean token; few_shot.py:450-469): q [F, C] fp32 (q_proj of
  * token 0, bias included, NOT yet scaled), kv [F*T, 2C] fp32 = [k_proj | v_proj] of all T = HW+1 tokens, out [F, C] fp32 =
  * softmax(scale * q k^T) v per head (C = heads * head_dim, head_dim <= 128, T <= 512); c_proj follows as a cfsar_gemm. */

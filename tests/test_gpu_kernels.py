@@ -411,3 +411,20 @@ def test_vit_attention_pipelined_variant(hip, monkeypatch):
     env = dict(os.environ, CFSAR_ATTN_VARIANT="2")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("Co,H,W_", [(32, 24, 20), (8, 9, 11), (64, 6, 6)])
+def test_stem_conv_direct(hip, Co, H, W_):
+    """cfsar_stem_conv3x3_s2 == relu(conv2d(x, w, stride=2, padding=1) + b) from NCHW fp32 frames to NHWC (fp32 arithmetic)."""
+    import torch.nn.functional as F
+    x = _rand(3, 3, H, W_, seed=41)
+    w = _rand(Co, 3, 3, 3, seed=42, scale=27 ** -0.5)
+    b = _rand(Co, seed=43)
+    ref = torch.relu(F.conv2d(x, w, b, stride=2, padding=1)).permute(0, 2, 3, 1).contiguous()
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    out = torch.empty(3 * Ho * Wo, Co, device="cuda", dtype=torch.float32)
+    hip.stem_conv(x.cuda(), w.cuda(), b.cuda(), out)
+    assert maxdiff(out.cpu().reshape(ref.shape), ref) < 1e-5
+    out16 = torch.empty(3 * Ho * Wo, Co, device="cuda", dtype=torch.bfloat16)
+    hip.stem_conv(x.cuda(), w.cuda(), b.cuda(), out16)
+    assert maxdiff(out16.float().cpu().reshape(ref.shape), ref) < 2e-2
