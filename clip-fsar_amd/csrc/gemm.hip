@@ -747,6 +747,28 @@ constexpr int LDS4 = 8 * EPI_WAVE_BYTES > NSTAGE4 * STAGE4 ? 8 * EPI_WAVE_BYTES 
 
 __device__ __forceinline__ int swz4(int row) { return (row >> 2) & 3; }
 
+// linear tile index -> (row band, column) walking `group` row bands before the next column of tiles (group <= 1: row-major)
+__device__ __forceinline__ void tile_of(int lin, int tiles_m, int tiles_n, int group, int& tm, int& tn) {
+    if (group <= 1) {
+        tm = lin / tiles_n;
+        tn = lin - tm * tiles_n;
+        return;
+    }
+    const int per = group * tiles_n;
+    const int gid = lin / per, first = gid * group;
+    const int gsz = tiles_m - first < group ? tiles_m - first : group;
+    const int rem = lin - gid * per;
+    tm = first + rem % gsz;
+    tn = rem / gsz;
+}
+// short-K GEMMs (QKV, out_proj, c_fc): groups of 8 row bands (+2...+4 % measured); dbg 512 / 1024: 4 / 16; 2048: off
+__device__ __forceinline__ int tile_group(const GemmArgs& p, int ntiles) {
+    if (p.dbg & 2048) return 1;
+    if (p.dbg & 512) return 4;
+    if (p.dbg & 1024) return 16;
+    return ((p.dbg & 256) || (p.K <= 1024 && ntiles >= 512)) ? 8 : 1;
+}
+
 template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
 __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p4(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -928,8 +950,10 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p6(GemmArgs p) {
     // staging: each operand tile = 16 instructions of 16 rows x 64 B; wave w issues instructions {w, w+8} of X and of W
     const char* srcX[2];
     const char* srcW[2];
+    const int tgroup = tile_group(p, p.ntiles);
     auto set_src = [&](int lin) {
-        const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+        int tm, tn;
+        tile_of(lin, p.ntiles / p.tiles_n, p.tiles_n, tgroup, tm, tn);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (i * 8 + wave) * 16 + (lane >> 2);
@@ -953,7 +977,8 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p6(GemmArgs p) {
 
     // pre_issued: slices 0..2 of this tile were already issued (persistent form: during / after the previous epilogue)
     auto do_tile = [&](int lin, int next_lin, bool pre_issued) {
-    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+    int tm, tn;
+    tile_of(lin, p.ntiles / p.tiles_n, p.tiles_n, tgroup, tm, tn);
     const int m0 = tm * BM4, n0 = tn * BN4;
     stamp(lin, 0);
     if (!pre_issued) set_src(lin);
@@ -1731,7 +1756,8 @@ __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
     for (int b = blockIdx.x; b < nwg; b += PERSIST ? (int)gridDim.x : nwg) {
     const int xcd = b & 7;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+    int tm, tn;
+    tile_of(lin, nwg / p.tiles_n, p.tiles_n, tile_group(p, nwg), tm, tn);
     const int m0 = tm * BM4, n0 = tn * BN4;
 
     // staging: an operand tile = 32 pieces of 8 rows x 128 B (1 KiB per wave-instruction); wave w owns pieces
