@@ -9,6 +9,48 @@ namespace {
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
+// O^T tile -> global, 16 bytes per lane.  A lane (q = lane&15, g = lane>>4) holds d = 16dt + 4g + r of its query row; lanes g
+// and g^1 hold the two halves of each 8-wide d chunk.  After one exchange with lane^16 (4 dwords each way) the even-g lane owns
+// the chunks of dt 0,1 and the odd-g lane those of dt 2,3: two dwordx4 stores per lane instead of four dwordx2 (the
+// attention epilogue is store-ISSUE bound: 59 of 273 us at 640 frames were the 8-byte stores).
+__device__ __forceinline__ void pack_o_tile(const f32x4 (&o)[4], float inv, int g, uint4 (&val)[2]) {
+    unsigned pk[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (__bf16)(o[dt][r] * inv);
+        const uint2 u = __builtin_bit_cast(uint2, v);
+        pk[dt][0] = u.x;
+        pk[dt][1] = u.y;
+    }
+    const bool odd = g & 1;
+    // send the two dt chunks the partner will store, keep the two this lane stores
+    unsigned recv[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) recv[i][w] = __shfl_xor(odd ? pk[i][w] : pk[2 + i][w], 16, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int dt = odd ? 2 + i : i;
+        // chunk of 8 d values starting at 16dt + 8(g>>1): low half from the even-g lane, high half from the odd-g lane
+        val[i] = odd ? make_uint4(recv[i][0], recv[i][1], pk[dt][0], pk[dt][1]) : make_uint4(pk[dt][0], pk[dt][1], recv[i][0], recv[i][1]);
+    }
+}
+__device__ __forceinline__ void store_o_packed(const uint4 (&val)[2], bool valid, __bf16* orow, int g) {
+    if (valid) {
+        const bool odd = g & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(orow + (odd ? 2 + i : i) * 16 + (g >> 1) * 8) = val[i];
+    }
+}
+__device__ __forceinline__ void store_o_tile(const f32x4 (&o)[4], float inv, bool valid, __bf16* orow, int g) {
+    uint4 val[2];
+    pack_o_tile(o, inv, g, val);
+    store_o_packed(val, valid, orow, g);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel.  One 256-thread workgroup per (head, frame).
 //   LDS:  K tile  [NP keys][64] bf16, 128-byte rows, 16-byte chunks XOR-swizzled with (row>>1)&7
@@ -25,7 +67,7 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 constexpr int ATT_THREADS = 512;   // 8 waves share one staged (frame, head); 2 workgroups per CU (LDS) = 4 waves/SIMD
 template <int NKB, int NTV>
 __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
-                                                            int ntok, int D, float scale_log2e) {
+                                                            int ntok, int D, float scale_log2e, int dbg) {
     constexpr int NP = NKB * 32;
     constexpr int NT = NKB * 2;                                    // 16-key tiles
     constexpr int VT_STRIDE = ((NP * 2 + 255) / 256) * 256 + 16;   // bytes
@@ -37,21 +79,26 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t ld = (size_t)3 * D;
     const __bf16* base = qkv + (size_t)f * ntok * ld + h * 64;
+    if (dbg & (16 | 32)) {                       // experiment: phase-shift every second first-round workgroup
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin < 512 && ((lin >> ((dbg & 32) ? 0 : 8)) & 1))
+            for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- stage K (swizzled rows) : NP*8 16-byte chunks
     for (int idx = tid; idx < NP * 8; idx += ATT_THREADS) {
         const int r = idx >> 3, pc = idx & 7;
         const int c = pc ^ swz(r);
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < ntok) v = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + D + c * 8);
+        if (r < ntok && !(dbg & 1)) v = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + D + c * 8);
         *reinterpret_cast<uint4*>(sK + r * 128 + pc * 16) = v;
     }
     // ---- stage V^T: thread takes keys (2kp, 2kp+1) x 8 d values, writes 8 packed bf16 pairs
     for (int idx = tid; idx < (NP / 2) * 8; idx += ATT_THREADS) {
         const int kp = idx % (NP / 2), dc = idx / (NP / 2);
         uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-        if (2 * kp < ntok) v0 = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp) * ld + 2 * D + dc * 8);
-        if (2 * kp + 1 < ntok) v1 = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp + 1) * ld + 2 * D + dc * 8);
+        if (2 * kp < ntok && !(dbg & 1)) v0 = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp) * ld + 2 * D + dc * 8);
+        if (2 * kp + 1 < ntok && !(dbg & 1)) v1 = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp + 1) * ld + 2 * D + dc * 8);
         const unsigned a[4] = {v0.x, v0.y, v0.z, v0.w};
         const unsigned b[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
@@ -113,7 +160,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
             if (j < nt_valid) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[j][r], scale_log2e, -mxs));   // raw v_exp_f32
+                    const float pv = (dbg & 2) ? fmaf(s[j][r], scale_log2e, -mxs) : __builtin_amdgcn_exp2f(fmaf(s[j][r], scale_log2e, -mxs));   // raw v_exp_f32
                     s[j][r] = pv;
                     sum += pv;
                 }
@@ -128,7 +175,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
+        for (int kb = 0; kb < ((dbg & 8) ? 1 : NKB); ++kb) {
             bf16x8 pf;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -146,16 +193,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
             if (kb & 1) __builtin_amdgcn_sched_barrier(0);
         }
         // O^T[d][q]: lane owns query q16, d = 16dt + 4g + r
-        if (qvalid) {
-            __bf16* orow = out + ((size_t)f * ntok + qrow) * D + h * 64;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                bf16x4 ov;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = (__bf16)(o[dt][r] * inv);
-                *reinterpret_cast<bf16x4*>(orow + dt * 16 + g * 4) = ov;
-            }
-        }
+        store_o_tile(o, inv, qvalid && !((dbg & 4) && o[0][0] != 123.f), out + ((size_t)f * ntok + qrow) * D + h * 64, g);
     }
 }
 
@@ -183,7 +221,8 @@ __device__ __forceinline__ void att_glds16(const void* src, unsigned lds_addr) {
         : "memory");
 }
 
-template <int NKB, int NTV, int NW, int HG>
+// QT = query tiles per wave: with QT = 2 every K / V^T fragment read from LDS feeds two MFMAs (the kernel is LDS-bound).
+template <int NKB, int NTV, int NW, int HG, int QT>
 __global__ __launch_bounds__(NW * 64) void vit_attn_bf16_pipe_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
                                                                       int ntok, int D, float scale_log2e) {
     constexpr int NTHR = NW * 64;
@@ -241,19 +280,27 @@ __global__ __launch_bounds__(NW * 64) void vit_attn_bf16_pipe_kernel(const __bf1
 
     const int q16 = lane & 15, g = lane >> 4;
     constexpr int nt_valid = NTV > 0 ? NTV : NKB * 2;
-    // this wave's query tile (NW >= number of query tiles); waves beyond the last tile only help with staging
-    const int qt = wave;
-    const bool has_tile = qt * 16 < ntok;
-    int qrow = qt * 16 + q16;
-    const bool qvalid = has_tile && qrow < ntok;
-    if (qrow >= ntok) qrow = ntok - 1;
-    auto load_q = [&](int h, bf16x8 (&qf)[2]) {
+    // this wave's QT query tiles (NW * QT >= number of query tiles); tiles beyond the last one are computed on a clamped
+    // row and not stored
+    int qrow[QT];
+    bool qvalid[QT];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            qf[ks] = *reinterpret_cast<const bf16x8*>(fbase + h * 64 + (size_t)qrow * ld + ks * 32 + g * 8);
+    for (int t = 0; t < QT; ++t) {
+        const int r = (wave * QT + t) * 16 + q16;
+        qvalid[t] = r < ntok;
+        qrow[t] = r < ntok ? r : ntok - 1;
+    }
+    const bool has_tile = wave * QT * 16 < ntok;
+    auto load_q = [&](int h, bf16x8 (&qf)[QT][2]) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                qf[t][ks] = *reinterpret_cast<const bf16x8*>(fbase + h * 64 + (size_t)qrow[t] * ld + ks * 32 + g * 8);
     };
 
-    bf16x8 qcur[2], qnext[2];
+    bf16x8 qcur[QT][2], qnext[QT][2];
+    uint4 opend[QT][2];                                   // packed output of the previous head, not yet stored
     stage_dma(h0, 0);
     load_q(h0, qcur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -268,91 +315,109 @@ __global__ __launch_bounds__(NW * 64) void vit_attn_bf16_pipe_kernel(const __bf1
             stage_dma(h + 1, (hi + 1) & 1);       // other buffer: last read by head hi-1, every wave is past that barrier
             load_q(h + 1, qnext);
         }
+        // The previous head's output goes out HERE, next to the DMA issue: stores and LDS-DMA share the vmcnt counter, so
+        // a store issued at the end of the compute phase would put its full latency into the vmcnt(0) before the barrier.
+        if (hi > 0 && has_tile) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+                store_o_packed(opend[t], qvalid[t], out + ((size_t)f * ntok + qrow[t]) * D + (h - 1) * 64, g);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (has_tile) {
-            f32x4 s[NT];
+            f32x4 s[QT][NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < QT; ++t) s[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (j < nt_valid) {
                     const int kr = j * 16 + q16;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kr * 128 + (((ks * 4 + g) ^ swz(kr)) << 4));
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qcur[ks], acc, 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < QT; ++t)
+                            s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qcur[t][ks], s[t][j], 0, 0, 0);
                     }
                 }
-                s[j] = acc;
                 if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            float mx = -1e30f;
+            float inv[QT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (NTV == 0 || j == nt_valid - 1) {
+            for (int t = 0; t < QT; ++t) {
+                float mx = -1e30f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (j * 16 + g * 4 + r >= ntok) s[j][r] = -1e30f;
+                for (int j = 0; j < NT; ++j) {
+                    if (NTV == 0 || j == nt_valid - 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (j * 16 + g * 4 + r >= ntok) s[t][j][r] = -1e30f;
+                    }
+                    if (j < nt_valid) mx = fmaxf(fmaxf(mx, fmaxf(s[t][j][0], s[t][j][1])), fmaxf(s[t][j][2], s[t][j][3]));
                 }
-                if (j < nt_valid) mx = fmaxf(fmaxf(mx, fmaxf(s[j][0], s[j][1])), fmaxf(s[j][2], s[j][3]));
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mxs = mx * scale_log2e;
-            float sum = 0.f;
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mxs = mx * scale_log2e;
+                float sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (j < nt_valid) {
+                for (int j = 0; j < NT; ++j) {
+                    if (j < nt_valid) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[j][r], scale_log2e, -mxs));
-                        s[j][r] = pv;
-                        sum += pv;
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][j][r], scale_log2e, -mxs));
+                            s[t][j][r] = pv;
+                            sum += pv;
+                        }
                     }
                 }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                inv[t] = __builtin_amdgcn_rcpf(sum);
             }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = __builtin_amdgcn_rcpf(sum);
-            f32x4 o[4];
+            f32x4 o[QT][4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
-                bf16x8 pf;
+                bf16x8 pf[QT];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pf[r] = (__bf16)s[2 * kb][r];
-                    pf[4 + r] = (__bf16)s[2 * kb + 1][r];
-                }
+                for (int t = 0; t < QT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pf[t][r] = (__bf16)s[t][2 * kb][r];
+                        pf[t][4 + r] = (__bf16)s[t][2 * kb + 1][r];
+                    }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const char* vr = sVt + (dt * 16 + q16) * VT_STRIDE + (kb * 32 + g * 4) * 2;
                     const uint2 lo = *reinterpret_cast<const uint2*>(vr);
                     const uint2 hi2 = *reinterpret_cast<const uint2*>(vr + 32);
-                    const uint4 packed = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, packed), pf, o[dt], 0, 0, 0);
+                    const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi2.x, hi2.y));
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t], o[t][dt], 0, 0, 0);
                 }
                 if (kb & 1) __builtin_amdgcn_sched_barrier(0);
             }
-            if (qvalid) {
-                __bf16* orow = out + ((size_t)f * ntok + qrow) * D + h * 64;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    bf16x4 ov;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ov[r] = (__bf16)(o[dt][r] * inv);
-                    *reinterpret_cast<bf16x4*>(orow + dt * 16 + g * 4) = ov;
-                }
-            }
+            for (int t = 0; t < QT; ++t) pack_o_tile(o[t], inv[t], g, opend[t]);   // stored at the start of the next head
         }
         if (hi + 1 < HG) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces (issued a whole head ago) have landed
             __syncthreads();                                     // ... and everybody else's; head h's V^T reads are done
             transpose_v((hi + 1) & 1);
-            qcur[0] = qnext[0];
-            qcur[1] = qnext[1];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                qcur[t][0] = qnext[t][0];
+                qcur[t][1] = qnext[t][1];
+            }
             __syncthreads();
         }
+    }
+    if (has_tile) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+            store_o_packed(opend[t], qvalid[t], out + ((size_t)f * ntok + qrow[t]) * D + (h0 + HG - 1) * 64, g);
     }
 }
 
@@ -420,12 +485,13 @@ int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, h
         attr_set = true;
     }
     const float scale_log2e = 0.125f * 1.4426950408889634f;
+    static const int dbg = [] { const char* e = getenv("CFSAR_ATTN_DEBUG"); return e ? atoi(e) : 0; }();   // dev ablations
     hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB, NTV>), dim3(heads, F), dim3(ATT_THREADS), LDS, s,
-                       static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e);
+                       static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e, dbg);
     return cfsar_check_launch("cfsar_vit_attention(bf16)");
 }
 
-template <int NKB, int NTV, int NW, int HG>
+template <int NKB, int NTV, int NW, int HG, int QT>
 int launch_bf16_pipe(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
     constexpr int NP = NKB * 32;
     constexpr int VT_STRIDE = ((NP * 2 + 255) / 256) * 256 + 16;
@@ -433,13 +499,13 @@ int launch_bf16_pipe(const void* qkv, void* out, int F, int ntok, int D, int hea
     static_assert(LDS <= 160 * 1024, "two K/V^T buffers + the raw V buffer must fit the 160 KiB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attn_bf16_pipe_kernel<NKB, NTV, NW, HG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attn_bf16_pipe_kernel<NKB, NTV, NW, HG, QT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return cfsar_fail("cfsar_vit_attention: set LDS size: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const float scale_log2e = 0.125f * 1.4426950408889634f;
-    hipLaunchKernelGGL((vit_attn_bf16_pipe_kernel<NKB, NTV, NW, HG>), dim3(heads / HG, F), dim3(NW * 64), LDS, s,
+    hipLaunchKernelGGL((vit_attn_bf16_pipe_kernel<NKB, NTV, NW, HG, QT>), dim3(heads / HG, F), dim3(NW * 64), LDS, s,
                        static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e);
     return cfsar_check_launch("cfsar_vit_attention(bf16, pipelined)");
 }
@@ -460,7 +526,8 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
         // at 640 frames): the waits it removes were not the limiter -- the kernel is LDS-bound (fragment reads: 54 KB per
         // 16-query tile; LDS busy 45 % + 37 % of that in bank-conflict cycles, rocprofv3 --pmc); kept for the next round's
         // 32-query tiles, which halve the LDS bytes per query.
-        if (ntok == 197 && heads % 4 == 0 && variant == 2) return launch_bf16_pipe<7, 13, 13, 4>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197 && heads % 4 == 0 && variant == 2) return launch_bf16_pipe<7, 13, 13, 4, 1>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197 && heads % 4 == 0 && variant == 3) return launch_bf16_pipe<7, 13, 7, 4, 2>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 197) return launch_bf16<7, 13>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 257) return launch_bf16<9, 17>(qkv, out, F, ntok, D, heads, s);     // ViT-L/14 @224
         if (ntok <= 224) return launch_bf16<7, 0>(qkv, out, F, ntok, D, heads, s);

@@ -389,9 +389,10 @@ def test_attnpool_attend_single_query(hip, T, heads, hd):
     assert maxdiff(out.cpu(), ref) < 2e-5
 
 
-def test_vit_attention_pipelined_variant(hip, monkeypatch):
-    """The 4-heads-per-workgroup LDS-DMA form of the bf16 attention kernel (CFSAR_ATTN_VARIANT=2, read once per process ->
-    run in a subprocess) == the fp32 softmax(q k^T / 8) v on bf16-rounded inputs."""
+@pytest.mark.parametrize("variant", ["2", "3"])
+def test_vit_attention_pipelined_variant(hip, variant):
+    """The 4-heads-per-workgroup LDS-DMA form of the bf16 attention kernel (CFSAR_ATTN_VARIANT=2: one query tile per wave,
+    3: two query tiles per wave; read once per process -> run in a subprocess) == the fp32 softmax(q k^T / 8) v on bf16-rounded inputs."""
     import subprocess, sys, os, textwrap
     code = textwrap.dedent("""
         import torch, sys
@@ -408,7 +409,7 @@ def test_vit_attention_pipelined_variant(hip, monkeypatch):
         assert d < 2e-2, d
         print("ok", d)
     """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CFSAR_ATTN_VARIANT="2")
+    env = dict(os.environ, CFSAR_ATTN_VARIANT=variant)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
