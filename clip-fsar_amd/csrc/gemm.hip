@@ -377,14 +377,14 @@ __device__ __forceinline__ void epilogue_lds_bf16(f32x16 (*acc)[2], const GemmAr
 }
 
 // ---- K slice with register double-buffered fragments: the ds_read_b128 of sub-step s+1 are in flight while the
-// MFMAs of sub-step s execute.
-template <typename TI>
-__device__ __forceinline__ void mma_slice_db(f32x16 (&acc)[2][2], const char* sX, const char* sW, const int (&offX)[2],
-                                             const int (&offW)[2], const int (&sxX)[2], const int (&sxW)[2], int hi) {
-    uint4 xf[2][2], wf[2][2];
+// MFMAs of sub-step s execute.  MI = 32-row tiles of the wave in M (2: 64x64 wave tile, 1: 32x64).
+template <typename TI, int MI = 2>
+__device__ __forceinline__ void mma_slice_db(f32x16 (&acc)[MI][2], const char* sX, const char* sW, const int (&offX)[MI],
+                                             const int (&offW)[2], const int (&sxX)[MI], const int (&sxW)[2], int hi) {
+    uint4 xf[2][MI], wf[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        xf[0][i] = *reinterpret_cast<const uint4*>(sX + offX[i] + ((hi ^ sxX[i]) << 4));
+        if (i < MI) xf[0][i] = *reinterpret_cast<const uint4*>(sX + offX[i] + ((hi ^ sxX[i]) << 4));
         wf[0][i] = *reinterpret_cast<const uint4*>(sW + offW[i] + ((hi ^ sxW[i]) << 4));
     }
 #pragma unroll
@@ -394,13 +394,13 @@ __device__ __forceinline__ void mma_slice_db(f32x16 (&acc)[2][2], const char* sX
             const int c = 2 * (s + 1) + hi;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                xf[nxt][i] = *reinterpret_cast<const uint4*>(sX + offX[i] + ((c ^ sxX[i]) << 4));
+                if (i < MI) xf[nxt][i] = *reinterpret_cast<const uint4*>(sX + offX[i] + ((c ^ sxX[i]) << 4));
                 wf[nxt][i] = *reinterpret_cast<const uint4*>(sW + offW[i] + ((c ^ sxW[i]) << 4));
             }
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the next sub-step's reads AHEAD of this sub-step's MFMAs
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 if constexpr (sizeof(TI) == 2) {
@@ -569,8 +569,12 @@ __device__ __forceinline__ void glds16_asm(const char* src, unsigned lds_addr) {
 // gemm_kernel_p10): per K slice every lane picks the pixel of its chunk's tap, or a 16-byte block of zeros outside the image
 // (LDS-DMA takes per-lane source addresses).  This is the conv kernel for Cout <= 128 (256x128 tile; p10 for wider ones).
 __device__ const uint4 g_zero_chunk[2] = {};
-template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP, bool CONV = false>
+// NARROW: 256 x 64 tile (8 waves stacked in M, each 32 x 64) for Cout <= 64: the RN50 stem / layer1 convs are bound by the
+// MFMA work wasted on padding columns, not by bytes.
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP, bool CONV = false, bool NARROW = false>
 __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
+    constexpr int BNT = NARROW ? 64 : BN2;
+    constexpr int MIW = NARROW ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BK = ROWB / (int)sizeof(TI);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
-    const int m0 = tm * BM2, n0 = tn * BN2;
+    const int m0 = tm * BM2, n0 = tn * BNT;
 
     // staging: X tile = 32 instructions of 8 rows, W tile = 16; wave w issues X instr {w, w+8, w+16, w+24}, W {w, w+8}
     const char* srcX[4];
@@ -609,7 +613,7 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < (NARROW ? 1 : 2); ++i) {
         const int row = (i * 8 + wave) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ swz(row);
         int gn = n0 + row;
@@ -637,24 +641,26 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
             for (int i = 0; i < 4; ++i) glds16_asm(srcX[i] + koff, base + i * 8192);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16_asm(srcW[i] + koff, base + BM2 * ROWB + i * 8192);
+        for (int i = 0; i < (NARROW ? 1 : 2); ++i) glds16_asm(srcW[i] + koff, base + BM2 * ROWB + i * 8192);
     };
 
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
     const int lr = lane & 31, hi = lane >> 5;
-    int offX[2], offW[2], sxX[2], sxW[2];
+    int offX[MIW], offW[2], sxX[MIW], sxW[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int rx = wm * 64 + i * 32 + lr;
+        const int rx = wm * (32 * MIW) + i * 32 + lr;
         const int rw = wn * 64 + i * 32 + lr;
-        offX[i] = rx * ROWB;
-        sxX[i] = swz(rx);
+        if (i < MIW) {
+            offX[i] = rx * ROWB;
+            sxX[i] = swz(rx);
+        }
         offW[i] = rw * ROWB;
         sxW[i] = swz(rw);
     }
-    f32x16 acc[2][2];
+    f32x16 acc[MIW][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MIW; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -665,24 +671,32 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
     if (nk > 1) issue(1, 1);
     int st = 0;                      // stage holding slice kt
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // slice kt landed, kt+1 may still fly
+        if (kt + 1 < nk) {                                                  // slice kt landed, kt+1 may still fly
+            if constexpr (NARROW) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(p.dbg & 2)) __syncthreads();   // everyone's part of slice kt is in LDS; everyone is done reading slice kt-1
         int st2 = st + 2;
         st2 = st2 >= NSTAGE2 ? st2 - NSTAGE2 : st2;
         if (kt + 2 < nk && !(p.dbg & 1)) issue(st2, kt + 2);
         const char* sX = smem + st * STAGE2;
-        mma_slice_db<TI>(acc, sX, sX + BM2 * ROWB, offX, offW, sxX, sxW, hi);
+        mma_slice_db<TI, MIW>(acc, sX, sX + BM2 * ROWB, offX, offW, sxX, sxW, hi);
         st = st + 1 >= NSTAGE2 ? 0 : st + 1;
     }
     __syncthreads();                 // every wave is done with the ring: reuse it as per-wave transpose buffers
-    const int mb = m0 + wm * 64, nb = n0 + wn * 64;
+    const int mb = m0 + wm * (32 * MIW), nb = n0 + wn * 64;
     f32x16 (*accp)[2] = acc;
     if (p.dbg & 4) {
-        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3];
+        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[MIW - 1][1][3];
         return;
     }
-    const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
+    const bool full = mb + 32 * MIW <= p.M && nb + 64 <= p.N;
+    if constexpr (NARROW) {
+        if (full) epilogue_lds<TO, ACT, HAS_RES, REMAP, true, 1>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+        else epilogue_lds<TO, ACT, HAS_RES, REMAP, false, 1>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+        return;
+    }
     if constexpr (kBf16PackedEpilogue && sizeof(TO) == 2 && !HAS_RES && !REMAP) {
         if (full) epilogue_lds_bf16<ACT, true>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
         else epilogue_lds_bf16<ACT, false>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
@@ -692,17 +706,17 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
     }
 }
 
-template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP, bool CONV = false>
+template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP, bool CONV = false, bool NARROW = false>
 int launch_p3_inst(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP, CONV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP, CONV, NARROW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
         if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles_m = (a.M + BM2 - 1) / BM2;
-    hipLaunchKernelGGL((gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP, CONV>), dim3(tiles_m * a.tiles_n), dim3(NTHREADS2),
+    hipLaunchKernelGGL((gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP, CONV, NARROW>), dim3(tiles_m * a.tiles_n), dim3(NTHREADS2),
                        NSTAGE2 * STAGE2, s, a);
     return cfsar_check_launch("cfsar_gemm(p3)");
 }
@@ -2125,6 +2139,11 @@ extern "C" int cfsar_conv3x3_nhwc(const void* in, const void* W, void* out, cons
     while ((1 << a.conv_lgC) < C) ++a.conv_lgC;
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const int conv_variant = [] { const char* e = getenv("CFSAR_CONV_VARIANT"); return e ? atoi(e) : 0; }();
+    if (out_dtype == CFSAR_BF16 && (conv_variant == 4 || (conv_variant == 0 && Cout <= 64))) {     // 256x64 tile
+        a.tiles_n = (Cout + 63) / 64;
+        return residual ? launch_p3_inst<__bf16, __bf16, CFSAR_ACT_NONE, true, false, true, true>(a, s)
+                        : launch_p3_inst<__bf16, __bf16, CFSAR_ACT_NONE, false, false, true, true>(a, s);
+    }
     if (out_dtype == CFSAR_BF16 && (conv_variant == 3 || (conv_variant == 0 && Cout <= 128))) {   // narrow outputs: 256x128 tile
         a.tiles_n = (Cout + BN2 - 1) / BN2;
         return residual ? launch_p3_inst<__bf16, __bf16, CFSAR_ACT_NONE, true, false, true>(a, s)
