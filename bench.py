@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--episodes-per-step", type=int, default=8)
+    ap.add_argument("--episodes-per-step", type=int, default=16)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic episodes resident in HBM per rank")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))

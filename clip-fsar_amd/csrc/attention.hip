@@ -67,7 +67,8 @@ __device__ __forceinline__ void store_o_tile(const f32x4 (&o)[4], float inv, boo
 constexpr int ATT_THREADS = 512;   // 8 waves share one staged (frame, head); 2 workgroups per CU (LDS) = 4 waves/SIMD
 template <int NKB, int NTV>
 __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
-                                                            int ntok, int D, float scale_log2e, int dbg) {
+                                                            int ntok, int D, float scale_log2e, int dbg,
+                                                            unsigned long long* trace) {
     constexpr int NP = NKB * 32;
     constexpr int NT = NKB * 2;                                    // 16-key tiles
     constexpr int VT_STRIDE = ((NP * 2 + 255) / 256) * 256 + 16;   // bytes
@@ -79,37 +80,62 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t ld = (size_t)3 * D;
     const __bf16* base = qkv + (size_t)f * ntok * ld + h * 64;
+    // dev tool: cycle stamps of (workgroup, wave) -> trace[((f*gridDim.x + h)*8 + wave)*16 + slot]; NULL = off
+    auto stamp = [&](int slot) {
+        if (trace && lane == 0) trace[(((size_t)f * gridDim.x + h) * 8 + wave) * 16 + slot] = __builtin_readcyclecounter();
+    };
+    stamp(0);
     if (dbg & (16 | 32)) {                       // experiment: phase-shift every second first-round workgroup
         const int lin = blockIdx.y * gridDim.x + blockIdx.x;
         if (lin < 512 && ((lin >> ((dbg & 32) ? 0 : 8)) & 1))
             for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
     }
 
-    // ---- stage K (swizzled rows) : NP*8 16-byte chunks
-    for (int idx = tid; idx < NP * 8; idx += ATT_THREADS) {
-        const int r = idx >> 3, pc = idx & 7;
-        const int c = pc ^ swz(r);
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < ntok && !(dbg & 1)) v = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + D + c * 8);
-        *reinterpret_cast<uint4*>(sK + r * 128 + pc * 16) = v;
-    }
-    // ---- stage V^T: thread takes keys (2kp, 2kp+1) x 8 d values, writes 8 packed bf16 pairs
-    for (int idx = tid; idx < (NP / 2) * 8; idx += ATT_THREADS) {
-        const int kp = idx % (NP / 2), dc = idx / (NP / 2);
-        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-        if (2 * kp < ntok && !(dbg & 1)) v0 = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp) * ld + 2 * D + dc * 8);
-        if (2 * kp + 1 < ntok && !(dbg & 1)) v1 = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp + 1) * ld + 2 * D + dc * 8);
-        const unsigned a[4] = {v0.x, v0.y, v0.z, v0.w};
-        const unsigned b[4] = {v1.x, v1.y, v1.z, v1.w};
+    // ---- stage K (swizzled rows, NP*8 16-byte chunks) and V^T: ALL global loads of a thread are issued before the first LDS
+    // write (cycle stamps: the load -> write -> load -> write form spent 11.5 K of a workgroup's 28.8 K cycles here, three to
+    // four dependent memory round trips)
+    constexpr int KIT = (NP * 8 + ATT_THREADS - 1) / ATT_THREADS;
+    constexpr int VIT = ((NP / 2) * 8 + ATT_THREADS - 1) / ATT_THREADS;
+    uint4 kreg[KIT], vreg[VIT][2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned lo = (a[j] & 0xFFFFu) | (b[j] << 16);          // d = dc*8 + 2j
-            const unsigned hi = (a[j] >> 16) | (b[j] & 0xFFFF0000u);      // d = dc*8 + 2j + 1
-            *reinterpret_cast<unsigned*>(sVt + (dc * 8 + 2 * j) * VT_STRIDE + kp * 4) = lo;
-            *reinterpret_cast<unsigned*>(sVt + (dc * 8 + 2 * j + 1) * VT_STRIDE + kp * 4) = hi;
+    for (int it = 0; it < KIT; ++it) {
+        const int idx = tid + it * ATT_THREADS;
+        const int r = idx >> 3, c = (idx & 7) ^ swz(r);
+        kreg[it] = make_uint4(0, 0, 0, 0);
+        if (idx < NP * 8 && r < ntok && !(dbg & 1)) kreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + D + c * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+        const int idx = tid + it * ATT_THREADS;
+        const int kp = idx % (NP / 2), dc = idx / (NP / 2);
+        vreg[it][0] = vreg[it][1] = make_uint4(0, 0, 0, 0);
+        if (idx < (NP / 2) * 8 && !(dbg & 1)) {
+            if (2 * kp < ntok) vreg[it][0] = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp) * ld + 2 * D + dc * 8);
+            if (2 * kp + 1 < ntok) vreg[it][1] = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp + 1) * ld + 2 * D + dc * 8);
         }
     }
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+        const int idx = tid + it * ATT_THREADS;
+        if (idx < NP * 8) *reinterpret_cast<uint4*>(sK + (idx >> 3) * 128 + (idx & 7) * 16) = kreg[it];
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+        const int idx = tid + it * ATT_THREADS;
+        if (idx < (NP / 2) * 8) {
+            const int kp = idx % (NP / 2), dc = idx / (NP / 2);
+            const unsigned a[4] = {vreg[it][0].x, vreg[it][0].y, vreg[it][0].z, vreg[it][0].w};
+            const unsigned b[4] = {vreg[it][1].x, vreg[it][1].y, vreg[it][1].z, vreg[it][1].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<unsigned*>(sVt + (dc * 8 + 2 * j) * VT_STRIDE + kp * 4) = (a[j] & 0xFFFFu) | (b[j] << 16);          // d = dc*8 + 2j
+                *reinterpret_cast<unsigned*>(sVt + (dc * 8 + 2 * j + 1) * VT_STRIDE + kp * 4) = (a[j] >> 16) | (b[j] & 0xFFFF0000u);  // d + 1
+            }
+        }
+    }
+    stamp(1);
     __syncthreads();
+    stamp(2);
 
     const int q16 = lane & 15, g = lane >> 4;
     const int nqt = (ntok + 15) >> 4;
@@ -124,6 +150,8 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
         for (int ks = 0; ks < 2; ++ks)
             qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + ks * 32 + g * 8);
 
+        const bool first = qt == wave;
+        if (first) stamp(3);
         // S^T tiles (tiles that hold only padded keys are skipped; their probabilities are 0)
         f32x4 s[NT];
 #pragma unroll
@@ -140,6 +168,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
             s[j] = acc;
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the K-fragment live ranges (no spills)
         }
+        if (first) stamp(4);
         // mask the padded keys of the last (partial) tile, row max over keys (in-lane, then across the 4 lane groups)
         float mx = -1e30f;
 #pragma unroll
@@ -170,6 +199,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
         sum += __shfl_xor(sum, 32, 64);
         const float inv = __builtin_amdgcn_rcpf(sum);
 
+        if (first) stamp(5);
         // O^T = V^T . P^T
         f32x4 o[4];
 #pragma unroll
@@ -193,8 +223,11 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
             if (kb & 1) __builtin_amdgcn_sched_barrier(0);
         }
         // O^T[d][q]: lane owns query q16, d = 16dt + 4g + r
+        if (first) stamp(6);
         store_o_tile(o, inv, qvalid && !((dbg & 4) && o[0][0] != 123.f), out + ((size_t)f * ntok + qrow) * D + h * 64, g);
+        if (first) stamp(7);
     }
+    stamp(8);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -472,6 +505,8 @@ __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float* __restri
     }
 }
 
+static unsigned long long* g_attn_trace = nullptr;   // dev tool (tools/attn_trace.py)
+
 template <int NKB, int NTV>
 int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
     constexpr int NP = NKB * 32;
@@ -487,7 +522,7 @@ int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, h
     const float scale_log2e = 0.125f * 1.4426950408889634f;
     static const int dbg = [] { const char* e = getenv("CFSAR_ATTN_DEBUG"); return e ? atoi(e) : 0; }();   // dev ablations
     hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB, NTV>), dim3(heads, F), dim3(ATT_THREADS), LDS, s,
-                       static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e, dbg);
+                       static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e, dbg, g_attn_trace);
     return cfsar_check_launch("cfsar_vit_attention(bf16)");
 }
 
@@ -511,6 +546,9 @@ int launch_bf16_pipe(const void* qkv, void* out, int F, int ntok, int D, int hea
 }
 
 }  // namespace
+
+// dev tool (not in the public header): buffer of 16 x u64 per (workgroup, wave) for the bf16 kernel's phase stamps; NULL = off
+extern "C" void cfsar_debug_set_attn_trace(void* buf) { g_attn_trace = static_cast<unsigned long long*>(buf); }
 
 extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads,
                                    cfsar_stream_t stream) {

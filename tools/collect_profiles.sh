@@ -6,7 +6,8 @@ TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-events"
+EPS=${EPS:-16}
+CMD="python bench.py --steps 4 --warmup 2 --episodes-per-step $EPS --no-cpu-baseline --no-kernel-events"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 python tools/trace_summary.py $OUT/trace/t_kernel_trace.csv 0 > $OUT/kernel_summary.txt
 cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
@@ -34,7 +35,7 @@ for k in f:
     out[k] = {"launches": len(f[k]), "fetch_bytes_per_launch": fb / len(f[k]), "write_bytes_per_launch": wb / max(len(w.get(k, [1])), 1)}
     tot_f += fb; tot_w += wb; n += len(f[k])
 out["_all_bf16_gemm"] = {"launches": n, "hbm_bytes_per_launch": (tot_f + tot_w) / max(n, 1),
-                         "note": "FETCH_SIZE*1024*2 (gfx950 correction) + WRITE_SIZE*1024, separate --pmc passes, bench.py --episodes-per-step 8"}
+                         "note": "FETCH_SIZE*1024*2 (gfx950 correction) + WRITE_SIZE*1024, separate --pmc passes, bench.py --episodes-per-step $EPS"}
 json.dump(out, open("$OUT/gemm_traffic.json", "w"), indent=1)
 print(json.dumps(out["_all_bf16_gemm"]))
 PY
