@@ -15,7 +15,29 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libclipfsar_hip.so")
 SOURCES = ["runtime.hip", "gemm.hip", "rowops.hip", "attention.hip", "tail.hip", "conv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Rpass-analysis=kernel-resource-usage"]      # per-kernel VGPR / scratch report -> build/resource_usage.json
+USAGE = os.path.join(HERE, "build", "resource_usage.json")
+
+
+def _parse_usage(text: str) -> dict:
+    """hipcc -Rpass-analysis=kernel-resource-usage remarks -> {mangled kernel name: {vgprs, agprs, scratch, spills, occupancy}}"""
+    import re
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        if cur is None:
+            continue
+        for key, pat in (("vgprs", r"remark:\s+VGPRs: (\d+)"), ("agprs", r"remark:\s+AGPRs: (\d+)"),
+                         ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("spills", r"VGPRs Spill: (\d+)"),
+                         ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, line)
+            if m:
+                cur[key] = int(m.group(1))
+    return out
 
 
 def _stale() -> bool:
@@ -40,12 +62,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
+    usage = {}
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
-        if verbose and out.strip():
-            print(out)
+        usage.update(_parse_usage(out))
+        rest = "\n".join(l for l in out.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l)
+        if verbose and rest.strip():
+            print(rest)
+    import json
+    with open(USAGE, "w") as f:
+        json.dump(usage, f, indent=0, sort_keys=True)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -8,6 +8,7 @@
 namespace {
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+typedef unsigned att_u32x4 __attribute__((ext_vector_type(4)));
 
 // O^T tile -> global, 16 bytes per lane.  A lane (q = lane&15, g = lane>>4) holds d = 16dt + 4g + r of its query row; lanes g
 // and g^1 hold the two halves of each 8-wide d chunk.  After one exchange with lane^16 (4 dwords each way) the even-g lane owns
@@ -96,36 +97,36 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
     // four dependent memory round trips)
     constexpr int KIT = (NP * 8 + ATT_THREADS - 1) / ATT_THREADS;
     constexpr int VIT = ((NP / 2) * 8 + ATT_THREADS - 1) / ATT_THREADS;
-    uint4 kreg[KIT], vreg[VIT][2];
+    att_u32x4 kreg[KIT], vreg0[VIT], vreg1[VIT];     // native vectors: plain SSA values (a HIP uint4 copy is a memcpy -> scratch)
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
         const int idx = tid + it * ATT_THREADS;
         const int r = idx >> 3, c = (idx & 7) ^ swz(r);
-        kreg[it] = make_uint4(0, 0, 0, 0);
-        if (idx < NP * 8 && r < ntok && !(dbg & 1)) kreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + D + c * 8);
+        kreg[it] = att_u32x4{0, 0, 0, 0};
+        if (idx < NP * 8 && r < ntok && !(dbg & 1)) kreg[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)r * ld + D + c * 8);
     }
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {
         const int idx = tid + it * ATT_THREADS;
         const int kp = idx % (NP / 2), dc = idx / (NP / 2);
-        vreg[it][0] = vreg[it][1] = make_uint4(0, 0, 0, 0);
+        vreg0[it] = vreg1[it] = att_u32x4{0, 0, 0, 0};
         if (idx < (NP / 2) * 8 && !(dbg & 1)) {
-            if (2 * kp < ntok) vreg[it][0] = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp) * ld + 2 * D + dc * 8);
-            if (2 * kp + 1 < ntok) vreg[it][1] = *reinterpret_cast<const uint4*>(base + (size_t)(2 * kp + 1) * ld + 2 * D + dc * 8);
+            if (2 * kp < ntok) vreg0[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)(2 * kp) * ld + 2 * D + dc * 8);
+            if (2 * kp + 1 < ntok) vreg1[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)(2 * kp + 1) * ld + 2 * D + dc * 8);
         }
     }
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
         const int idx = tid + it * ATT_THREADS;
-        if (idx < NP * 8) *reinterpret_cast<uint4*>(sK + (idx >> 3) * 128 + (idx & 7) * 16) = kreg[it];
+        if (idx < NP * 8) *reinterpret_cast<att_u32x4*>(sK + (idx >> 3) * 128 + (idx & 7) * 16) = kreg[it];
     }
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {
         const int idx = tid + it * ATT_THREADS;
         if (idx < (NP / 2) * 8) {
             const int kp = idx % (NP / 2), dc = idx / (NP / 2);
-            const unsigned a[4] = {vreg[it][0].x, vreg[it][0].y, vreg[it][0].z, vreg[it][0].w};
-            const unsigned b[4] = {vreg[it][1].x, vreg[it][1].y, vreg[it][1].z, vreg[it][1].w};
+            const unsigned a[4] = {vreg0[it][0], vreg0[it][1], vreg0[it][2], vreg0[it][3]};
+            const unsigned b[4] = {vreg1[it][0], vreg1[it][1], vreg1[it][2], vreg1[it][3]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 *reinterpret_cast<unsigned*>(sVt + (dc * 8 + 2 * j) * VT_STRIDE + kp * 4) = (a[j] & 0xFFFFu) | (b[j] << 16);          // d = dc*8 + 2j
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < ((dbg & 8) ? 1 : NKB); ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             bf16x8 pf;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -58,3 +58,35 @@ def test_no_cpu_fallback_in_product_path():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "clipfsar_oracle" not in src and "ref_harness" not in src, os.path.join(dirpath, f)
+
+
+def test_hot_kernels_use_no_scratch():
+    """Regression guard on the compiler's resource report (clip-fsar_amd/build.py writes build/resource_usage.json): the
+    kernels of the ViT / RN50 hot path keep their working set in registers.  A run-time loop bound or a struct copy that
+    sends an accumulator array to scratch is a 20-30 % slowdown that no parity test notices."""
+    import json
+    import __graft_entry__ as ge
+    ge.build()
+    from clip_fsar_amd import build as b
+    if not os.path.exists(b.USAGE):
+        b.build(force=True, verbose=False)
+    usage = json.load(open(b.USAGE))
+    assert len(usage) > 40, len(usage)
+    hot = {  # substring of the mangled name -> max scratch bytes per lane
+        "vit_attn_bf16_kernelILi7ELi13E": 0, "vit_attn_bf16_kernelILi9ELi17E": 0, "layernorm_kernel": 0,
+        "gemm_kernel_p10IDF16bLi0ELb0ELb0ELb0E": 0,        # QKV
+        "gemm_kernel_p10IfLi0ELb1ELb0ELb0E": 0,            # out_proj / c_proj (fp32 residual stream)
+        "gemm_kernel_p3IDF16bDF16bLi0ELb0ELb0ELb1ELb0E": 0, "gemm_kernel_p3IDF16bDF16bLi0ELb0ELb0ELb1ELb1E": 0,   # RN50 implicit convs
+        "stem_conv1_kernel": 0,
+        "cos_otam_kernel": 512,                            # the per-thread OTAM DP rows live in scratch by design (serial DP)
+    }
+    for key, limit in hot.items():
+        names = [n for n in usage if key in n]
+        assert names, "kernel %s not found in the resource report" % key
+        for n in names:
+            assert usage[n].get("scratch", 0) <= limit, (n, usage[n])
+    # the c_fc kernel (p6 + QuickGELU) and the main loops of the one-wave-per-SIMD family may spill a few epilogue scalars;
+    # bound it so that a main-loop spill (hundreds of bytes) is caught
+    for n, u in usage.items():
+        if "gemm_kernel_p6" in n or "gemm_kernel_p10" in n:
+            assert u.get("scratch", 0) <= 256, (n, u)

@@ -11,9 +11,10 @@ cfgs = [tuple(int(x) for x in c.split(":")) for c in sys.argv[2:]]
 L = hip.lib()
 L.cfsar_debug_set_gemm_variant.argtypes = [ctypes.c_int, ctypes.c_int]
 L.cfsar_debug_set_gemm_variant.restype = None
-M = 80 * 197 * B
+D = int(os.environ.get("AB_D", "768"))                      # 1024 + AB_TOK=257 AB_FPE=160: ViT-L/14, 16 frames
+M = int(os.environ.get("AB_FPE", "80")) * int(os.environ.get("AB_TOK", "197")) * B
 dev = "cuda"
-shapes = [("qkv", 2304, 768), ("out", 768, 768), ("fc", 3072, 768), ("proj", 768, 3072)]
+shapes = [("qkv", 3 * D, D), ("out", D, D), ("fc", 4 * D, D), ("proj", D, 4 * D)]
 if os.environ.get("AB_SHAPES"):
     shapes = [s for s in shapes if s[0] in os.environ["AB_SHAPES"].split(",")]
 ROUNDS, ITERS = 7, 8
