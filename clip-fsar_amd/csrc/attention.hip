@@ -65,17 +65,24 @@ __device__ __forceinline__ void store_o_tile(const f32x4 (&o)[4], float inv, boo
 // ------------------------------------------------------------------------------------------------------------
 // NKB = number of 32-key blocks (7 -> up to 224 keys, 9 -> up to 288 keys); NTV = number of 16-key tiles that hold at
 // least one real key when known at compile time (13 for 197 tokens, 17 for 257), 0 = generic (all tiles, all masked).
-constexpr int ATT_THREADS = 512;   // 8 waves share one staged (frame, head); 2 workgroups per CU (LDS) = 4 waves/SIMD
-template <int NKB, int NTV>
-__global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
+// ATT_THREADS = 512: 8 waves share one staged (frame, head); 2 workgroups per CU (LDS 61 KB each) = 4 waves/SIMD.
+// COMPACT (needs NTV > 0): K holds only the NTV*16 rows that are read and V^T rows are 16*NTV + 8 keys long -> 54 336 B for
+// 197 tokens, THREE workgroups per CU; used with 256-thread workgroups (4 waves, 3-4 query tiles each).
+template <int NTV>
+constexpr int att_vt_stride(int NP, bool compact) { return compact ? (NTV * 16 + 8) * 2 : ((NP * 2 + 255) / 256) * 256 + 16; }
+template <int NKB, int NTV, int ATT_THREADS = 512, bool COMPACT = false>
+__global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_attn_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
                                                             int ntok, int D, float scale_log2e, int dbg,
                                                             unsigned long long* trace) {
     constexpr int NP = NKB * 32;
     constexpr int NT = NKB * 2;                                    // 16-key tiles
-    constexpr int VT_STRIDE = ((NP * 2 + 255) / 256) * 256 + 16;   // bytes
+    constexpr int VT_STRIDE = att_vt_stride<NTV>(NP, COMPACT);     // bytes
+    constexpr int KROWS = COMPACT ? NTV * 16 : NP;                 // K rows kept in LDS
+    constexpr int VKEYS = COMPACT ? VT_STRIDE / 2 : NP;            // keys per V^T row that are written (pairs: VKEYS / 2)
+    static_assert(!COMPACT || NTV > 0, "the compact LDS image needs the number of valid key tiles at compile time");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
-    char* sVt = smem + NP * 128;
+    char* sVt = smem + KROWS * 128;
 
     const int h = blockIdx.x, f = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,22 +102,22 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
     // ---- stage K (swizzled rows, NP*8 16-byte chunks) and V^T: ALL global loads of a thread are issued before the first LDS
     // write (cycle stamps: the load -> write -> load -> write form spent 11.5 K of a workgroup's 28.8 K cycles here, three to
     // four dependent memory round trips)
-    constexpr int KIT = (NP * 8 + ATT_THREADS - 1) / ATT_THREADS;
-    constexpr int VIT = ((NP / 2) * 8 + ATT_THREADS - 1) / ATT_THREADS;
+    constexpr int KIT = (KROWS * 8 + ATT_THREADS - 1) / ATT_THREADS;
+    constexpr int VIT = ((VKEYS / 2) * 8 + ATT_THREADS - 1) / ATT_THREADS;
     att_u32x4 kreg[KIT], vreg0[VIT], vreg1[VIT];     // native vectors: plain SSA values (a HIP uint4 copy is a memcpy -> scratch)
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
         const int idx = tid + it * ATT_THREADS;
         const int r = idx >> 3, c = (idx & 7) ^ swz(r);
         kreg[it] = att_u32x4{0, 0, 0, 0};
-        if (idx < NP * 8 && r < ntok && !(dbg & 1)) kreg[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)r * ld + D + c * 8);
+        if (idx < KROWS * 8 && r < ntok && !(dbg & 1)) kreg[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)r * ld + D + c * 8);
     }
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {
         const int idx = tid + it * ATT_THREADS;
-        const int kp = idx % (NP / 2), dc = idx / (NP / 2);
+        const int kp = idx % (VKEYS / 2), dc = idx / (VKEYS / 2);
         vreg0[it] = vreg1[it] = att_u32x4{0, 0, 0, 0};
-        if (idx < (NP / 2) * 8 && !(dbg & 1)) {
+        if (idx < (VKEYS / 2) * 8 && !(dbg & 1)) {
             if (2 * kp < ntok) vreg0[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)(2 * kp) * ld + 2 * D + dc * 8);
             if (2 * kp + 1 < ntok) vreg1[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)(2 * kp + 1) * ld + 2 * D + dc * 8);
         }
@@ -118,13 +125,13 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void vit_attn_bf16_kernel(const __b
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
         const int idx = tid + it * ATT_THREADS;
-        if (idx < NP * 8) *reinterpret_cast<att_u32x4*>(sK + (idx >> 3) * 128 + (idx & 7) * 16) = kreg[it];
+        if (idx < KROWS * 8) *reinterpret_cast<att_u32x4*>(sK + (idx >> 3) * 128 + (idx & 7) * 16) = kreg[it];
     }
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {
         const int idx = tid + it * ATT_THREADS;
-        if (idx < (NP / 2) * 8) {
-            const int kp = idx % (NP / 2), dc = idx / (NP / 2);
+        if (idx < (VKEYS / 2) * 8) {
+            const int kp = idx % (VKEYS / 2), dc = idx / (VKEYS / 2);
             const unsigned a[4] = {vreg0[it][0], vreg0[it][1], vreg0[it][2], vreg0[it][3]};
             const unsigned b[4] = {vreg1[it][0], vreg1[it][1], vreg1[it][2], vreg1[it][3]};
 #pragma unroll
@@ -508,21 +515,21 @@ __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float* __restri
 
 static unsigned long long* g_attn_trace = nullptr;   // dev tool (tools/attn_trace.py)
 
-template <int NKB, int NTV>
+template <int NKB, int NTV, int NTHR = 512, bool COMPACT = false>
 int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
     constexpr int NP = NKB * 32;
-    constexpr int VT_STRIDE = ((NP * 2 + 255) / 256) * 256 + 16;
-    constexpr int LDS = NP * 128 + 64 * VT_STRIDE;
+    constexpr int VT_STRIDE = att_vt_stride<NTV>(NP, COMPACT);
+    constexpr int LDS = (COMPACT ? NTV * 16 : NP) * 128 + 64 * VT_STRIDE + (COMPACT ? 64 : 0);   // + tail pad: the last V^T row is over-read
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<NKB, NTV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<NKB, NTV, NTHR, COMPACT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return cfsar_fail("cfsar_vit_attention: set LDS size: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const float scale_log2e = 0.125f * 1.4426950408889634f;
     static const int dbg = [] { const char* e = getenv("CFSAR_ATTN_DEBUG"); return e ? atoi(e) : 0; }();   // dev ablations
-    hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB, NTV>), dim3(heads, F), dim3(ATT_THREADS), LDS, s,
+    hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB, NTV, NTHR, COMPACT>), dim3(heads, F), dim3(NTHR), LDS, s,
                        static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e, dbg, g_attn_trace);
     return cfsar_check_launch("cfsar_vit_attention(bf16)");
 }
@@ -565,6 +572,7 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
         // at 640 frames): the waits it removes were not the limiter -- the kernel is LDS-bound (fragment reads: 54 KB per
         // 16-query tile; LDS busy 45 % + 37 % of that in bank-conflict cycles, rocprofv3 --pmc); kept for the next round's
         // 32-query tiles, which halve the LDS bytes per query.
+        if (ntok == 197 && variant == 4) return launch_bf16<7, 13, 256, true>(qkv, out, F, ntok, D, heads, s);   // 3 WGs per CU
         if (ntok == 197 && heads % 4 == 0 && variant == 2) return launch_bf16_pipe<7, 13, 13, 4, 1>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 197 && heads % 4 == 0 && variant == 3) return launch_bf16_pipe<7, 13, 7, 4, 2>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 197) return launch_bf16<7, 13>(qkv, out, F, ntok, D, heads, s);
