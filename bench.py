@@ -257,15 +257,16 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                                "traffic": measured_traffic(B),
-                               "kernel": "gemm_kernel<bf16> (QKV / out_proj / c_fc / c_proj / patch-embed)",
+                               "kernel": "gemm_kernel_p10 / _p6 / _p3 <bf16> (QKV, out_proj, c_proj / c_fc / patch-embed)",
                                "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                                "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3)}
         else:
             out["roofline"] = None
         out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)          # the ONE JSON line, after every library's own teardown chatter
 
 
 if __name__ == "__main__":
