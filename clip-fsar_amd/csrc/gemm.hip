@@ -1991,6 +1991,192 @@ int launch_p10(const GemmArgs& a0, hipStream_t s) {
     return r ? launch_p10_inst<TO, CFSAR_ACT_NONE, true, PERSIST>(a, s) : launch_p10_inst<TO, CFSAR_ACT_NONE, false, PERSIST>(a, s);
 }
 
+// ============================================================================================================
+// v9 ("p12"): p10's operand path (128-byte K tiles, whole-line requests, register staging, two 64 KiB LDS stages, one barrier
+// per K tile) with TWO waves per SIMD: 512 threads, 8 waves as 2(M) x 4(N), wave tile 128 x 64 (128 accumulators).  For the
+// QuickGELU epilogue (c_fc) the second wave per SIMD overlaps the 2-transcendentals-per-element VALU work and the stores of
+// one wave with those of the other, which is what p10 lacks; the main loop keeps p10's request efficiency, which p6 lacks.
+// Per wave and K tile: 32 MFMAs, 24 fragment reads, 4 + 4 global loads, 4 + 4 LDS writes.
+// ============================================================================================================
+template <typename TO, int ACT, bool HAS_RES>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_p12(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    int tm, tn;
+    tile_of(lin, nwg / p.tiles_n, p.tiles_n, tile_group(p, nwg), tm, tn);
+    const int m0 = tm * BM4, n0 = tn * BN4;
+
+    // staging: an operand tile = 32 pieces of 8 rows x 128 B; wave w owns pieces {w, w+8, w+16, w+24}
+    unsigned offX[4], offWg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);
+        int gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        int gn = n0 + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        offX[i] = (unsigned)gm * (unsigned)p.lda * 2u + chunk * 16;
+        offWg[i] = (unsigned)gn * (unsigned)p.ldw * 2u + chunk * 16;
+    }
+    const int wr_off = wave * 1024 + lane * 16;          // + piece i * 8192 (+ BM4*ROWB10 for W) inside a stage
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lr = lane & 31, hi = lane >> 5;
+    int rdX[4], rdW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rx = wm * 128 + i * 32 + lr;
+        rdX[i] = rx * ROWB10 + ((hi ^ swz(rx)) << 4);                      // sub-step ss: ^ (ss << 5)
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rw = wn * 64 + i * 32 + lr;
+        rdW[i] = BM4 * ROWB10 + rw * ROWB10 + ((hi ^ swz(rw)) << 4);
+    }
+    f32x16 acc[4][2];                                                      // [mi][ni]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.K / 64;
+    u32x4 GX[4], GW[4];
+    uint4 xfA[4], wfA[2], xfB[4], wfB[2];
+    auto gloadX = [&](int kt, auto J) {
+        GX[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.A + (size_t)kt * ROWB10 + offX[decltype(J)::value]);
+    };
+    auto gloadW = [&](int kt, auto J) {
+        GW[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.W + (size_t)kt * ROWB10 + offWg[decltype(J)::value]);
+    };
+    auto swriteX = [&](int stage, auto J) {
+        *reinterpret_cast<u32x4*>(smem + stage * STAGE10 + wr_off + decltype(J)::value * 8192) = GX[decltype(J)::value];
+    };
+    auto swriteW = [&](int stage, auto J) {
+        *reinterpret_cast<u32x4*>(smem + stage * STAGE10 + BM4 * ROWB10 + wr_off + decltype(J)::value * 8192) = GW[decltype(J)::value];
+    };
+    // read order = order of first use by the MFMA sequence (ni-major): x0 w0 x1 x2 x3 w1
+    auto load_one = [&](int stage, int ss, auto J, uint4 (&xf)[4], uint4 (&wf)[2]) {
+        constexpr int j = decltype(J)::value;
+        const char* base = smem + stage * STAGE10;
+        const int x2 = ss << 5;
+        constexpr int isx[6] = {1, 0, 1, 1, 1, 0};
+        constexpr int idx[6] = {0, 0, 1, 2, 3, 1};
+        if constexpr (isx[j] != 0) xf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdX[idx[j]] ^ x2));
+        else wf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdW[idx[j]] ^ x2));
+    };
+    auto mfma_one = [&](auto J, uint4 (&xf)[4], uint4 (&wf)[2]) {
+        constexpr int j = decltype(J)::value;
+        constexpr int ni = j >> 2, mi = j & 3;
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]),
+                                                              acc[mi][ni], 0, 0, 0);
+    };
+    // one 128-byte K tile = 4 sub-steps of 8 MFMAs; after MFMA j: a fragment read (j < 6) and, for j >= 4, one memory filler
+    auto tile = [&](int kt, int cur, int nxt, auto LOAD, auto WRITE) {
+        constexpr bool load = decltype(LOAD)::value, write = decltype(WRITE)::value;
+        static_for<8>([&](auto J) {                                     // sub-step 0: reads(ss 1), ds_write X(kt+1)
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfA, wfA);
+            if constexpr (j < 6) load_one(cur, 1, J, xfB, wfB);
+            if constexpr (j >= 4 && write) swriteX(nxt, std::integral_constant<int, j - 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<8>([&](auto J) {                                     // sub-step 1: reads(ss 2), global_load X(kt+2)
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfB, wfB);
+            if constexpr (j < 6) load_one(cur, 2, J, xfA, wfA);
+            if constexpr (j >= 4 && load) gloadX(kt + 2, std::integral_constant<int, j - 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<8>([&](auto J) {                                     // sub-step 2: reads(ss 3), ds_write W(kt+1)
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfA, wfA);
+            if constexpr (j < 6) load_one(cur, 3, J, xfB, wfB);
+            if constexpr (j >= 4 && write) swriteW(nxt, std::integral_constant<int, j - 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<8>([&](auto J) {                                     // sub-step 3: global_load W(kt+2) | barrier | reads(kt+1, ss 0)
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfB, wfB);
+            if constexpr (j < 2) {
+                if constexpr (load) {
+                    gloadW(kt + 2, std::integral_constant<int, 2 * j>{});
+                    gloadW(kt + 2, std::integral_constant<int, 2 * j + 1>{});
+                }
+            } else if constexpr (write) load_one(nxt, 0, std::integral_constant<int, j - 2>{}, xfA, wfA);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j == 1 && write) {
+                __syncthreads();                                        // hipcc adds lgkmcnt(0): this wave's ds_writes
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    static_for<4>([&](auto J) { gloadX(0, J); });
+    static_for<4>([&](auto J) { gloadW(0, J); });
+    static_for<4>([&](auto J) { swriteX(0, J); });
+    static_for<4>([&](auto J) { swriteW(0, J); });
+    if (nk > 1) {
+        static_for<4>([&](auto J) { gloadX(1, J); });
+        static_for<4>([&](auto J) { gloadW(1, J); });
+    }
+    __syncthreads();
+    static_for<6>([&](auto J) { load_one(0, 0, J, xfA, wfA); });
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) tile(kt, kt & 1, (kt + 1) & 1, T_{}, T_{});
+    if (nk > 1) {
+        tile(kt, kt & 1, (kt + 1) & 1, F_{}, T_{});
+        ++kt;
+    }
+    tile(kt, kt & 1, (kt + 1) & 1, F_{}, F_{});
+    __syncthreads();
+    if (p.dbg & 4) {
+        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[3][1][2] + acc[2][0][1];
+        return;
+    }
+    char* wbuf = smem + wave * EPI_WAVE_BYTES;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 64;
+        const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
+        if (full) epilogue_lds<TO, ACT, HAS_RES, false, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
+        else epilogue_lds<TO, ACT, HAS_RES, false, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
+    }
+}
+
+template <typename TO, int ACT, bool HAS_RES>
+int launch_p12_inst(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p12<TO, ACT, HAS_RES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel_p12<TO, ACT, HAS_RES>), dim3(a.ntiles), dim3(512), LDS4, s, a);
+    return cfsar_check_launch("cfsar_gemm(p12)");
+}
+
+template <typename TO>
+int launch_p12(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_n = (a.N + BN4 - 1) / BN4;
+    a.ntiles = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
+    const bool r = a.res != nullptr;
+    if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF || a.K % 64 != 0) return -2;
+    if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32)) return -2;   // 32-bit offsets
+    if (a.act == CFSAR_ACT_QUICKGELU) return r ? -2 : launch_p12_inst<TO, CFSAR_ACT_QUICKGELU, false>(a, s);
+    return r ? launch_p12_inst<TO, CFSAR_ACT_NONE, true>(a, s) : launch_p12_inst<TO, CFSAR_ACT_NONE, false>(a, s);
+}
+
 // dev tool (not in the public header): device buffer of 8 x u64 per 256x256 tile for the p6 phase timestamps; NULL = off
 extern "C" void cfsar_debug_set_gemm_trace(void* buf) { g_trace = static_cast<unsigned long long*>(buf); }
 // dev tool (not in the public header): override CFSAR_GEMM_VARIANT / CFSAR_GEMM_DEBUG at run time; -1 = use the environment
@@ -2049,6 +2235,14 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     // p3: its 256x128 tile wastes less of a narrow N, two waves per SIMD overlap the HBM-bound epilogue, and the
     // 16-byte-per-lane bf16 epilogue fits its register budget (tools/rn_gemm_ab.py).
     const bool p10_shape = out_dtype == CFSAR_F32 || (N >= 512 && K >= 512 && !residual);
+    // 12 = p12: p10's operand path with two waves per SIMD.  Measured fastest on all four ViT GEMMs (M = 252 160, same box,
+    // interleaved: QKV 888 vs 960 us (p10), out_proj 457 vs 476, c_fc 1 288 vs 1 409 (p6), c_proj 1 143 vs 1 178): the auto
+    // choice wherever p10 or p6 were chosen before.
+    // Also the RN50 1x1 convs with N >= 256 (tools/rn_gemm_ab.py); narrower outputs stay on p3's 256x128 tile.
+    if (in_dtype == CFSAR_BF16 && (forced == 12 || (forced == 0 && tiles4 >= 240 && N >= 256))) {
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p12<__bf16>(a, s) : launch_p12<float>(a, s);
+        if (rc != -2) return rc;
+    }
     if (in_dtype == CFSAR_BF16 && (forced == 10 || (forced == 0 && tiles4 >= 512 && act == CFSAR_ACT_NONE && p10_shape))) {
         const int rc = out_dtype == CFSAR_BF16 ? launch_p10<__bf16, false>(a, s) : launch_p10<float, false>(a, s);
         if (rc != -2) return rc;
@@ -2082,7 +2276,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
         const int rc = out_dtype == CFSAR_BF16 ? launch_p5<__bf16>(a, s) : launch_p5<float>(a, s);
         if (rc != -2) return rc;
     }
-    const bool use_p3 = forced == 2 || forced == 3 || forced == 4 || forced == 6 || forced == 8 || forced == 9 || forced == 10 || forced == 11 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
+    const bool use_p3 = forced == 2 || forced == 3 || forced == 4 || forced == 6 || forced == 8 || forced == 9 || forced == 10 || forced == 11 || forced == 12 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
     if (use_p3) {
         int rc;
         if (in_dtype == CFSAR_BF16)

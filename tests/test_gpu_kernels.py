@@ -312,7 +312,7 @@ def test_avgpool_and_attnpool_tokens(hip, dtype):
     assert maxdiff(tok.float().cpu(), ref_tok) < (2e-6 if dtype == "f32" else 3e-2)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12])
 def test_gemm_every_kernel_variant(hip, variant):
     """Each bf16 GEMM kernel kept in gemm.hip (v1 / p3 / p4 / p5 / p6 / p6-persistent / p8 / p9 / p10; the auto policy only
     picks p10, p6, p3 and v1) against the fp32 product of the bf16-rounded operands, on ragged M and N edges, through the
