@@ -257,7 +257,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                                "traffic": measured_traffic(B),
-                               "kernel": "gemm_kernel_p10 / _p6 / _p3 <bf16> (QKV, out_proj, c_proj / c_fc / patch-embed)",
+                               "kernel": "gemm_kernel_p12<bf16> (QKV, out_proj, c_fc, c_proj) + gemm_kernel_p3<bf16> (patch embed)",
                                "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                                "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3)}
         else:
