@@ -44,7 +44,7 @@ struct GemmArgs {
     int row_group, row_gap, row_off, res_mod, res_off;
     int tiles_n;
     int ntiles;    // persistent p6: total number of 256x256 tiles
-    int stagger;   // p4: first-round phase offset in units of s_sleep(127) (~4 us)
+    int stagger;   // unused (first-round phase offset experiment of the removed p4 kernel)
     unsigned long long* trace;   // dev tool: per-tile phase timestamps (s_memtime), 8 slots per tile; normally NULL
     int dbg;   // ablation bits (env CFSAR_GEMM_DEBUG): 1 = no in-loop DMA, 2 = no in-loop barrier, 4 = no epilogue
     int conv_H, conv_W, conv_lgC;   // implicit 3x3 / pad 1 / stride 1 conv (p10 CONV): A = NHWC input [F,H,W,C], C = 1 << conv_lgC
@@ -243,7 +243,7 @@ __device__ __forceinline__ void epilogue_lds_x8(f32x16 (*acc)[2], const GemmArgs
     }
 }
 
-// X8 = false: the one-wave-per-SIMD kernels (p8-p10) hold 256 accumulator registers through the epilogue and spill with
+// X8 = false: the one-wave-per-SIMD kernel (p10) holds 256 accumulator registers through the epilogue and spills with
 // the wider form
 template <typename TO, int ACT, bool HAS_RES, bool REMAP, bool FULL, int NMI = 2, bool X8 = true>
 __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p, int mbase, int nbase, int lane,
@@ -747,10 +747,13 @@ int launch_p3(const GemmArgs& a0, hipStream_t s) {
 }
 
 // ============================================================================================================
-// v3 ("p4"): 256(M) x 256(N) tile, 512 threads (8 waves as 2(M) x 4(N), each wave 128 x 64 = 4x2 MFMA 32x32 tiles,
-// 128 accumulator VGPRs).  K in 64-byte slices (32 bf16) through a FOUR-stage LDS ring (4 x 32 KiB) filled by asm
-// LDS-DMA running three slices ahead (counted vmcnt).  Versus p3 this moves 1/3 fewer bytes global->LDS and 1/4 fewer
-// bytes LDS->VGPR per MFMA.  64-byte LDS rows: chunk ^= (row>>2)&3 keeps ds_read_b128 conflict-free.
+// v3 ("p6"): 256(M) x 256(N) tile, 512 threads (8 waves as 2(M) x 4(N), each wave 128 x 64 = 4x2 MFMA 32x32 tiles,
+// 128 accumulator VGPRs), the two M halves running one barrier apart (one group's MFMA phase overlaps the other's
+// fragment reads / LDS-DMA issue).  K in 64-byte slices (32 bf16) through a FOUR-stage LDS ring (4 x 32 KiB) filled by
+// asm LDS-DMA running three slices ahead (counted vmcnt).  64-byte LDS rows: chunk ^= (row>>2)&3 keeps ds_read_b128
+// conflict-free.  The round's default until p10 / p12; its siblings p4 (no ping-pong), p5 (256x128, two workgroups per CU),
+// p8 (one wave per SIMD + LDS-DMA) and p9 (p10 with 64-byte slices) measured within 3 % of it and were removed
+// (numbers: profiles/r01_gemm_ablation.md).
 // ============================================================================================================
 constexpr int BM4 = 256;
 constexpr int BN4 = 256;
@@ -781,152 +784,6 @@ __device__ __forceinline__ int tile_group(const GemmArgs& p, int ntiles) {
     if (p.dbg & 512) return 4;
     if (p.dbg & 1024) return 16;
     return ((p.dbg & 256) || (p.K <= 1024 && ntiles >= 512)) ? 8 : 1;
-}
-
-template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
-__global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p4(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BK = ROWB4 / (int)sizeof(TI);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
-    const int m0 = tm * BM4, n0 = tn * BN4;
-
-    // staging: each operand tile = 16 instructions of 16 rows x 64 B; wave w issues instructions {w, w+8} of X and of W
-    const char* srcX[2];
-    const char* srcW[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (i * 8 + wave) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ swz4(row);
-        int gm = ((p.dbg & 8) ? 0 : m0) + row;
-        gm = gm < p.M ? gm : p.M - 1;
-        int gn = ((p.dbg & 8) ? 0 : n0) + row;
-        gn = gn < p.N ? gn : p.N - 1;
-        srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
-        srcW[i] = p.W + ((size_t)gn * p.ldw) * sizeof(TI) + chunk * 16;
-    }
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
-    auto issue = [&](int stage, int kt) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)stage * (unsigned)STAGE4);
-        const size_t koff = (size_t)kt * ROWB4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) glds16_asm(srcX[i] + koff, base + i * 8192);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) glds16_asm(srcW[i] + koff, base + BM4 * ROWB4 + i * 8192);
-    };
-
-    const int wm = wave >> 2, wn = wave & 3;
-    const int lr = lane & 31, hi = lane >> 5;
-    int offX[4], offW[2], sxX[4], sxW[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rx = wm * 128 + i * 32 + lr;
-        offX[i] = rx * ROWB4;
-        sxX[i] = swz4(rx);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rw = wn * 64 + i * 32 + lr;
-        offW[i] = BM4 * ROWB4 + rw * ROWB4;
-        sxW[i] = swz4(rw);
-    }
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int nk = p.K / BK;
-    // Phase stagger: the workgroups of the first round start together and would stay in lockstep for the whole launch
-    // (same work per tile), so every CU would hit its store-only epilogue -- an HBM write burst with idle MFMA pipes --
-    // at the same moment.  Half of the first-round workgroups therefore start `stagger` x ~4 us late; later rounds
-    // inherit the offset because a workgroup is dispatched when its predecessor on that CU retires.
-    if (p.stagger > 0 && b < 256 && ((b >> 3) & 1))
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    // Fragments of slice kt+1 are read from LDS (into the other register set) while the MFMAs of slice kt execute, so
-    // no MFMA ever waits for LDS latency behind a barrier.  Invariant at the barrier of step kt: slices <= kt+1 have
-    // landed for every wave (each wave leaves only its share of slice kt+2 in flight: vmcnt(4)); slice kt+3 is then
-    // issued into the stage of slice kt-1, whose fragments were consumed one step ago.
-    auto load_frags = [&](int kt, uint4 (&xf)[2][4], uint4 (&wf)[2][2]) {
-        const char* base = smem + (kt & 3) * STAGE4;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                xf[s2][i] = *reinterpret_cast<const uint4*>(base + offX[i] + (((2 * s2 + hi) ^ sxX[i]) << 4));
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                wf[s2][i] = *reinterpret_cast<const uint4*>(base + offW[i] + (((2 * s2 + hi) ^ sxW[i]) << 4));
-        }
-    };
-    auto mma = [&](uint4 (&xf)[2][4], uint4 (&wf)[2][2]) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    if constexpr (sizeof(TI) == 2) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s2][ni]),
-                                                                              __builtin_bit_cast(bf16x8, xf[s2][mi]),
-                                                                              acc[mi][ni], 0, 0, 0);
-                    } else {
-                        const f32x4 a = __builtin_bit_cast(f32x4, wf[s2][ni]);
-                        const f32x4 bb = __builtin_bit_cast(f32x4, xf[s2][mi]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bb[j], acc[mi][ni], 0, 0, 0);
-                    }
-                }
-    };
-    auto step = [&](int kt, uint4 (&xc)[2][4], uint4 (&wc)[2][2], uint4 (&xn)[2][4], uint4 (&wn_)[2][2]) {
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(p.dbg & 2)) __syncthreads();
-        if (kt + 3 < nk && !(p.dbg & 1)) issue((kt + 3) & 3, kt + 3);
-        if (kt + 1 < nk && !(p.dbg & 16)) load_frags(kt + 1, xn, wn_);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(p.dbg & 32)) mma(xc, wc);
-    };
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 2) issue(2, 2);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    uint4 xfA[2][4], wfA[2][2], xfB[2][4], wfB[2][2];
-    load_frags(0, xfA, wfA);
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, xfA, wfA, xfB, wfB);
-        if (kt + 1 < nk) step(kt + 1, xfB, wfB, xfA, wfA);
-    }
-    __syncthreads();
-    if (p.dbg & 4) {
-        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[3][1][2] + acc[2][0][1];
-        return;
-    }
-    char* wbuf = smem + wave * EPI_WAVE_BYTES;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 64;
-        const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
-        if constexpr (kBf16PackedEpilogue && sizeof(TO) == 2 && !HAS_RES && !REMAP) {
-            if (full) epilogue_lds_bf16<ACT, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
-            else epilogue_lds_bf16<ACT, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
-        } else {
-            if (full) epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
-            else epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
-        }
-    }
 }
 
 // PERSIST: launched with 256 workgroups (one per CU); each walks tiles b, b+256, ... -- no workgroup retire/dispatch and
@@ -1148,33 +1005,6 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p6(GemmArgs p) {
     }
 }
 
-template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
-int launch_p4_inst(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p4<TI, TO, ACT, HAS_RES, REMAP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
-        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    const int tiles_m = (a.M + BM4 - 1) / BM4;
-    hipLaunchKernelGGL((gemm_kernel_p4<TI, TO, ACT, HAS_RES, REMAP>), dim3(tiles_m * a.tiles_n), dim3(NTHREADS2), LDS4, s, a);
-    return cfsar_check_launch("cfsar_gemm(p4)");
-}
-
-// bf16 only, the shapes of the ViT blocks
-template <typename TO>
-int launch_p4(const GemmArgs& a0, hipStream_t s) {
-    GemmArgs a = a0;
-    a.tiles_n = (a.N + BN4 - 1) / BN4;
-    const bool r = a.res != nullptr;
-    if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF) return -2;
-    if (a.act == CFSAR_ACT_QUICKGELU)
-        return r ? -2 : launch_p4_inst<__bf16, TO, CFSAR_ACT_QUICKGELU, false, false>(a, s);
-    return r ? launch_p4_inst<__bf16, TO, CFSAR_ACT_NONE, true, false>(a, s)
-             : launch_p4_inst<__bf16, TO, CFSAR_ACT_NONE, false, false>(a, s);
-}
-
 template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP, bool PERSIST>
 int launch_p6_inst(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
@@ -1202,360 +1032,12 @@ int launch_p6(const GemmArgs& a0, hipStream_t s) {
              : launch_p6_inst<__bf16, TO, CFSAR_ACT_NONE, false, false, PERSIST>(a, s);
 }
 
-// ============================================================================================================
-// v4 ("p5"): 256(M) x 128(N) tile, 256 threads (4 waves as 2x2, each wave 128 x 64 = 4x2 MFMA tiles), 64-byte K
-// slices, THREE-stage ring of 24 KiB (72 KiB per workgroup) -> TWO independent workgroups per CU.  The two workgroups
-// drift out of phase, so one workgroup's pipeline fill / epilogue (no MFMA) overlaps the other's main loop -- the
-// serialisation that caps the one-workgroup-per-CU kernels (p3/p4) on the short-K (768) GEMMs of the ViT.
-// ============================================================================================================
-constexpr int BM5 = 256;
-constexpr int BN5 = 128;
-constexpr int STAGE5 = (BM5 + BN5) * ROWB4;   // 24 KiB
-constexpr int NSTAGE5 = 3;
-constexpr int LDS5 = NSTAGE5 * STAGE5;        // 73728 B  (>= 4 * EPI_WAVE_BYTES = 69632)
-
-template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_p5(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BK = ROWB4 / (int)sizeof(TI);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
-    const int m0 = tm * BM5, n0 = tn * BN5;
-
-    // staging: X tile = 16 instructions of 16 rows x 64 B, W tile = 8; wave w issues X {w, w+4, w+8, w+12}, W {w, w+4}
-    const char* srcX[4];
-    const char* srcW[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (i * 4 + wave) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ swz4(row);
-        int gm = m0 + row;
-        gm = gm < p.M ? gm : p.M - 1;
-        srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (i * 4 + wave) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ swz4(row);
-        int gn = n0 + row;
-        gn = gn < p.N ? gn : p.N - 1;
-        srcW[i] = p.W + ((size_t)gn * p.ldw) * sizeof(TI) + chunk * 16;
-    }
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
-    auto issue = [&](int stage, int kt) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)stage * (unsigned)STAGE5);
-        const size_t koff = (size_t)kt * ROWB4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16_asm(srcX[i] + koff, base + i * 4096);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) glds16_asm(srcW[i] + koff, base + BM5 * ROWB4 + i * 4096);
-    };
-
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 31, hi = lane >> 5;
-    int offX[4], offW[2], sxX[4], sxW[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rx = wm * 128 + i * 32 + lr;
-        offX[i] = rx * ROWB4;
-        sxX[i] = swz4(rx);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rw = wn * 64 + i * 32 + lr;
-        offW[i] = BM5 * ROWB4 + rw * ROWB4;
-        sxW[i] = swz4(rw);
-    }
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int nk = p.K / BK;
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    int st = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int st2 = st + 2;
-        st2 = st2 >= NSTAGE5 ? st2 - NSTAGE5 : st2;
-        if (kt + 2 < nk) issue(st2, kt + 2);
-        const char* base = smem + st * STAGE5;
-        uint4 xf[2][4], wf[2][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xf[0][i] = *reinterpret_cast<const uint4*>(base + offX[i] + ((hi ^ sxX[i]) << 4));
-#pragma unroll
-        for (int i = 0; i < 2; ++i) wf[0][i] = *reinterpret_cast<const uint4*>(base + offW[i] + ((hi ^ sxW[i]) << 4));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xf[1][i] = *reinterpret_cast<const uint4*>(base + offX[i] + (((2 + hi) ^ sxX[i]) << 4));
-#pragma unroll
-        for (int i = 0; i < 2; ++i) wf[1][i] = *reinterpret_cast<const uint4*>(base + offW[i] + (((2 + hi) ^ sxW[i]) << 4));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    if constexpr (sizeof(TI) == 2) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s2][ni]),
-                                                                              __builtin_bit_cast(bf16x8, xf[s2][mi]),
-                                                                              acc[mi][ni], 0, 0, 0);
-                    } else {
-                        const f32x4 a = __builtin_bit_cast(f32x4, wf[s2][ni]);
-                        const f32x4 bb = __builtin_bit_cast(f32x4, xf[s2][mi]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bb[j], acc[mi][ni], 0, 0, 0);
-                    }
-                }
-        st = st + 1 >= NSTAGE5 ? 0 : st + 1;
-    }
-    __syncthreads();
-    char* wbuf = smem + wave * EPI_WAVE_BYTES;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 64;
-        const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
-        if constexpr (kBf16PackedEpilogue && sizeof(TO) == 2 && !HAS_RES && !REMAP) {
-            if (full) epilogue_lds_bf16<ACT, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
-            else epilogue_lds_bf16<ACT, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
-        } else {
-            if (full) epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
-            else epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
-        }
-    }
-}
-
-template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP>
-int launch_p5_inst(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p5<TI, TO, ACT, HAS_RES, REMAP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
-        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    const int tiles_m = (a.M + BM5 - 1) / BM5;
-    hipLaunchKernelGGL((gemm_kernel_p5<TI, TO, ACT, HAS_RES, REMAP>), dim3(tiles_m * a.tiles_n), dim3(256), LDS5, s, a);
-    return cfsar_check_launch("cfsar_gemm(p5)");
-}
-
-template <typename TO>
-int launch_p5(const GemmArgs& a0, hipStream_t s) {
-    GemmArgs a = a0;
-    a.tiles_n = (a.N + BN5 - 1) / BN5;
-    const bool r = a.res != nullptr;
-    if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF) return -2;
-    if (a.act == CFSAR_ACT_QUICKGELU)
-        return r ? -2 : launch_p5_inst<__bf16, TO, CFSAR_ACT_QUICKGELU, false, false>(a, s);
-    return r ? launch_p5_inst<__bf16, TO, CFSAR_ACT_NONE, true, false>(a, s)
-             : launch_p5_inst<__bf16, TO, CFSAR_ACT_NONE, false, false>(a, s);
-}
-
 }  // namespace
 
 static unsigned long long* g_trace = nullptr;
 static int g_variant_override = -1, g_dbg_override = -1;   // dev tool: in-process A/B (tools/gemm_ab.py)
-// ============================================================================================================
-// v6 ("p8"): 256(M) x 256(N) tile, 256 threads = ONE wave per SIMD (4 waves as 2 x 2, each wave 128 x 128 = 4x4 MFMA
-// 32x32 tiles, 256 accumulator registers out of the 512-entry unified VGPR/AGPR file).  Same 4-stage / 64-byte-slice
-// LDS ring and asm LDS-DMA as p4, but every fragment read from LDS now feeds FOUR MFMAs instead of 2.67 (LDS->VGPR
-// bytes per FLOP -33 % vs the 128x64 wave tile) and a single wave owns the SIMD's matrix pipe: its 16 independent
-// accumulator chains issue back to back while the ds_reads of the next 16-wide K sub-step and the DMA of slice kt+3
-// are in flight (software pipelining inside one wave instead of two waves taking turns).
-// ============================================================================================================
-template <typename TO, int ACT, bool HAS_RES>
-__global__ __launch_bounds__(256) void gemm_kernel_p8(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __bf16 TI;
-    constexpr int BK = ROWB4 / (int)sizeof(TI);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
-    const int m0 = tm * BM4, n0 = tn * BN4;
-
-    // staging: each operand tile = 16 instructions of 16 rows x 64 B; wave w issues instructions {w, w+4, w+8, w+12}
-    const char* srcX[4];
-    const char* srcW[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (i * 4 + wave) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ swz4(row);
-        int gm = ((p.dbg & 8) ? 0 : m0) + row;
-        gm = gm < p.M ? gm : p.M - 1;
-        int gn = ((p.dbg & 8) ? 0 : n0) + row;
-        gn = gn < p.N ? gn : p.N - 1;
-        srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
-        srcW[i] = p.W + ((size_t)gn * p.ldw) * sizeof(TI) + chunk * 16;
-    }
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
-    auto issue = [&](int kt) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)(kt & 3) * (unsigned)STAGE4);
-        const size_t koff = (size_t)kt * ROWB4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16_asm(srcX[i] + koff, base + i * 4096);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16_asm(srcW[i] + koff, base + BM4 * ROWB4 + i * 4096);
-    };
-
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 31, hi = lane >> 5;
-    int offX[4], offW[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rx = wm * 128 + i * 32 + lr;
-        offX[i] = rx * ROWB4 + ((hi ^ swz4(rx)) << 4);                    // sub-step 0; sub-step 1 = ^ 32 (chunk ^ 2)
-        const int rw = wn * 128 + i * 32 + lr;
-        offW[i] = BM4 * ROWB4 + rw * ROWB4 + ((hi ^ swz4(rw)) << 4);
-    }
-    f32x16 acc[2][4][2];                                                   // [n half][mi][ni within the half]
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.0f;
-
-    const int nk = p.K / BK;
-    uint4 xfA[4], wfA[4], xfB[4], wfB[4];
-    // One DMA instruction / one fragment read at a time, so that they can be interleaved 1:1 with the MFMAs below.
-    auto issue_one = [&](int kt, int j) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)(kt & 3) * (unsigned)STAGE4);
-        const size_t koff = (size_t)kt * ROWB4;
-        if (j < 4) glds16_asm(srcX[j] + koff, base + j * 4096);
-        else glds16_asm(srcW[j - 4] + koff, base + BM4 * ROWB4 + (j - 4) * 4096);
-    };
-    // read order = order of first use by the MFMA sequence (ni-major): x0 w0 x1 x2 x3 w1 w2 w3
-    auto load_one = [&](int kt, int s2, int j, uint4 (&xf)[4], uint4 (&wf)[4]) {
-        const char* base = smem + (kt & 3) * STAGE4;
-        const int x2 = s2 << 5;
-        constexpr int isx[8] = {1, 0, 1, 1, 1, 0, 0, 0};
-        constexpr int idx[8] = {0, 0, 1, 2, 3, 1, 2, 3};
-        if (isx[j]) xf[idx[j]] = *reinterpret_cast<const uint4*>(base + (offX[idx[j]] ^ x2));
-        else wf[idx[j]] = *reinterpret_cast<const uint4*>(base + (offW[idx[j]] ^ x2));
-    };
-    auto mfma_one = [&](int j, uint4 (&xf)[4], uint4 (&wf)[4]) {
-        const int ni = j >> 2, mi = j & 3;
-        acc[ni >> 1][mi][ni & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]), acc[ni >> 1][mi][ni & 1], 0, 0, 0);
-    };
-    // One K slice = 32 MFMAs per wave (2 sub-steps x 16).  Sub-step 0 carries the 8 fragment reads of sub-step 1 and the
-    // wave's 8 DMA instructions of slice kt+3; sub-step 1 carries the 8 fragment reads of slice kt+1 / sub-step 0: the
-    // matrix pipe is fed every 32 cycles while at most one other instruction group issues between two MFMAs.
-    // ISSUE / NEXT / VM8 are compile-time so that the steady-state loop has no branch: a conditional ds_read would force
-    // hipcc to the conservative lgkmcnt and stall every MFMA on the reads issued just before it.
-    auto step = [&](int kt, auto ISSUE, auto NEXT, auto VM8) {
-        if constexpr (decltype(VM8)::value) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(p.dbg & 2)) __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            mfma_one(j, xfA, wfA);
-            if (j < 8) load_one(kt, 1, j, xfB, wfB);
-            else if constexpr (decltype(ISSUE)::value) {
-                if (!(p.dbg & 1)) issue_one(kt + 3, j - 8);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            mfma_one(j, xfB, wfB);
-            if constexpr (decltype(NEXT)::value) {
-                if (j < 8) load_one(kt + 1, 0, j, xfA, wfA);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    issue(0);
-    issue(1);
-    issue(2);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) load_one(0, 0, j, xfA, wfA);
-    // Invariant at the barrier of step kt: slices <= kt+1 have landed for every wave (a wave leaves only its 8
-    // instructions of slice kt+2 in flight); slice kt+3 then goes into the stage of slice kt-1, last read one step ago.
-    int kt = 0;
-    for (; kt < nk - 3; ++kt) step(kt, T_{}, T_{}, T_{});
-    step(kt, F_{}, T_{}, T_{});          // nk-3: slices nk-2, nk-1 still to land
-    step(kt + 1, F_{}, T_{}, F_{});      // nk-2
-    step(kt + 2, F_{}, F_{}, F_{});      // nk-1
-    __syncthreads();
-    if (p.dbg & 4) {
-        if (acc[0][0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][1][3] + acc[0][3][1][2] + acc[1][2][0][1];
-        return;
-    }
-    char* wbuf = smem + wave * EPI_WAVE_BYTES;
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 128 + nh * 64;
-            const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
-            if (full) epilogue_lds<TO, ACT, HAS_RES, false, true, 2, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
-            else epilogue_lds<TO, ACT, HAS_RES, false, false, 2, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
-        }
-}
-
-template <typename TO, int ACT, bool HAS_RES>
-int launch_p8_inst(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p8<TO, ACT, HAS_RES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
-        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_kernel_p8<TO, ACT, HAS_RES>), dim3(a.ntiles), dim3(256), LDS4, s, a);
-    return cfsar_check_launch("cfsar_gemm(p8)");
-}
-
-template <typename TO>
-int launch_p8(const GemmArgs& a0, hipStream_t s) {
-    GemmArgs a = a0;
-    a.tiles_n = (a.N + BN4 - 1) / BN4;
-    a.ntiles = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
-    const bool r = a.res != nullptr;
-    if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF || a.K < 96) return -2;   // >= 3 K slices
-    if (a.act == CFSAR_ACT_QUICKGELU) return r ? -2 : launch_p8_inst<TO, CFSAR_ACT_QUICKGELU, false>(a, s);
-    return r ? launch_p8_inst<TO, CFSAR_ACT_NONE, true>(a, s) : launch_p8_inst<TO, CFSAR_ACT_NONE, false>(a, s);
-}
-
-// ============================================================================================================
-// v7 ("p9"): p8's geometry (256x256 tile, ONE wave per SIMD, 128x128 wave tiles, 1:1 MFMA/filler interleave) with
-// REGISTER-STAGED operands: global_load_dwordx4 -> VGPR -> ds_write_b128 instead of LDS-DMA.  Measured on MI355X
-// (profiles/r01_gemm_ablation.md): an LDS-DMA instruction costs its wave ~60-100 issue cycles (> the 32-cycle shadow of
-// one MFMA) and the DMA path streams 64-71 GB/s per CU from L2 against ~100 GB/s for plain vector loads; with eight DMA
-// pieces per 64-byte slice p8 loses ~330 of every ~1 350 cycles to them.  Here every filler (16 ds_read_b128, 8
-// global_load_dwordx4, 8 ds_write_b128 per slice and wave) sits in the shadow of one of the slice's 32 MFMAs.
-// Pipeline: THREE LDS stages (96 KiB) + TWO register sets.  Iteration kt computes slice kt from stage kt%3, loads
-// slice kt+3 from global memory into G[(kt+1)&1], and writes slice kt+2 (loaded one iteration ago into G[kt&1]) to
-// stage (kt+2)%3, whose last reader was iteration kt-1.  hipcc counts vmcnt/lgkmcnt itself (no conditionals in the
-// steady state).  Needs an even number (>= 4) of 64-byte K slices.
-// ============================================================================================================
-constexpr int NSTAGE9 = 3;
+// ---- helpers shared by the register-staged kernels (p10, p12)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: loads/stores stay SSA values (no memcpy)
 // compile-time loop: indices are constants in the AST, so the register arrays below are split by the FIRST SROA pass
 // (a `#pragma unroll` loop index is still dynamic there and leaves them to the size-limited alloca promotion -> scratch)
@@ -1567,180 +1049,10 @@ template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
-template <typename TO, int ACT, bool HAS_RES>
-__global__ __launch_bounds__(256) void gemm_kernel_p9(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __bf16 TI;
-    constexpr int BK = ROWB4 / (int)sizeof(TI);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
-    const int m0 = tm * BM4, n0 = tn * BN4;
-
-    // staging: each operand tile = 16 pieces of 16 rows x 64 B (1 KiB per wave-instruction); wave w owns pieces
-    // {w, w+4, w+8, w+12}; the XOR swizzle is applied to the global chunk a lane fetches, the LDS image is lane-linear
-    unsigned offX[4], offWg[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (i * 4 + wave) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ swz4(row);
-        int gm = m0 + row;
-        gm = gm < p.M ? gm : p.M - 1;
-        int gn = n0 + row;
-        gn = gn < p.N ? gn : p.N - 1;
-        offX[i] = (unsigned)gm * (unsigned)p.lda * 2u + chunk * 16;
-        offWg[i] = (unsigned)gn * (unsigned)p.ldw * 2u + chunk * 16;
-    }
-    const int wr_off = wave * 1024 + lane * 16;          // + piece i * 4096 (+ BM4*ROWB4 for W) inside a stage
-
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 31, hi = lane >> 5;
-    int rdX[4], rdW[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rx = wm * 128 + i * 32 + lr;
-        rdX[i] = rx * ROWB4 + ((hi ^ swz4(rx)) << 4);                     // sub-step 0; sub-step 1 = ^ 32
-        const int rw = wn * 128 + i * 32 + lr;
-        rdW[i] = BM4 * ROWB4 + rw * ROWB4 + ((hi ^ swz4(rw)) << 4);
-    }
-    f32x16 acc[2][4][2];                                                   // [n half][mi][ni within the half]
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.0f;
-
-    const int nk = p.K / BK;
-    u32x4 G0[8], G1[8];                 // two register sets of 8 pieces (4 of X, 4 of W)
-    uint4 xfA[4], wfA[4], xfB[4], wfB[4];
-    auto gload_one = [&](int kt, auto J, u32x4 (&g)[8]) {
-        constexpr int j = decltype(J)::value;
-        if constexpr (j < 4) g[j] = *reinterpret_cast<const u32x4*>(p.A + (size_t)kt * ROWB4 + offX[j]);
-        else g[j] = *reinterpret_cast<const u32x4*>(p.W + (size_t)kt * ROWB4 + offWg[j - 4]);
-    };
-    auto swrite_one = [&](int stage, auto J, const u32x4 (&g)[8]) {
-        constexpr int j = decltype(J)::value;
-        char* dst = smem + stage * STAGE4 + wr_off + (j < 4 ? j * 4096 : BM4 * ROWB4 + (j - 4) * 4096);
-        *reinterpret_cast<u32x4*>(dst) = g[j];
-    };
-    // read order = order of first use by the MFMA sequence (ni-major): x0 w0 x1 x2 x3 w1 w2 w3
-    auto load_one = [&](int stage, int s2, auto J, uint4 (&xf)[4], uint4 (&wf)[4]) {
-        constexpr int j = decltype(J)::value;
-        const char* base = smem + stage * STAGE4;
-        const int x2 = s2 << 5;
-        constexpr int isx[8] = {1, 0, 1, 1, 1, 0, 0, 0};
-        constexpr int idx[8] = {0, 0, 1, 2, 3, 1, 2, 3};
-        if constexpr (isx[j] != 0) xf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdX[idx[j]] ^ x2));
-        else wf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdW[idx[j]] ^ x2));
-    };
-    auto mfma_one = [&](auto J, uint4 (&xf)[4], uint4 (&wf)[4]) {
-        constexpr int j = decltype(J)::value;
-        constexpr int ni = j >> 2, mi = j & 3;
-        acc[ni >> 1][mi][ni & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]), acc[ni >> 1][mi][ni & 1], 0, 0, 0);
-    };
-    // stages: s0 = kt%3 (compute), s1 = (kt+1)%3 (next fragments), s2 = (kt+2)%3 (being written)
-    auto step = [&](int kt, int s0, int s1, int s2, auto PAR, auto LOAD, auto WRITE, auto NEXT) {
-        constexpr int par = decltype(PAR)::value;
-        __syncthreads();                                    // hipcc adds lgkmcnt(0): this wave's ds_writes of slice kt+1
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<16>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            mfma_one(J, xfA, wfA);
-            if constexpr (j < 8) load_one(s0, 1, J, xfB, wfB);
-            else if constexpr (decltype(LOAD)::value) {
-                if constexpr (par == 0) gload_one(kt + 3, std::integral_constant<int, j - 8>{}, G1);
-                else gload_one(kt + 3, std::integral_constant<int, j - 8>{}, G0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        static_for<16>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            mfma_one(J, xfB, wfB);
-            if constexpr (j < 8) {
-                if constexpr (decltype(NEXT)::value) load_one(s1, 0, J, xfA, wfA);
-            } else if constexpr (decltype(WRITE)::value) {
-                if constexpr (par == 0) swrite_one(s2, std::integral_constant<int, j - 8>{}, G0);
-                else swrite_one(s2, std::integral_constant<int, j - 8>{}, G1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    // prologue: slices 0 and 1 -> LDS stages 0 and 1, slice 2 -> G[0]
-    static_for<8>([&](auto J) { gload_one(0, J, G0); });
-    static_for<8>([&](auto J) { gload_one(1, J, G1); });
-    static_for<8>([&](auto J) { swrite_one(0, J, G0); });
-    static_for<8>([&](auto J) { gload_one(2, J, G0); });
-    static_for<8>([&](auto J) { swrite_one(1, J, G1); });
-    __syncthreads();
-    static_for<8>([&](auto J) { load_one(0, 0, J, xfA, wfA); });
-    int kt = 0, s0 = 0, s1 = 1, s2 = 2;
-    auto rot = [&]() { const int t = s0; s0 = s1; s1 = s2; s2 = t; };
-    for (; kt < nk - 4; kt += 2) {                           // nk even: steady steps 0 .. nk-4, in pairs + one
-        step(kt, s0, s1, s2, P0{}, T_{}, T_{}, T_{}); rot();
-        step(kt + 1, s0, s1, s2, P1{}, T_{}, T_{}, T_{}); rot();
-    }
-    step(kt, s0, s1, s2, P0{}, T_{}, T_{}, T_{}); rot();      // kt = nk-4: loads the last slice (nk-1)
-    step(kt + 1, s0, s1, s2, P1{}, F_{}, T_{}, T_{}); rot();  // nk-3: writes the last slice
-    step(kt + 2, s0, s1, s2, P0{}, F_{}, F_{}, T_{}); rot();  // nk-2
-    step(kt + 3, s0, s1, s2, P1{}, F_{}, F_{}, F_{});         // nk-1
-    __syncthreads();
-    if (p.dbg & 4) {
-        if (acc[0][0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][1][3] + acc[0][3][1][2] + acc[1][2][0][1];
-        return;
-    }
-    char* wbuf = smem + wave * EPI_WAVE_BYTES;
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 128 + nh * 64;
-            const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
-            if (full) epilogue_lds<TO, ACT, HAS_RES, false, true, 2, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
-            else epilogue_lds<TO, ACT, HAS_RES, false, false, 2, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
-        }
-}
-
-template <typename TO, int ACT, bool HAS_RES>
-int launch_p9_inst(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p9<TO, ACT, HAS_RES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
-        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_kernel_p9<TO, ACT, HAS_RES>), dim3(a.ntiles), dim3(256), LDS4, s, a);
-    return cfsar_check_launch("cfsar_gemm(p9)");
-}
-
-template <typename TO>
-int launch_p9(const GemmArgs& a0, hipStream_t s) {
-    GemmArgs a = a0;
-    a.tiles_n = (a.N + BN4 - 1) / BN4;
-    a.ntiles = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
-    const bool r = a.res != nullptr;
-    const int nk = a.K / 32;
-    if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF || nk < 4 || (nk & 1)) return -2;
-    // 32-bit operand offsets
-    if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32)) return -2;
-    if (a.act == CFSAR_ACT_QUICKGELU) return r ? -2 : launch_p9_inst<TO, CFSAR_ACT_QUICKGELU, false>(a, s);
-    return r ? launch_p9_inst<TO, CFSAR_ACT_NONE, true>(a, s) : launch_p9_inst<TO, CFSAR_ACT_NONE, false>(a, s);
-}
 
 // ============================================================================================================
-// v8 ("p10"): p9 with WHOLE CACHE LINES per request.  Measured (tools/ubench/vgpr_l2.hip): the L2 -> CU path delivers
+// v4 ("p10"): ONE wave per SIMD (256 threads, 2 x 2 waves, 128 x 128 wave tiles, 256 accumulators in AGPRs), register-staged
+// operands, WHOLE CACHE LINES per request.  Measured (tools/ubench/vgpr_l2.hip): the L2 -> CU path delivers
 // ~100 GB/s per CU for 8 rows x 128 B per wave-instruction but only ~61 GB/s for the 16 rows x 64 B pieces that 64-byte K
 // slices imply (the L2 serves requests, not bytes): every 64-byte-slice kernel above runs its operand stream at > 50 %
 // of that ceiling.  Here K advances in 128-byte tiles (64 bf16): TWO 64 KiB LDS stages of 128-byte rows
@@ -1992,7 +1304,7 @@ int launch_p10(const GemmArgs& a0, hipStream_t s) {
 }
 
 // ============================================================================================================
-// v9 ("p12"): p10's operand path (128-byte K tiles, whole-line requests, register staging, two 64 KiB LDS stages, one barrier
+// v5 ("p12"): p10's operand path (128-byte K tiles, whole-line requests, register staging, two 64 KiB LDS stages, one barrier
 // per K tile) with TWO waves per SIMD: 512 threads, 8 waves as 2(M) x 4(N), wave tile 128 x 64 (128 accumulators).  For the
 // QuickGELU epilogue (c_fc) the second wave per SIMD overlaps the 2-transcendentals-per-element VALU work and the stores of
 // one wave with those of the other, which is what p10 lacks; the main loop keeps p10's request efficiency, which p6 lacks.
@@ -2221,29 +1533,21 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     a.trace = g_trace;
     a.conv_H = a.conv_W = a.conv_lgC = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // variant: 0 = auto, 1 = v1 (128x128, 2-stage, compiler-managed LDS-DMA), 2 = p3 (256x128, 3-stage, asm LDS-DMA)
+    // CFSAR_GEMM_VARIANT (dev): 0 = auto, 1 = v1 (128x128, also the fp32 path), 2 = p3 (256x128, asm LDS-DMA), 6 = p6 (256x256
+    // ping-pong LDS-DMA), 7 = p6 persistent, 10 = p10 (one wave per SIMD, register-staged whole-line requests), 11 = p10
+    // persistent, 12 = p12 (p10's operand path, two waves per SIMD).  auto: p12 for N >= 256 with enough 256x256 tiles to fill
+    // the chip; otherwise p3 (skinny / short-K bf16 GEMMs: its 256x128 tile wastes less of a narrow N and the 16-byte-per-lane
+    // bf16 epilogue fits its register budget, tools/rn_gemm_ab.py) when M >= 1024; v1 below.
     static const int forced_env = [] { const char* e = getenv("CFSAR_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
     const int forced = g_variant_override >= 0 ? g_variant_override : forced_env;
-    // p4 needs enough 256x256 tiles to fill the 256 CUs for >= 2 rounds
     const long tiles4 = (long)((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
-    // variants: 1 = v1 (128x128), 2 = p3 (256x128, 3-stage), 3 = p4 (256x256, 4-stage), 4 = p5 (256x128, 2 WG/CU),
-    // 6 = p6 (256x256 ping-pong).  auto: p6 when >= 2 rounds of 256x256 tiles exist, else p3 / v1.
-    // 10 = p10 (one wave per SIMD, register-staged whole-line operand requests).  auto: p10 for the epilogues without an
-    // activation (QKV, out_proj, c_proj, RN50 convs: +2...+6 % over p6 at M = 126080, tools/gemm_ab.py); the QuickGELU
-    // epilogue (c_fc) keeps p6, whose second wave per SIMD hides part of the 2-transcendentals-per-element VALU time.
-    // ... and the skinny / short-K bf16-out GEMMs of the RN50 tower (N <= 256 or K < 512, often with a bf16 residual) go to
-    // p3: its 256x128 tile wastes less of a narrow N, two waves per SIMD overlap the HBM-bound epilogue, and the
-    // 16-byte-per-lane bf16 epilogue fits its register budget (tools/rn_gemm_ab.py).
-    const bool p10_shape = out_dtype == CFSAR_F32 || (N >= 512 && K >= 512 && !residual);
-    // 12 = p12: p10's operand path with two waves per SIMD.  Measured fastest on all four ViT GEMMs (M = 252 160, same box,
-    // interleaved: QKV 888 vs 960 us (p10), out_proj 457 vs 476, c_fc 1 288 vs 1 409 (p6), c_proj 1 143 vs 1 178): the auto
-    // choice wherever p10 or p6 were chosen before.
-    // Also the RN50 1x1 convs with N >= 256 (tools/rn_gemm_ab.py); narrower outputs stay on p3's 256x128 tile.
+    // p12 measured fastest on all four ViT GEMMs (M = 252 160, same box, interleaved: QKV 888 vs 960 us (p10), out_proj 457 vs
+    // 476, c_fc 1 288 vs 1 409 (p6), c_proj 1 143 vs 1 178) and on the RN50 1x1 convs with N >= 256 (tools/rn_gemm_ab.py).
     if (in_dtype == CFSAR_BF16 && (forced == 12 || (forced == 0 && tiles4 >= 240 && N >= 256))) {
         const int rc = out_dtype == CFSAR_BF16 ? launch_p12<__bf16>(a, s) : launch_p12<float>(a, s);
         if (rc != -2) return rc;
     }
-    if (in_dtype == CFSAR_BF16 && (forced == 10 || (forced == 0 && tiles4 >= 512 && act == CFSAR_ACT_NONE && p10_shape))) {
+    if (in_dtype == CFSAR_BF16 && forced == 10) {
         const int rc = out_dtype == CFSAR_BF16 ? launch_p10<__bf16, false>(a, s) : launch_p10<float, false>(a, s);
         if (rc != -2) return rc;
     }
@@ -2251,32 +1555,15 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
         const int rc = out_dtype == CFSAR_BF16 ? launch_p10<__bf16, true>(a, s) : launch_p10<float, true>(a, s);
         if (rc != -2) return rc;
     }
-    if (in_dtype == CFSAR_BF16 && forced == 9) {               // 9 = p9 (p8 geometry, register-staged operands)
-        const int rc = out_dtype == CFSAR_BF16 ? launch_p9<__bf16>(a, s) : launch_p9<float>(a, s);
-        if (rc != -2) return rc;
-    }
-    if (in_dtype == CFSAR_BF16 && forced == 8) {               // 8 = p8 (one wave per SIMD, 128x128 wave tiles)
-        const int rc = out_dtype == CFSAR_BF16 ? launch_p8<__bf16>(a, s) : launch_p8<float>(a, s);
-        if (rc != -2) return rc;
-    }
     if (in_dtype == CFSAR_BF16 && forced == 7) {               // 7 = p6 persistent
         const int rc = out_dtype == CFSAR_BF16 ? launch_p6<__bf16, true>(a, s) : launch_p6<float, true>(a, s);
         if (rc != -2) return rc;
     }
-    if (in_dtype == CFSAR_BF16 && (forced == 6 || (forced == 0 && tiles4 >= 512 && (act != CFSAR_ACT_NONE || p10_shape)))) {
+    if (in_dtype == CFSAR_BF16 && forced == 6) {
         const int rc = out_dtype == CFSAR_BF16 ? launch_p6<__bf16, false>(a, s) : launch_p6<float, false>(a, s);
         if (rc != -2) return rc;
     }
-    const bool use_p4 = in_dtype == CFSAR_BF16 && (forced == 3 || forced == 6 || forced == 7);
-    if (use_p4) {
-        const int rc = out_dtype == CFSAR_BF16 ? launch_p4<__bf16>(a, s) : launch_p4<float>(a, s);
-        if (rc != -2) return rc;
-    }
-    if (in_dtype == CFSAR_BF16 && forced == 4) {
-        const int rc = out_dtype == CFSAR_BF16 ? launch_p5<__bf16>(a, s) : launch_p5<float>(a, s);
-        if (rc != -2) return rc;
-    }
-    const bool use_p3 = forced == 2 || forced == 3 || forced == 4 || forced == 6 || forced == 8 || forced == 9 || forced == 10 || forced == 11 || forced == 12 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
+    const bool use_p3 = forced == 2 || forced == 6 || forced == 7 || forced == 10 || forced == 11 || forced == 12 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
     if (use_p3) {
         int rc;
         if (in_dtype == CFSAR_BF16)
