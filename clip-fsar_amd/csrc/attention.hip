@@ -239,230 +239,6 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_a
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Pipelined form for the ViT-B/16 shape (197 tokens = 13 query tiles): one workgroup of NW = 13 waves (one query tile per
-// wave and head: no idle waves in a second round) walks HG consecutive heads of a frame.  While head h is computed, K and
-// V of head h+1 stream in by LDS-DMA (no registers): K straight into the other K/V^T buffer, V row-major into a raw
-// buffer that is transposed LDS -> LDS after the compute phase; the query fragment of head h+1 is prefetched into
-// registers.  The compute phase issues no vector-memory load, so nothing in it waits on the DMA.  The one-head kernel has
-// every wave of a workgroup waiting during its staging phase (rocprofv3: 64 % of its wave-cycles in s_waitcnt, the MFMA
-// pipe 16 % busy); here that latency hides behind the MFMA / exp work of the previous head.
-// LDS: 2 x (K 28 KiB + V^T 33 KiB) + raw V 28 KiB = 150.5 KiB.  The per-tile arithmetic is identical to
-// vit_attn_bf16_kernel.
-// ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void att_glds16(const void* src, unsigned lds_addr) {   // LDS[m0 + lane*16 .. +16] = *src
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src), "s"(lds_addr)
-        : "memory");
-}
-
-// QT = query tiles per wave: with QT = 2 every K / V^T fragment read from LDS feeds two MFMAs (the kernel is LDS-bound).
-template <int NKB, int NTV, int NW, int HG, int QT>
-__global__ __launch_bounds__(NW * 64) void vit_attn_bf16_pipe_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
-                                                                      int ntok, int D, float scale_log2e) {
-    constexpr int NTHR = NW * 64;
-    constexpr int NP = NKB * 32;
-    constexpr int NT = NKB * 2;
-    constexpr int VT_STRIDE = ((NP * 2 + 255) / 256) * 256 + 16;   // bytes
-    constexpr int BUF = NP * 128 + 64 * VT_STRIDE;
-    constexpr int NPIECE = NP / 8;                                 // 1 KiB DMA pieces (8 rows x 128 B) per operand
-    constexpr int VIT = ((NP / 2) * 8 + NTHR - 1) / NTHR;          // (key pair, 8 d) transposition items per thread
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sVraw = smem + 2 * BUF;
-
-    const int f = blockIdx.y, h0 = blockIdx.x * HG;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t ld = (size_t)3 * D;
-    const __bf16* fbase = qkv + (size_t)f * ntok * ld;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-
-    // K -> buffer `buf` (swizzled rows, swizzle applied to the source chunk), V -> raw buffer (same image); rows >= ntok
-    // re-read the last token (finite values; their scores are masked and their probabilities are exactly 0)
-    auto stage_dma = [&](int h, int buf) {
-        const __bf16* base = fbase + h * 64;
-        for (int i = wave; i < 2 * NPIECE; i += NW) {
-            const int piece = i < NPIECE ? i : i - NPIECE;
-            const int r = piece * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ swz(r);
-            const int rc = r < ntok ? r : ntok - 1;
-            const __bf16* src = base + (size_t)rc * ld + (i < NPIECE ? D : 2 * D) + c * 8;
-            const unsigned dst = i < NPIECE ? lds0 + (unsigned)buf * BUF + piece * 1024 : lds0 + 2u * BUF + piece * 1024;
-            att_glds16(src, __builtin_amdgcn_readfirstlane(dst));
-        }
-    };
-    // raw V (swizzled [key][64 d]) -> V^T [64 d][keys] of buffer `buf`: thread takes keys (2kp, 2kp+1) x 8 d values
-    auto transpose_v = [&](int buf) {
-        char* sVt = smem + buf * BUF + NP * 128;
-#pragma unroll
-        for (int it = 0; it < VIT; ++it) {
-            const int idx = tid + it * NTHR;
-            if (idx < (NP / 2) * 8) {
-                const int kp = idx % (NP / 2), dc = idx / (NP / 2);
-                const int r0 = 2 * kp, r1 = 2 * kp + 1;
-                const uint4 v0 = *reinterpret_cast<const uint4*>(sVraw + r0 * 128 + ((dc ^ swz(r0)) << 4));
-                const uint4 v1 = *reinterpret_cast<const uint4*>(sVraw + r1 * 128 + ((dc ^ swz(r1)) << 4));
-                const unsigned a[4] = {v0.x, v0.y, v0.z, v0.w};
-                const unsigned b[4] = {v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    *reinterpret_cast<unsigned*>(sVt + (dc * 8 + 2 * j) * VT_STRIDE + kp * 4) = (a[j] & 0xFFFFu) | (b[j] << 16);
-                    *reinterpret_cast<unsigned*>(sVt + (dc * 8 + 2 * j + 1) * VT_STRIDE + kp * 4) = (a[j] >> 16) | (b[j] & 0xFFFF0000u);
-                }
-            }
-        }
-    };
-
-    const int q16 = lane & 15, g = lane >> 4;
-    constexpr int nt_valid = NTV > 0 ? NTV : NKB * 2;
-    // this wave's QT query tiles (NW * QT >= number of query tiles); tiles beyond the last one are computed on a clamped
-    // row and not stored
-    int qrow[QT];
-    bool qvalid[QT];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const int r = (wave * QT + t) * 16 + q16;
-        qvalid[t] = r < ntok;
-        qrow[t] = r < ntok ? r : ntok - 1;
-    }
-    const bool has_tile = wave * QT * 16 < ntok;
-    auto load_q = [&](int h, bf16x8 (&qf)[QT][2]) {
-#pragma unroll
-        for (int t = 0; t < QT; ++t)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                qf[t][ks] = *reinterpret_cast<const bf16x8*>(fbase + h * 64 + (size_t)qrow[t] * ld + ks * 32 + g * 8);
-    };
-
-    bf16x8 qcur[QT][2], qnext[QT][2];
-    uint4 opend[QT][2];                                   // packed output of the previous head, not yet stored
-    stage_dma(h0, 0);
-    load_q(h0, qcur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    transpose_v(0);
-    __syncthreads();
-    for (int hi = 0; hi < HG; ++hi) {
-        const int h = h0 + hi;
-        const char* sK = smem + (hi & 1) * BUF;
-        const char* sVt = sK + NP * 128;
-        if (hi + 1 < HG) {
-            stage_dma(h + 1, (hi + 1) & 1);       // other buffer: last read by head hi-1, every wave is past that barrier
-            load_q(h + 1, qnext);
-        }
-        // The previous head's output goes out HERE, next to the DMA issue: stores and LDS-DMA share the vmcnt counter, so
-        // a store issued at the end of the compute phase would put its full latency into the vmcnt(0) before the barrier.
-        if (hi > 0 && has_tile) {
-#pragma unroll
-            for (int t = 0; t < QT; ++t)
-                store_o_packed(opend[t], qvalid[t], out + ((size_t)f * ntok + qrow[t]) * D + (h - 1) * 64, g);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_tile) {
-            f32x4 s[QT][NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-#pragma unroll
-                for (int t = 0; t < QT; ++t) s[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (j < nt_valid) {
-                    const int kr = j * 16 + q16;
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kr * 128 + (((ks * 4 + g) ^ swz(kr)) << 4));
-#pragma unroll
-                        for (int t = 0; t < QT; ++t)
-                            s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qcur[t][ks], s[t][j], 0, 0, 0);
-                    }
-                }
-                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-            float inv[QT];
-#pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                float mx = -1e30f;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if (NTV == 0 || j == nt_valid - 1) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (j * 16 + g * 4 + r >= ntok) s[t][j][r] = -1e30f;
-                    }
-                    if (j < nt_valid) mx = fmaxf(fmaxf(mx, fmaxf(s[t][j][0], s[t][j][1])), fmaxf(s[t][j][2], s[t][j][3]));
-                }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float mxs = mx * scale_log2e;
-                float sum = 0.f;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if (j < nt_valid) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][j][r], scale_log2e, -mxs));
-                            s[t][j][r] = pv;
-                            sum += pv;
-                        }
-                    }
-                }
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
-                inv[t] = __builtin_amdgcn_rcpf(sum);
-            }
-            f32x4 o[QT][4];
-#pragma unroll
-            for (int t = 0; t < QT; ++t)
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) {
-                bf16x8 pf[QT];
-#pragma unroll
-                for (int t = 0; t < QT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        pf[t][r] = (__bf16)s[t][2 * kb][r];
-                        pf[t][4 + r] = (__bf16)s[t][2 * kb + 1][r];
-                    }
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const char* vr = sVt + (dt * 16 + q16) * VT_STRIDE + (kb * 32 + g * 4) * 2;
-                    const uint2 lo = *reinterpret_cast<const uint2*>(vr);
-                    const uint2 hi2 = *reinterpret_cast<const uint2*>(vr + 32);
-                    const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi2.x, hi2.y));
-#pragma unroll
-                    for (int t = 0; t < QT; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t], o[t][dt], 0, 0, 0);
-                }
-                if (kb & 1) __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int t = 0; t < QT; ++t) pack_o_tile(o[t], inv[t], g, opend[t]);   // stored at the start of the next head
-        }
-        if (hi + 1 < HG) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces (issued a whole head ago) have landed
-            __syncthreads();                                     // ... and everybody else's; head h's V^T reads are done
-            transpose_v((hi + 1) & 1);
-#pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                qcur[t][0] = qnext[t][0];
-                qcur[t][1] = qnext[t][1];
-            }
-            __syncthreads();
-        }
-    }
-    if (has_tile) {
-#pragma unroll
-        for (int t = 0; t < QT; ++t)
-            store_o_packed(opend[t], qvalid[t], out + ((size_t)f * ntok + qrow[t]) * D + (h0 + HG - 1) * 64, g);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // fp32 VALU kernel (validation mode).  One workgroup per (head, frame); K and V rows in LDS (fp32); one thread per
 // query row with an online softmax (running max / sum, fp32) -- all lanes read the same K/V row (LDS broadcast).
 // ------------------------------------------------------------------------------------------------------------
@@ -534,25 +310,6 @@ int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, h
     return cfsar_check_launch("cfsar_vit_attention(bf16)");
 }
 
-template <int NKB, int NTV, int NW, int HG, int QT>
-int launch_bf16_pipe(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
-    constexpr int NP = NKB * 32;
-    constexpr int VT_STRIDE = ((NP * 2 + 255) / 256) * 256 + 16;
-    constexpr int LDS = 2 * (NP * 128 + 64 * VT_STRIDE) + NP * 128;
-    static_assert(LDS <= 160 * 1024, "two K/V^T buffers + the raw V buffer must fit the 160 KiB LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attn_bf16_pipe_kernel<NKB, NTV, NW, HG, QT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return cfsar_fail("cfsar_vit_attention: set LDS size: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    const float scale_log2e = 0.125f * 1.4426950408889634f;
-    hipLaunchKernelGGL((vit_attn_bf16_pipe_kernel<NKB, NTV, NW, HG, QT>), dim3(heads / HG, F), dim3(NW * 64), LDS, s,
-                       static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e);
-    return cfsar_check_launch("cfsar_vit_attention(bf16, pipelined)");
-}
-
 }  // namespace
 
 // dev tool (not in the public header): buffer of 16 x u64 per (workgroup, wave) for the bf16 kernel's phase stamps; NULL = off
@@ -568,13 +325,11 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
     if (dtype == CFSAR_BF16) {
         CFSAR_REQUIRE(ntok <= 288, "cfsar_vit_attention: ntok=%d > 288", ntok);
         static const int variant = [] { const char* e = getenv("CFSAR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-        // CFSAR_ATTN_VARIANT=2: the pipelined 4-heads-per-workgroup form.  Measured equal to the one-head kernel (266 vs 267 us
-        // at 640 frames): the waits it removes were not the limiter -- the kernel is LDS-bound (fragment reads: 54 KB per
-        // 16-query tile; LDS busy 45 % + 37 % of that in bank-conflict cycles, rocprofv3 --pmc); kept for the next round's
-        // 32-query tiles, which halve the LDS bytes per query.
-        if (ntok == 197 && variant == 4) return launch_bf16<7, 13, 256, true>(qkv, out, F, ntok, D, heads, s);   // 3 WGs per CU
-        if (ntok == 197 && heads % 4 == 0 && variant == 2) return launch_bf16_pipe<7, 13, 13, 4, 1>(qkv, out, F, ntok, D, heads, s);
-        if (ntok == 197 && heads % 4 == 0 && variant == 3) return launch_bf16_pipe<7, 13, 7, 4, 2>(qkv, out, F, ntok, D, heads, s);
+        // CFSAR_ATTN_VARIANT=4 (dev): compact LDS image + 256-thread workgroups = three workgroups per CU (measured slower:
+        // 305 vs 255-277 us at 640 frames).  A pipelined multi-head form (LDS-DMA staging of the next head during the compute
+        // phase, one or two query tiles per wave) was measured equal to this kernel and removed; numbers and the per-phase cycle
+        // stamps are in profiles/r01_attention_ablation.md.
+        if (ntok == 197 && variant == 4) return launch_bf16<7, 13, 256, true>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 197) return launch_bf16<7, 13>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 257) return launch_bf16<9, 17>(qkv, out, F, ntok, D, heads, s);     // ViT-L/14 @224
         if (ntok <= 224) return launch_bf16<7, 0>(qkv, out, F, ntok, D, heads, s);
