@@ -141,6 +141,9 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_a
             }
         }
     }
+    if constexpr (COMPACT) {                 // the last V^T row is over-read by 16 bytes (keys 216-223 of d = 63): keep them finite
+        if (tid < 4) *reinterpret_cast<att_u32x4*>(sVt + 64 * VT_STRIDE + tid * 16) = att_u32x4{0, 0, 0, 0};
+    }
     stamp(1);
     __syncthreads();
     stamp(2);
