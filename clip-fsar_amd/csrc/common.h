@@ -9,8 +9,15 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+// 2-byte element type -> its 4- and 8-wide vectors (epilogues are generic over bf16 / fp16 outputs)
+template <typename T> struct Vec2B;
+template <> struct Vec2B<__bf16> { typedef bf16x4 v4; typedef bf16x8 v8; };
+template <> struct Vec2B<_Float16> { typedef f16x4 v4; typedef f16x8 v8; };
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <> struct Vec2B<float> { typedef f32x4 v4; typedef f32x4 v8; };   // placeholder: float paths never use it
 
 #define CFSAR_WAVE 64
 

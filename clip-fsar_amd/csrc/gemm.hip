@@ -35,8 +35,8 @@ struct GemmArgs {
     const char* W;
     void* out;
     const float* bias;
-    const void* res;      // residual, fp32 or (res_bf16) bf16
-    int res_bf16;
+    const void* res;      // residual: fp32 (res_kind 0), bf16 (1) or fp16 (2)
+    int res_kind;
     int relu;             // ReLU applied last (after bias / activation / residual): conv+BN(+identity)+ReLU of the RN50 tower
     int M, N, K;
     int lda, ldw, ldo, ldr;
@@ -64,9 +64,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-__device__ __forceinline__ float4 load_res4(const void* res, int is_bf16, size_t elem_off) {
-    if (is_bf16) {
+__device__ __forceinline__ float4 load_res4(const void* res, int kind, size_t elem_off) {
+    if (kind == 1) {
         const bf16x4 r = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(res) + elem_off);
+        return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+    }
+    if (kind == 2) {
+        const f16x4 r = *reinterpret_cast<const f16x4*>(static_cast<const _Float16*>(res) + elem_off);
         return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
     }
     return *reinterpret_cast<const float4*>(static_cast<const float*>(res) + elem_off);
@@ -102,7 +106,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], const GemmArgs& p,
                     for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
                 }
                 if (p.res) {
-                    const float4 rv = load_res4(p.res, p.res_bf16, (size_t)rrow * p.ldr + n);
+                    const float4 rv = load_res4(p.res, p.res_kind, (size_t)rrow * p.ldr + n);
                     v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                 }
                 if (p.relu) {
@@ -110,10 +114,10 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], const GemmArgs& p,
                     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
                 }
                 if constexpr (sizeof(TO) == 2) {
-                    bf16x4 o;
+                    typename Vec2B<TO>::v4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + (size_t)orow * p.ldo + n) = o;
+                    for (int j = 0; j < 4; ++j) o[j] = (TO)v[j];
+                    *reinterpret_cast<typename Vec2B<TO>::v4*>(reinterpret_cast<TO*>(p.out) + (size_t)orow * p.ldo + n) = o;
                 } else {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow * p.ldo + n) =
                         make_float4(v[0], v[1], v[2], v[3]);
@@ -163,9 +167,11 @@ constexpr int EPI_WAVE_BYTES = 64 * EPI_RS;     // 17408 B per wave
 // residual load (bf16: one dwordx4) and the store (one dwordx4) move whole 128-byte row segments per 8 lanes, 8 rows per
 // wave-instruction -- half the VMEM instructions of the 4-column form.  The RN50 bottleneck tails (K = 64...512, bf16
 // residual + ReLU) are bound by exactly those instructions.
-template <int ACT, bool HAS_RES, bool FULL, int NMI>
+template <typename T2, int ACT, bool HAS_RES, bool FULL, int NMI>
 __device__ __forceinline__ void epilogue_lds_x8(f32x16 (*acc)[2], const GemmArgs& p, int mbase, int nbase, int lane,
                                                 char* wbuf) {
+    typedef typename Vec2B<T2>::v8 T2x8;
+    typedef typename Vec2B<T2>::v4 T2x4;
     const int lr = lane & 31, hi = lane >> 5;
     const int rsub = lane >> 3, cc = lane & 7;
     const int M = p.M, N = p.N, ldo = p.ldo, ldr = p.ldr, row_off = p.row_off;
@@ -173,10 +179,10 @@ __device__ __forceinline__ void epilogue_lds_x8(f32x16 (*acc)[2], const GemmArgs
     const int nc = n + 8 <= N ? n : N - 8;                   // clamped column for loads; stores are predicated
     const int nvalid = FULL ? 8 : (n + 8 <= N ? 8 : (n + 4 <= N ? 4 : 0));
     const void* resp = p.res;
-    const int res_bf16 = p.res_bf16, relu = p.relu;
-    __bf16* outp = reinterpret_cast<__bf16*>(p.out);
+    const int res_kind = p.res_kind, relu = p.relu;
+    T2* outp = reinterpret_cast<T2*>(p.out);
     constexpr int NIT = 4 * NMI;
-    uint4 rb[HAS_RES ? NIT : 1];                              // bf16 residual: 8 values; fp32 residual: loaded in the row loop
+    uint4 rb[HAS_RES ? NIT : 1];                              // 2-byte residual: 8 values; fp32 residual: loaded in the row loop
     size_t ooff[NIT], roff[HAS_RES ? NIT : 1];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -185,7 +191,7 @@ __device__ __forceinline__ void epilogue_lds_x8(f32x16 (*acc)[2], const GemmArgs
         ooff[it] = (size_t)(mc + row_off) * ldo + nc;
         if constexpr (HAS_RES) {
             roff[it] = (size_t)(mc + row_off) * ldr + nc;
-            if (res_bf16) rb[it] = *reinterpret_cast<const uint4*>(static_cast<const __bf16*>(resp) + roff[it]);
+            if (res_kind) rb[it] = *reinterpret_cast<const uint4*>(static_cast<const char*>(resp) + roff[it] * 2);
         }
     }
     float4 bv0 = make_float4(0.f, 0.f, 0.f, 0.f), bv1 = bv0;
@@ -215,8 +221,12 @@ __device__ __forceinline__ void epilogue_lds_x8(f32x16 (*acc)[2], const GemmArgs
             for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], ACT);
         }
         if constexpr (HAS_RES) {
-            if (res_bf16) {
+            if (res_kind == 1) {
                 const bf16x8 r8 = __builtin_bit_cast(bf16x8, rb[it]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
+            } else if (res_kind == 2) {
+                const f16x8 r8 = __builtin_bit_cast(f16x8, rb[it]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
             } else {
@@ -229,16 +239,16 @@ __device__ __forceinline__ void epilogue_lds_x8(f32x16 (*acc)[2], const GemmArgs
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.0f);
         }
-        bf16x8 o;
+        T2x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
+        for (int j = 0; j < 8; ++j) o[j] = (T2)v[j];
         if (FULL || (nvalid == 8 && mbase + row < M)) {
-            *reinterpret_cast<bf16x8*>(outp + ooff[it]) = o;
+            *reinterpret_cast<T2x8*>(outp + ooff[it]) = o;
         } else if (nvalid == 4 && mbase + row < M) {          // ragged right edge (N % 8 == 4): the clamped lane owns columns
-            bf16x4 o4;                                        // [N-8, N); its last four are the tile's last four
+            T2x4 o4;                                          // [N-8, N); its last four are the tile's last four
 #pragma unroll
             for (int j = 0; j < 4; ++j) o4[j] = o[4 + j];
-            *reinterpret_cast<bf16x4*>(outp + ooff[it] + 4) = o4;
+            *reinterpret_cast<T2x4*>(outp + ooff[it] + 4) = o4;
         }
     }
 }
@@ -250,7 +260,7 @@ __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p
                                              char* wbuf) {
     if constexpr (sizeof(TO) == 2 && !REMAP && X8) {
         if (!(p.dbg & 128) && (p.ldo & 7) == 0 && (!HAS_RES || (p.ldr & 7) == 0) && p.N >= 8) {
-            epilogue_lds_x8<ACT, HAS_RES, FULL, NMI>(acc, p, mbase, nbase, lane, wbuf);
+            epilogue_lds_x8<TO, ACT, HAS_RES, FULL, NMI>(acc, p, mbase, nbase, lane, wbuf);
             return;
         }
     }
@@ -261,7 +271,7 @@ __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p
     const bool nvalid = n < N;
     const int nc = nvalid ? n : N - 4;                       // clamped column: loads stay in bounds, stores are predicated
     const void* resp = p.res;
-    const int res_bf16 = p.res_bf16, relu = p.relu;
+    const int res_kind = p.res_kind, relu = p.relu;
     TO* outp = reinterpret_cast<TO*>(p.out);
     // (1) issue every residual load of this lane up front (16 x 16 B, whole 256-byte row segments per 16 lanes)
     float4 rv[8 * NMI];
@@ -277,7 +287,7 @@ __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p
             rrow = p.res_mod > 0 ? (mc % p.res_mod) + p.res_off : orow;
         }
         ooff[it] = (size_t)orow * ldo + nc;
-        if constexpr (HAS_RES) rv[it] = load_res4(resp, res_bf16, (size_t)rrow * ldr + nc);
+        if constexpr (HAS_RES) rv[it] = load_res4(resp, res_kind, (size_t)rrow * ldr + nc);
     }
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + nc);
@@ -310,10 +320,10 @@ __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p
         }
         if (FULL || (nvalid && mbase + row < M)) {       // FULL: straight-line code, counted vmcnt waits
             if constexpr (sizeof(TO) == 2) {
-                bf16x4 o;
+                typename Vec2B<TO>::v4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
-                *reinterpret_cast<bf16x4*>(outp + ooff[it]) = o;
+                for (int j = 0; j < 4; ++j) o[j] = (TO)v[j];
+                *reinterpret_cast<typename Vec2B<TO>::v4*>(outp + ooff[it]) = o;
             } else {
                 *reinterpret_cast<float4*>(outp + ooff[it]) = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -744,6 +754,15 @@ int launch_p3(const GemmArgs& a0, hipStream_t s) {
             return r ? launch_p3_inst<TI, TO, CFSAR_ACT_NONE, true, false>(a, s)
                      : launch_p3_inst<TI, TO, CFSAR_ACT_NONE, false, false>(a, s);
     }
+}
+
+// fp16 output (the bf16 mode's residual stream): no activation + residual, with or without the patch-embed row remap
+int launch_p3_f16(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_n = (a.N + BN2 - 1) / BN2;
+    if (a.act != CFSAR_ACT_NONE || !a.res) return -2;
+    if (a.row_group > 0 || a.res_mod > 0) return launch_p3_inst<__bf16, _Float16, CFSAR_ACT_NONE, true, true>(a, s);
+    return launch_p3_inst<__bf16, _Float16, CFSAR_ACT_NONE, true, false>(a, s);
 }
 
 // ============================================================================================================
@@ -1489,6 +1508,16 @@ int launch_p12(const GemmArgs& a0, hipStream_t s) {
     return r ? launch_p12_inst<TO, CFSAR_ACT_NONE, true>(a, s) : launch_p12_inst<TO, CFSAR_ACT_NONE, false>(a, s);
 }
 
+// fp16 output (the bf16 mode's residual stream): only the no-activation + residual form exists
+static int launch_p12_f16(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_n = (a.N + BN4 - 1) / BN4;
+    a.ntiles = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
+    if (a.row_group > 0 || a.res_mod > 0 || a.act != CFSAR_ACT_NONE || !a.res || a.K % 64 != 0) return -2;
+    if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32)) return -2;
+    return launch_p12_inst<_Float16, CFSAR_ACT_NONE, true>(a, s);
+}
+
 // dev tool (not in the public header): device buffer of 8 x u64 per 256x256 tile for the p6 phase timestamps; NULL = off
 extern "C" void cfsar_debug_set_gemm_trace(void* buf) { g_trace = static_cast<unsigned long long*>(buf); }
 // dev tool (not in the public header): override CFSAR_GEMM_VARIANT / CFSAR_GEMM_DEBUG at run time; -1 = use the environment
@@ -1501,24 +1530,27 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     CFSAR_REQUIRE(A && W && out, "cfsar_gemm: null operand");
     CFSAR_REQUIRE(M > 0 && N > 0 && K > 0, "cfsar_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     CFSAR_REQUIRE(in_dtype == CFSAR_F32 || in_dtype == CFSAR_BF16, "cfsar_gemm: bad in_dtype %d", in_dtype);
-    CFSAR_REQUIRE(out_dtype == CFSAR_F32 || out_dtype == CFSAR_BF16, "cfsar_gemm: bad out_dtype %d", out_dtype);
+    CFSAR_REQUIRE(out_dtype == CFSAR_F32 || out_dtype == CFSAR_BF16 || out_dtype == CFSAR_F16, "cfsar_gemm: bad out_dtype %d", out_dtype);
+    // fp16 output = the residual-stream update of the bf16 mode: bf16 operands, no activation, a residual
+    CFSAR_REQUIRE(out_dtype != CFSAR_F16 || (in_dtype == CFSAR_BF16 && act == CFSAR_ACT_NONE && residual),
+                  "cfsar_gemm: fp16 output needs bf16 operands, no activation and a residual");
     const int esz = in_dtype == CFSAR_BF16 ? 2 : 4;
     const int bk = ROWB / esz;
     CFSAR_REQUIRE(K % bk == 0, "cfsar_gemm: K=%d must be a multiple of %d for this dtype", K, bk);
     CFSAR_REQUIRE(N % 4 == 0, "cfsar_gemm: N=%d must be a multiple of 4", N);
     CFSAR_REQUIRE((lda * esz) % 16 == 0 && (ldw * esz) % 16 == 0, "cfsar_gemm: lda/ldw rows must be 16-byte aligned");
     CFSAR_REQUIRE(lda >= K && ldw >= K && ldo >= N, "cfsar_gemm: leading dimension too small");
-    CFSAR_REQUIRE((ldo * (out_dtype == CFSAR_BF16 ? 2 : 4)) % 8 == 0, "cfsar_gemm: ldo alignment");
+    CFSAR_REQUIRE((ldo * (out_dtype == CFSAR_F32 ? 4 : 2)) % 8 == 0, "cfsar_gemm: ldo alignment");
     CFSAR_REQUIRE(!residual || (ldr >= N && ldr % 4 == 0), "cfsar_gemm: bad ldr");
     CFSAR_REQUIRE(act >= 0 && act <= 2, "cfsar_gemm: bad act %d", act);
-    CFSAR_REQUIRE(res_dtype == CFSAR_F32 || res_dtype == CFSAR_BF16, "cfsar_gemm: bad res_dtype %d", res_dtype);
+    CFSAR_REQUIRE(res_dtype == CFSAR_F32 || res_dtype == CFSAR_BF16 || res_dtype == CFSAR_F16, "cfsar_gemm: bad res_dtype %d", res_dtype);
     GemmArgs a;
     a.A = static_cast<const char*>(A);
     a.W = static_cast<const char*>(W);
     a.out = out;
     a.bias = bias;
     a.res = residual;
-    a.res_bf16 = res_dtype == CFSAR_BF16;
+    a.res_kind = res_dtype == CFSAR_BF16 ? 1 : (res_dtype == CFSAR_F16 ? 2 : 0);
     a.relu = relu;
     a.M = M; a.N = N; a.K = K;
     a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.ldr = ldr;
@@ -1544,8 +1576,16 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     // p12 measured fastest on all four ViT GEMMs (M = 252 160, same box, interleaved: QKV 888 vs 960 us (p10), out_proj 457 vs
     // 476, c_fc 1 288 vs 1 409 (p6), c_proj 1 143 vs 1 178) and on the RN50 1x1 convs with N >= 256 (tools/rn_gemm_ab.py).
     if (in_dtype == CFSAR_BF16 && (forced == 12 || (forced == 0 && tiles4 >= 240 && N >= 256))) {
-        const int rc = out_dtype == CFSAR_BF16 ? launch_p12<__bf16>(a, s) : launch_p12<float>(a, s);
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p12<__bf16>(a, s)
+                       : out_dtype == CFSAR_F16 ? launch_p12_f16(a, s) : launch_p12<float>(a, s);
         if (rc != -2) return rc;
+    }
+    if (out_dtype == CFSAR_F16) {                    // only p12, p3 and v1 are instantiated for the fp16 stream
+        if (M >= 1024) {
+            const int rc = launch_p3_f16(a, s);
+            if (rc != -2) return rc;
+        }
+        return launch<__bf16, _Float16>(a, s);
     }
     if (in_dtype == CFSAR_BF16 && forced == 10) {
         const int rc = out_dtype == CFSAR_BF16 ? launch_p10<__bf16, false>(a, s) : launch_p10<float, false>(a, s);
@@ -1604,7 +1644,7 @@ extern "C" int cfsar_conv3x3_nhwc(const void* in, const void* W, void* out, cons
     a.out = out;
     a.bias = bias;
     a.res = residual;
-    a.res_bf16 = res_dtype == CFSAR_BF16;
+    a.res_kind = res_dtype == CFSAR_BF16 ? 1 : (res_dtype == CFSAR_F16 ? 2 : 0);
     a.relu = relu;
     a.M = (int)M; a.N = Cout; a.K = ldw;
     a.lda = C; a.ldw = ldw; a.ldo = ldo; a.ldr = ldr;

@@ -39,14 +39,15 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ f
     }
 }
 
-__global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls,
+template <typename TX>
+__global__ __launch_bounds__(256) void cls_rows_kernel(TX* __restrict__ x, const float* __restrict__ cls,
                                                        const float* __restrict__ pos, int F, int ntok, int D) {
     const long long total = (long long)F * D;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long f = i / D;
         const int d = (int)(i - f * D);
-        x[f * (long long)ntok * D + d] = cls[d] + pos[d];
+        x[f * (long long)ntok * D + d] = (TX)(cls[d] + pos[d]);
     }
 }
 
@@ -93,41 +94,62 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __
 // wavefront-shuffle reductions, vectorised 16-byte loads / 8- or 16-byte stores.  Each wave handles RPW rows at once so
 // that 2x the loads are in flight per wave (the kernel is HBM-bound: 4 B in + 2 B out per element in bf16 mode).
 constexpr int LN_MAXV = 16;
-template <typename TO, int NV, int RPW>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long in_stride,
+// One wave normalises RPW rows; a lane owns NV vectors of EPV = 16 / sizeof(TI) consecutive elements per row (16-byte loads:
+// 4 floats or 8 halfs), statistics and arithmetic in fp32 (two-pass variance on the registers), 16-byte stores where the
+// output type allows.  TI: float | _Float16 (the fp16 residual stream of the bf16 mode); TO: float | __bf16 | _Float16.
+template <typename TI, typename TO, int NV, int RPW>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, long long in_stride,
                                                         TO* __restrict__ out, long long out_stride,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         int rows, int D, float eps) {
+    constexpr int EPV = 16 / (int)sizeof(TI);
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
     if (row0 >= rows) return;
-    const int nv = D >> 2;   // float4 count
-    float4 v[RPW][NV];
+    const int nv = D / EPV;   // vectors per row
+    float v[RPW][NV][EPV];
     float s[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = row0 + r < rows ? row0 + r : rows - 1;
-        const float* xr = x + (long long)row * in_stride;
+        const TI* xr = x + (long long)row * in_stride;
         s[r] = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int j = i * 64 + lane;
-            if (j < nv) v[r][i] = *reinterpret_cast<const float4*>(xr + 4 * j);
+            if (j < nv) {
+                if constexpr (sizeof(TI) == 2) {
+                    const f16x8 hv = *reinterpret_cast<const f16x8*>(xr + EPV * j);
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) v[r][i][e] = (float)hv[e];
+                } else {
+                    const float4 fv = *reinterpret_cast<const float4*>(xr + EPV * j);
+                    v[r][i][0] = fv.x; v[r][i][1] = fv.y; v[r][i][2] = fv.z; v[r][i][3] = fv.w;
+                }
+            }
         }
     }
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-            if (i * 64 + lane < nv) s[r] += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+            if (i * 64 + lane < nv) {
+#pragma unroll
+                for (int e = 0; e < EPV; e += 4) s[r] += (v[r][i][e] + v[r][i][e + 1]) + (v[r][i][e + 2] + v[r][i][e + 3]);
+            }
     }
-    float4 wv[NV], bv[NV];
+    float wv[NV][EPV], bv[NV][EPV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int j = i * 64 + lane;
         if (j < nv) {
-            wv[i] = *reinterpret_cast<const float4*>(w + 4 * j);
-            bv[i] = *reinterpret_cast<const float4*>(b + 4 * j);
+#pragma unroll
+            for (int e = 0; e < EPV; e += 4) {
+                const float4 w4 = *reinterpret_cast<const float4*>(w + EPV * j + e);
+                const float4 b4 = *reinterpret_cast<const float4*>(b + EPV * j + e);
+                wv[i][e] = w4.x; wv[i][e + 1] = w4.y; wv[i][e + 2] = w4.z; wv[i][e + 3] = w4.w;
+                bv[i][e] = b4.x; bv[i][e + 1] = b4.y; bv[i][e + 2] = b4.z; bv[i][e + 3] = b4.w;
+            }
         }
     }
 #pragma unroll
@@ -137,8 +159,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             if (i * 64 + lane < nv) {
-                const float a = v[r][i].x - mean, bq = v[r][i].y - mean, c = v[r][i].z - mean, d = v[r][i].w - mean;
-                ss += (a * a + bq * bq) + (c * c + d * d);
+#pragma unroll
+                for (int e = 0; e < EPV; e += 4) {
+                    const float a = v[r][i][e] - mean, bq = v[r][i][e + 1] - mean, c = v[r][i][e + 2] - mean, d = v[r][i][e + 3] - mean;
+                    ss += (a * a + bq * bq) + (c * c + d * d);
+                }
             }
         }
         const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
@@ -148,32 +173,128 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         for (int i = 0; i < NV; ++i) {
             const int j = i * 64 + lane;
             if (j < nv) {
-                float4 o;
-                o.x = (v[r][i].x - mean) * rstd * wv[i].x + bv[i].x;
-                o.y = (v[r][i].y - mean) * rstd * wv[i].y + bv[i].y;
-                o.z = (v[r][i].z - mean) * rstd * wv[i].z + bv[i].z;
-                o.w = (v[r][i].w - mean) * rstd * wv[i].w + bv[i].w;
-                if constexpr (sizeof(TO) == 2) {
-                    bf16x4 ob;
-                    ob[0] = (__bf16)o.x; ob[1] = (__bf16)o.y; ob[2] = (__bf16)o.z; ob[3] = (__bf16)o.w;
-                    *reinterpret_cast<bf16x4*>(orow + 4 * j) = ob;
+                float o[EPV];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o[e] = (v[r][i][e] - mean) * rstd * wv[i][e] + bv[i][e];
+                if constexpr (sizeof(TO) == 2 && EPV == 8) {
+                    typename Vec2B<TO>::v8 ob;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ob[e] = (TO)o[e];
+                    *reinterpret_cast<typename Vec2B<TO>::v8*>(orow + EPV * j) = ob;
+                } else if constexpr (sizeof(TO) == 2) {
+                    typename Vec2B<TO>::v4 ob;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ob[e] = (TO)o[e];
+                    *reinterpret_cast<typename Vec2B<TO>::v4*>(orow + EPV * j) = ob;
                 } else {
-                    *reinterpret_cast<float4*>(orow + 4 * j) = o;
+#pragma unroll
+                    for (int e = 0; e < EPV; e += 4)
+                        *reinterpret_cast<float4*>(orow + EPV * j + e) = make_float4(o[e], o[e + 1], o[e + 2], o[e + 3]);
                 }
             }
         }
     }
 }
 
-template <typename TO>
-int launch_ln(const float* x, long long in_stride, TO* out, long long out_stride, const float* w, const float* b, int rows,
+// fp16 rows whose vector count is not a multiple of 64 (D = 768 -> 96 vectors of 8 halfs) leave half of the lanes idle in the
+// last load of the kernel above.  Here one wave takes TWO rows as one flat run of 2*nv vectors (192 = 3 x 64 for D = 768): every
+// load and store instruction is full; the row statistics are two masked wave reductions.  Needs in_stride == D (dense rows).
+template <typename TO, int NVT>
+__global__ __launch_bounds__(256) void layernorm_f16_pair_kernel(const _Float16* __restrict__ x, TO* __restrict__ out,
+                                                                 long long out_stride, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= rows) return;
+    const int nv = D >> 3;
+    const int total = (row0 + 1 < rows ? 2 : 1) * nv;
+    const _Float16* xr = x + (long long)row0 * D;
+    float v[NVT][8];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NVT; ++i) {
+        const int k = i * 64 + lane;
+        if (k < total) {
+            const f16x8 hv = *reinterpret_cast<const f16x8*>(xr + 8 * k);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[i][e] = (float)hv[e];
+                t += v[i][e];
+            }
+            if (k < nv) s0 += t;
+            else s1 += t;
+        }
+    }
+    const float mean0 = wave_sum(s0) / (float)D, mean1 = wave_sum(s1) / (float)D;
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NVT; ++i) {
+        const int k = i * 64 + lane;
+        if (k < total) {
+            const float m = k < nv ? mean0 : mean1;
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[i][e] - m;
+                t += d * d;
+            }
+            if (k < nv) q0 += t;
+            else q1 += t;
+        }
+    }
+    const float rstd0 = 1.0f / sqrtf(wave_sum(q0) / (float)D + eps), rstd1 = 1.0f / sqrtf(wave_sum(q1) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NVT; ++i) {
+        const int k = i * 64 + lane;
+        if (k < total) {
+            const bool first = k < nv;
+            const int c = (first ? k : k - nv) * 8;                         // column of the vector
+            const float m = first ? mean0 : mean1, rs = first ? rstd0 : rstd1;
+            const float4 w0 = *reinterpret_cast<const float4*>(w + c), w1 = *reinterpret_cast<const float4*>(w + c + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(b + c), b1 = *reinterpret_cast<const float4*>(b + c + 4);
+            const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - m) * rs * wv[e] + bv[e];
+            TO* op = out + (long long)(row0 + (first ? 0 : 1)) * out_stride + c;
+            if constexpr (sizeof(TO) == 2) {
+                typename Vec2B<TO>::v8 ob;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ob[e] = (TO)o[e];
+                *reinterpret_cast<typename Vec2B<TO>::v8*>(op) = ob;
+            } else {
+                *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        }
+    }
+}
+
+template <typename TI, typename TO>
+int launch_ln(const TI* x, long long in_stride, TO* out, long long out_stride, const float* w, const float* b, int rows,
               int D, float eps, hipStream_t s) {
-    const int nvl = (D / 4 + 63) / 64;          // float4 per lane
+    constexpr int EPV = 16 / (int)sizeof(TI);
+    const int nvl = (D / EPV + 63) / 64;          // 16-byte vectors per lane
+    if constexpr (sizeof(TI) == 2) {
+        const int nv = D / 8;
+        if (in_stride == D && nv % 64 != 0 && (2 * nv) % 64 == 0 && 2 * nv / 64 <= 6) {       // e.g. D = 768: 3 full loads per row pair
+            const dim3 grid((unsigned)((rows + 7) / 8));
+            switch (2 * nv / 64) {
+                case 1: hipLaunchKernelGGL((layernorm_f16_pair_kernel<TO, 1>), grid, dim3(256), 0, s, x, out, out_stride, w, b, rows, D, eps); break;
+                case 3: hipLaunchKernelGGL((layernorm_f16_pair_kernel<TO, 3>), grid, dim3(256), 0, s, x, out, out_stride, w, b, rows, D, eps); break;
+                default: hipLaunchKernelGGL((layernorm_f16_pair_kernel<TO, 5>), grid, dim3(256), 0, s, x, out, out_stride, w, b, rows, D, eps); break;
+            }
+            return cfsar_check_launch("cfsar_layernorm");
+        }
+    }
 #define CFSAR_LN(NV, RPW)                                                                                             \
-    hipLaunchKernelGGL((layernorm_kernel<TO, NV, RPW>), dim3((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), dim3(256), 0, \
+    hipLaunchKernelGGL((layernorm_kernel<TI, TO, NV, RPW>), dim3((unsigned)((rows + 4 * RPW - 1) / (4 * RPW))), dim3(256), 0, \
                        s, x, in_stride, out, out_stride, w, b, rows, D, eps)
-    if (nvl <= 1) CFSAR_LN(1, 4);
-    else if (nvl <= 2) CFSAR_LN(2, 2);
+    constexpr int RM = 1;
+    if (nvl <= 1) CFSAR_LN(1, 4 * RM);
+    else if (nvl <= 2) CFSAR_LN(2, 2 * RM);
     else if (nvl <= 3) CFSAR_LN(3, 2);
     else if (nvl <= 4) CFSAR_LN(4, 2);
     else if (nvl <= 8) CFSAR_LN(8, 1);
@@ -210,9 +331,24 @@ extern "C" int cfsar_cls_rows(float* x, const float* cls, const float* pos, int 
     CFSAR_REQUIRE(x && cls && pos && F > 0 && ntok > 0 && D > 0, "cfsar_cls_rows: bad arguments");
     const long long total = (long long)F * D;
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(cls_rows_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, cls, pos, F,
+    hipLaunchKernelGGL(cls_rows_kernel<float>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, cls, pos, F,
                        ntok, D);
     return cfsar_check_launch("cfsar_cls_rows");
+}
+
+extern "C" int cfsar_cls_rows_ex(void* x, int x_dtype, const float* cls, const float* pos, int F, int ntok, int D,
+                                 cfsar_stream_t stream) {
+    CFSAR_REQUIRE(x && cls && pos && F > 0 && ntok > 0 && D > 0, "cfsar_cls_rows_ex: bad arguments");
+    const long long total = (long long)F * D;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (x_dtype == CFSAR_F32)
+        hipLaunchKernelGGL(cls_rows_kernel<float>, dim3(blocks), dim3(256), 0, s, static_cast<float*>(x), cls, pos, F, ntok, D);
+    else if (x_dtype == CFSAR_F16)
+        hipLaunchKernelGGL(cls_rows_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, static_cast<_Float16*>(x), cls, pos, F, ntok, D);
+    else
+        return cfsar_fail("cfsar_cls_rows_ex: bad dtype %d", x_dtype);
+    return cfsar_check_launch("cfsar_cls_rows_ex");
 }
 
 extern "C" int cfsar_preprocess_frames(const uint8_t* frames, float* out, int T, int H, int W, int scale_h, int scale_w,
@@ -230,18 +366,29 @@ extern "C" int cfsar_preprocess_frames(const uint8_t* frames, float* out, int T,
     return cfsar_check_launch("cfsar_preprocess_frames");
 }
 
-extern "C" int cfsar_layernorm(const float* x, int64_t in_stride, void* out, int64_t out_stride, int out_dtype,
-                               const float* weight, const float* bias, int rows, int D, float eps,
-                               cfsar_stream_t stream) {
+extern "C" int cfsar_layernorm_ex(const void* x, int in_dtype, int64_t in_stride, void* out, int64_t out_stride, int out_dtype,
+                                  const float* weight, const float* bias, int rows, int D, float eps, cfsar_stream_t stream) {
     CFSAR_REQUIRE(x && out && weight && bias, "cfsar_layernorm: null pointer");
     CFSAR_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4 * 64 * LN_MAXV, "cfsar_layernorm: bad D=%d", D);
     CFSAR_REQUIRE(in_stride % 4 == 0 && out_stride % 4 == 0, "cfsar_layernorm: strides must be multiples of 4");
+    CFSAR_REQUIRE(in_dtype != CFSAR_F16 || (D % 8 == 0 && in_stride % 8 == 0 && out_stride % 8 == 0), "cfsar_layernorm: fp16 input needs D and strides to be multiples of 8");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (out_dtype == CFSAR_BF16)
-        return launch_ln<__bf16>(x, (long long)in_stride, static_cast<__bf16*>(out), (long long)out_stride, weight, bias,
-                                 rows, D, eps, s);
-    if (out_dtype == CFSAR_F32)
-        return launch_ln<float>(x, (long long)in_stride, static_cast<float*>(out), (long long)out_stride, weight, bias, rows,
-                                D, eps, s);
-    return cfsar_fail("cfsar_layernorm: bad dtype %d", out_dtype);
+    const long long is = in_stride, os = out_stride;
+    if (in_dtype == CFSAR_F32) {
+        const float* xi = static_cast<const float*>(x);
+        if (out_dtype == CFSAR_BF16) return launch_ln<float, __bf16>(xi, is, static_cast<__bf16*>(out), os, weight, bias, rows, D, eps, s);
+        if (out_dtype == CFSAR_F32) return launch_ln<float, float>(xi, is, static_cast<float*>(out), os, weight, bias, rows, D, eps, s);
+    } else if (in_dtype == CFSAR_F16) {
+        const _Float16* xi = static_cast<const _Float16*>(x);
+        if (out_dtype == CFSAR_BF16) return launch_ln<_Float16, __bf16>(xi, is, static_cast<__bf16*>(out), os, weight, bias, rows, D, eps, s);
+        if (out_dtype == CFSAR_F16) return launch_ln<_Float16, _Float16>(xi, is, static_cast<_Float16*>(out), os, weight, bias, rows, D, eps, s);
+        if (out_dtype == CFSAR_F32) return launch_ln<_Float16, float>(xi, is, static_cast<float*>(out), os, weight, bias, rows, D, eps, s);
+    }
+    return cfsar_fail("cfsar_layernorm: unsupported dtype pair in=%d out=%d", in_dtype, out_dtype);
+}
+
+extern "C" int cfsar_layernorm(const float* x, int64_t in_stride, void* out, int64_t out_stride, int out_dtype,
+                               const float* weight, const float* bias, int rows, int D, float eps,
+                               cfsar_stream_t stream) {
+    return cfsar_layernorm_ex(x, CFSAR_F32, in_stride, out, out_stride, out_dtype, weight, bias, rows, D, eps, stream);
 }

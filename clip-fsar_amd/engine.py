@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 
 from . import hip
@@ -27,13 +29,22 @@ def _round_up(x, m):
 class HipViT:
     """CLIP VisionTransformer.forward (reference few_shot.py:671-688) on the HIP kernels."""
 
-    def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda"):
+    def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda", stream_dtype=None):
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
         self.arch = dict(arch)
         self.precision = precision
         self.dev = torch.device(device)
         self.cd = torch.bfloat16 if precision == "bf16" else torch.float32
+        # residual stream: fp32 in the validation mode.  The bf16 mode keeps it in IEEE fp16, as CLIP's own GPU path does
+        # (fp16 model, few_shot.py:605-611 casts LayerNorm to fp32 and back): out_proj / c_proj / LayerNorm are bound by the
+        # stream's bytes, and on top of bf16 operands the fp16 rounding is not measurable (feature rms error 0.0064 with an
+        # fp16 stream vs 0.0067 with an fp32 one, against 0.0092 for a bf16 stream; DESIGN.md "Numerics modes").
+        if stream_dtype is None:
+            stream_dtype = os.environ.get("CFSAR_STREAM", "fp16" if precision == "bf16" else "fp32")
+        if stream_dtype not in ("fp16", "fp32") or (precision == "fp32" and stream_dtype != "fp32"):
+            raise ValueError("stream_dtype must be 'fp32' (any precision) or 'fp16' (bf16 precision only)")
+        self.xd = torch.float16 if stream_dtype == "fp16" else torch.float32
         D, P = arch["width"], arch["patch"]
         if D != arch["heads"] * 64:
             raise ValueError("HipViT needs head_dim == 64 (width %d, heads %d)" % (D, arch["heads"]))
@@ -77,7 +88,7 @@ class HipViT:
             M, D, cd, dev = F_ * self.ntok, self.D, self.cd, self.dev
             self._ws = dict(
                 patches=torch.empty(F_ * (self.ntok - 1), self.kpad, device=dev, dtype=cd),
-                x=torch.empty(M, D, device=dev, dtype=torch.float32),
+                x=torch.empty(M, D, device=dev, dtype=self.xd),
                 h=torch.empty(M, D, device=dev, dtype=cd),
                 qkv=torch.empty(M, 3 * D, device=dev, dtype=cd),
                 o=torch.empty(M, D, device=dev, dtype=cd),

@@ -10,7 +10,7 @@ import os
 
 import torch  # noqa: F401  (imported first so that torch's libamdhip64.so.7 is the HIP runtime the library binds to)
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -26,6 +26,8 @@ SIGNATURES = {
     "cfsar_im2col_patches": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_cls_rows": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_layernorm": [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p],
+    "cfsar_layernorm_ex": [_c_p, _c_int, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p],
+    "cfsar_cls_rows_ex": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_gemm": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 15 + [_c_p],
     "cfsar_gemm_ex": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 17 + [_c_p],
     "cfsar_nchw_to_nhwc": [_c_p, _c_p] + [_c_int] * 5 + [_c_p],
@@ -91,6 +93,8 @@ def _code(dtype):
         return F32
     if dtype == torch.bfloat16:
         return BF16
+    if dtype == torch.float16:
+        return F16
     raise RuntimeError("clip_fsar_amd.hip: unsupported dtype %s" % dtype)
 
 
@@ -121,16 +125,16 @@ def im2col_patches(frames, out, patch):
 
 
 def cls_rows(x, cls, pos, F_, ntok, D):
-    _check(lib().cfsar_cls_rows(_dev(x, torch.float32, "x"), _dev(cls, torch.float32, "cls"),
-                                _dev(pos, torch.float32, "pos"), F_, ntok, D, _stream()), "cfsar_cls_rows")
+    _check(lib().cfsar_cls_rows_ex(_dev(x, None, "x"), _code(x.dtype), _dev(cls, torch.float32, "cls"),
+                                   _dev(pos, torch.float32, "pos"), F_, ntok, D, _stream()), "cfsar_cls_rows_ex")
 
 
 def layernorm(x, out, weight, bias, rows, D, in_stride=None, out_stride=None, eps=1e-5):
     in_stride = D if in_stride is None else in_stride
     out_stride = D if out_stride is None else out_stride
-    _check(lib().cfsar_layernorm(_dev(x, torch.float32, "x"), in_stride, _dev(out, None, "out"), out_stride,
-                                 _code(out.dtype), _dev(weight, torch.float32, "weight"),
-                                 _dev(bias, torch.float32, "bias"), rows, D, eps, _stream()), "cfsar_layernorm")
+    _check(lib().cfsar_layernorm_ex(_dev(x, None, "x"), _code(x.dtype), in_stride, _dev(out, None, "out"), out_stride,
+                                    _code(out.dtype), _dev(weight, torch.float32, "weight"),
+                                    _dev(bias, torch.float32, "bias"), rows, D, eps, _stream()), "cfsar_layernorm_ex")
 
 
 def gemm(A, W, out, bias=None, residual=None, act=ACT_NONE, M=None, N=None, K=None, lda=None, ldw=None, ldo=None,

@@ -12,7 +12,7 @@
  *   - `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); all work is enqueued on it and
  *     no entry point synchronises with the host;
  *   - return value 0 = success; non-zero = error, message via cfsar_last_error() (thread-local);
- *   - dtype codes: CFSAR_F32 = 0, CFSAR_BF16 = 1;  matrices are row-major with explicit leading dimensions
+ *   - dtype codes: CFSAR_F32 = 0, CFSAR_BF16 = 1, CFSAR_F16 = 2 (where stated);  matrices are row-major with explicit leading dimensions
  *     (in elements).
  */
 #ifndef CLIPFSAR_HIP_H
@@ -26,6 +26,7 @@ extern "C" {
 
 #define CFSAR_F32 0
 #define CFSAR_BF16 1
+#define CFSAR_F16 2 /* IEEE half: GEMM output / residual and LayerNorm input only (the residual stream of the bf16 mode) */
 
 #define CFSAR_ACT_NONE 0
 #define CFSAR_ACT_QUICKGELU 1 /* x*sigmoid(1.702x), few_shot.py:614-616 */
@@ -53,12 +54,18 @@ int cfsar_im2col_patches(const float* frames, void* out, int out_dtype, int F, i
 
 /* ---- A2 stage 3: class-token rows.  x[f*ntok*D + d] = cls[d] + pos[d]  (few_shot.py:675-676). */
 int cfsar_cls_rows(float* x, const float* cls, const float* pos, int F, int ntok, int D, cfsar_stream_t stream);
+/* Same for a residual stream of dtype x_dtype (CFSAR_F32 | CFSAR_F16). */
+int cfsar_cls_rows_ex(void* x, int x_dtype, const float* cls, const float* pos, int F, int ntok, int D, cfsar_stream_t stream);
 
 /* ---- A3 LayerNorm over the last dim (fp32 statistics, biased variance, eps inside the sqrt), few_shot.py:605-611
  * (ln_pre/ln_1/ln_2/ln_post) and :971-977 (context2 pre-norm).  x rows at stride in_stride (elements), out rows at
  * out_stride; out dtype f32 or bf16.  D % 4 == 0, D <= 4096.  In-place (out == x, f32) is allowed. */
 int cfsar_layernorm(const float* x, int64_t in_stride, void* out, int64_t out_stride, int out_dtype,
                     const float* weight, const float* bias, int rows, int D, float eps, cfsar_stream_t stream);
+/* Same with the input dtype explicit: in_dtype CFSAR_F32 (out F32 | BF16) or CFSAR_F16 (out BF16 | F16 | F32) -- the fp16
+ * residual stream of the bf16 mode (statistics and arithmetic stay fp32). */
+int cfsar_layernorm_ex(const void* x, int in_dtype, int64_t in_stride, void* out, int64_t out_stride, int out_dtype,
+                       const float* weight, const float* bias, int rows, int D, float eps, cfsar_stream_t stream);
 
 /* ---- A5/A6/A8/A11 dense projections: out = act(A . W^T + bias) + residual, MFMA (v_mfma_f32_32x32x16_bf16 for
  * bf16 inputs, v_mfma_f32_32x32x2_f32 for f32 inputs), fp32 accumulation.

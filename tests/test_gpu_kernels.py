@@ -429,3 +429,42 @@ def test_stem_conv_direct(hip, Co, H, W_):
     out16 = torch.empty(3 * Ho * Wo, Co, device="cuda", dtype=torch.bfloat16)
     hip.stem_conv(x.cuda(), w.cuda(), b.cuda(), out16)
     assert maxdiff(out16.float().cpu().reshape(ref.shape), ref) < 2e-2
+
+
+def test_fp16_residual_stream_ops(hip):
+    """The fp16 residual stream of the bf16 mode: GEMM with fp16 output + fp16 (or fp32) residual on every kernel that serves it
+    (p12 / p3 / v1, incl. the patch-embed row scatter), LayerNorm with fp16 input (bf16 / fp16 / fp32 output), cls rows."""
+    for (M, N, K) in [(1300, 768, 768), (200, 260, 192), (61 * 256, 1024, 128)]:       # p3, v1, p12 (61 x 4 = 244 tiles)
+        A = _rand(M, K, seed=51).to(torch.bfloat16)
+        W = _rand(N, K, seed=52, scale=K ** -0.5).to(torch.bfloat16)
+        bias = _rand(N, seed=53)
+        x0 = _rand(M, N, seed=54, scale=4.0).to(torch.float16)
+        ref = A.float() @ W.float().t() + bias + x0.float()
+        x = x0.clone().cuda()
+        hip.gemm(A.cuda(), W.cuda(), x, bias=bias.cuda(), residual=x)                    # in place on the stream
+        assert x.dtype == torch.float16
+        assert maxdiff(x.float().cpu(), ref) < 2e-2 * max(1.0, float(ref.abs().max())), (M, N, K)
+    # patch-embed form: fp16 output rows scattered behind each frame's class token, fp32 residual (positional embedding)
+    Fn, npatch, D, Kp = 3, 49, 256, 192
+    P = _rand(Fn * npatch, Kp, seed=55).to(torch.bfloat16)
+    Wp = _rand(D, Kp, seed=56, scale=Kp ** -0.5).to(torch.bfloat16)
+    pos = _rand(npatch + 1, D, seed=57)
+    xs = torch.zeros(Fn * (npatch + 1), D, device="cuda", dtype=torch.float16)
+    hip.gemm(P.cuda(), Wp.cuda(), xs, residual=pos.cuda(), M=Fn * npatch, N=D, K=Kp, ldo=D, ldr=D, row_group=npatch, row_gap=1,
+             row_off=1, res_mod=npatch, res_off=1)
+    refp = (P.float() @ Wp.float().t()).reshape(Fn, npatch, D) + pos[1:]
+    got = xs.float().cpu().reshape(Fn, npatch + 1, D)
+    assert maxdiff(got[:, 1:], refp) < 2e-2 * max(1.0, float(refp.abs().max()))
+    assert float(got[:, 0].abs().max()) == 0.0
+    cls = _rand(D, seed=58)
+    hip.cls_rows(xs, cls.cuda(), pos.cuda(), Fn, npatch + 1, D)
+    assert maxdiff(xs.float().cpu().reshape(Fn, npatch + 1, D)[:, 0], (cls + pos[0]).expand(Fn, D)) < 4e-3
+    # LayerNorm on fp16 rows
+    rows, D = 333, 768
+    xh = _rand(rows, D, seed=59, scale=3.0).to(torch.float16)
+    w, b = _rand(D, seed=60), _rand(D, seed=61)
+    ref_ln = torch.nn.functional.layer_norm(xh.float(), (D,), w, b, 1e-5)
+    for od, tol in ((torch.float32, 1e-4), (torch.float16, 4e-3), (torch.bfloat16, 3e-2)):
+        out = torch.empty(rows, D, device="cuda", dtype=od)
+        hip.layernorm(xh.cuda(), out, w.cuda(), b.cuda(), rows, D)
+        assert maxdiff(out.float().cpu(), ref_ln) < tol * max(1.0, float(ref_ln.abs().max())), od

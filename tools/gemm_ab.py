@@ -22,8 +22,9 @@ for tag, n, k in shapes:
     A = torch.randn(M, k, device=dev).to(torch.bfloat16)
     W = (torch.randn(n, k, device=dev) * k ** -0.5).to(torch.bfloat16)
     bias = torch.randn(n, device=dev)
-    out = torch.empty(M, n, device=dev, dtype=torch.bfloat16 if tag in ("qkv", "fc") else torch.float32)
-    res = out if out.dtype == torch.float32 else None
+    sd = torch.float16 if os.environ.get("AB_STREAM") == "fp16" else torch.float32      # residual-stream dtype
+    out = torch.empty(M, n, device=dev, dtype=torch.bfloat16 if tag in ("qkv", "fc") else sd)
+    res = out if tag in ("out", "proj") else None
     act = hip.ACT_QUICKGELU if tag == "fc" else hip.ACT_NONE
     times = {c: [] for c in cfgs}
     for rnd in range(ROUNDS + 1):

@@ -41,6 +41,9 @@ def main():
     w = torch.ones(D, device=dev); b = torch.zeros(D, device=dev)
     us = timeit(lambda: hip.layernorm(x, h, w, b, M, D))
     print("layernorm f32->bf16 rows=%d  %.1f us  %.1f GB/s" % (M, us, M * D * 6 / us / 1e3))
+    xh = x.to(torch.float16)
+    us = timeit(lambda: hip.layernorm(xh, h, w, b, M, D))
+    print("layernorm f16->bf16 rows=%d  %.1f us  %.1f GB/s" % (M, us, M * D * 4 / us / 1e3))
     qkv = torch.randn(M, 3 * D, device=dev).to(torch.bfloat16)
     o = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
     us = timeit(lambda: hip.vit_attention(qkv, o, F_, N, D, 12))
