@@ -247,6 +247,9 @@ def main():
             "config": {"workload": cfgsel["name"] + ", random-init CLIP weights, synthetic structured frames",
                        "episodes_per_step_per_gpu": B, "frames_per_episode": frames_per_ep,
                        "tflop_per_episode": round(tflop_per_ep, 4), "precision": args.precision,
+                       "numerics": ("bf16 MFMA operands, fp32 accumulation / LayerNorm + softmax statistics / final projection / "
+                                    "temporal head, fp16 residual stream" + (" (ViT)" if ARCH.startswith("ViT") else " n/a (RN50: bf16 activations)")
+                                    if args.precision == "bf16" else "fp32 throughout"),
                        "parallelism": "episodes sharded over %d rank(s); one all-gather of accuracies" % world},
             "top1_acc_mean": round(float(gathered.mean().item()), 4),
             "end_to_end_vit_tflops_per_gpu": round(eps_per_s / world * tflop_per_ep, 2),
