@@ -1329,14 +1329,17 @@ int launch_p10(const GemmArgs& a0, hipStream_t s) {
 // one wave with those of the other, which is what p10 lacks; the main loop keeps p10's request efficiency, which p6 lacks.
 // Per wave and K tile: 32 MFMAs, 24 fragment reads, 4 + 4 global loads, 4 + 4 LDS writes.
 // ============================================================================================================
-template <typename TO, int ACT, bool HAS_RES>
+// PERSIST: one workgroup per CU walks the virtual block ids b, b + grid, ... (grid % 8 == 0 keeps a workgroup on its XCD's band)
+template <typename TO, int ACT, bool HAS_RES, bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p12(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int nwg = PERSIST ? p.ntiles : (int)gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    for (int b = blockIdx.x; b < nwg; b += PERSIST ? (int)gridDim.x : nwg) {
+    const int xcd = b & 7;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     int tm, tn;
     tile_of(lin, nwg / p.tiles_n, p.tiles_n, tile_group(p, nwg), tm, tn);
@@ -1471,7 +1474,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p12(GemmArgs p) {
     __syncthreads();
     if (p.dbg & 4) {
         if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[3][1][2] + acc[2][0][1];
-        return;
+        if constexpr (PERSIST) continue;
+        else return;
     }
     char* wbuf = smem + wave * EPI_WAVE_BYTES;
 #pragma unroll
@@ -1481,22 +1485,24 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p12(GemmArgs p) {
         if (full) epilogue_lds<TO, ACT, HAS_RES, false, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
         else epilogue_lds<TO, ACT, HAS_RES, false, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
     }
+    if constexpr (PERSIST) __syncthreads();            // the epilogue staging aliases the LDS stages of the next tile
+    }
 }
 
-template <typename TO, int ACT, bool HAS_RES>
+template <typename TO, int ACT, bool HAS_RES, bool PERSIST = false>
 int launch_p12_inst(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p12<TO, ACT, HAS_RES>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p12<TO, ACT, HAS_RES, PERSIST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
         if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel_p12<TO, ACT, HAS_RES>), dim3(a.ntiles), dim3(512), LDS4, s, a);
+    hipLaunchKernelGGL((gemm_kernel_p12<TO, ACT, HAS_RES, PERSIST>), dim3(PERSIST ? 256 : a.ntiles), dim3(512), LDS4, s, a);
     return cfsar_check_launch("cfsar_gemm(p12)");
 }
 
-template <typename TO>
+template <typename TO, bool PERSIST = false>
 int launch_p12(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     a.tiles_n = (a.N + BN4 - 1) / BN4;
@@ -1504,8 +1510,8 @@ int launch_p12(const GemmArgs& a0, hipStream_t s) {
     const bool r = a.res != nullptr;
     if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF || a.K % 64 != 0) return -2;
     if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32)) return -2;   // 32-bit offsets
-    if (a.act == CFSAR_ACT_QUICKGELU) return r ? -2 : launch_p12_inst<TO, CFSAR_ACT_QUICKGELU, false>(a, s);
-    return r ? launch_p12_inst<TO, CFSAR_ACT_NONE, true>(a, s) : launch_p12_inst<TO, CFSAR_ACT_NONE, false>(a, s);
+    if (a.act == CFSAR_ACT_QUICKGELU) return r ? -2 : launch_p12_inst<TO, CFSAR_ACT_QUICKGELU, false, PERSIST>(a, s);
+    return r ? launch_p12_inst<TO, CFSAR_ACT_NONE, true, PERSIST>(a, s) : launch_p12_inst<TO, CFSAR_ACT_NONE, false, PERSIST>(a, s);
 }
 
 // fp16 output (the bf16 mode's residual stream): only the no-activation + residual form exists
@@ -1515,7 +1521,7 @@ static int launch_p12_f16(const GemmArgs& a0, hipStream_t s) {
     a.ntiles = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
     if (a.row_group > 0 || a.res_mod > 0 || a.act != CFSAR_ACT_NONE || !a.res || a.K % 64 != 0) return -2;
     if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32)) return -2;
-    return launch_p12_inst<_Float16, CFSAR_ACT_NONE, true>(a, s);
+    return launch_p12_inst<_Float16, CFSAR_ACT_NONE, true, true>(a, s);
 }
 
 // dev tool (not in the public header): device buffer of 8 x u64 per 256x256 tile for the p6 phase timestamps; NULL = off
@@ -1567,7 +1573,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     hipStream_t s = static_cast<hipStream_t>(stream);
     // CFSAR_GEMM_VARIANT (dev): 0 = auto, 1 = v1 (128x128, also the fp32 path), 2 = p3 (256x128, asm LDS-DMA), 6 = p6 (256x256
     // ping-pong LDS-DMA), 7 = p6 persistent, 10 = p10 (one wave per SIMD, register-staged whole-line requests), 11 = p10
-    // persistent, 12 = p12 (p10's operand path, two waves per SIMD).  auto: p12 for N >= 256 with enough 256x256 tiles to fill
+    // persistent, 12 = p12 (p10's operand path, two waves per SIMD), 13 = p12 persistent.  auto: p12 for N >= 256 with enough 256x256 tiles to fill
     // the chip; otherwise p3 (skinny / short-K bf16 GEMMs: its 256x128 tile wastes less of a narrow N and the 16-byte-per-lane
     // bf16 epilogue fits its register budget, tools/rn_gemm_ab.py) when M >= 1024; v1 below.
     static const int forced_env = [] { const char* e = getenv("CFSAR_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
@@ -1575,6 +1581,13 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     const long tiles4 = (long)((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
     // p12 measured fastest on all four ViT GEMMs (M = 252 160, same box, interleaved: QKV 888 vs 960 us (p10), out_proj 457 vs
     // 476, c_fc 1 288 vs 1 409 (p6), c_proj 1 143 vs 1 178) and on the RN50 1x1 convs with N >= 256 (tools/rn_gemm_ab.py).
+    // 13 = the persistent form (one workgroup per CU walking its tiles: no retire -> dispatch gap; +3 % on QKV / c_fc), the auto
+    // choice from two tiles per CU on; 12 = one workgroup per tile.
+    if (in_dtype == CFSAR_BF16 && (forced == 13 || (forced == 0 && tiles4 >= 512 && N >= 256))) {
+        const int rc = out_dtype == CFSAR_BF16 ? launch_p12<__bf16, true>(a, s)
+                       : out_dtype == CFSAR_F16 ? launch_p12_f16(a, s) : launch_p12<float, true>(a, s);
+        if (rc != -2) return rc;
+    }
     if (in_dtype == CFSAR_BF16 && (forced == 12 || (forced == 0 && tiles4 >= 240 && N >= 256))) {
         const int rc = out_dtype == CFSAR_BF16 ? launch_p12<__bf16>(a, s)
                        : out_dtype == CFSAR_F16 ? launch_p12_f16(a, s) : launch_p12<float>(a, s);
@@ -1603,7 +1616,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
         const int rc = out_dtype == CFSAR_BF16 ? launch_p6<__bf16, false>(a, s) : launch_p6<float, false>(a, s);
         if (rc != -2) return rc;
     }
-    const bool use_p3 = forced == 2 || forced == 6 || forced == 7 || forced == 10 || forced == 11 || forced == 12 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
+    const bool use_p3 = forced == 2 || forced == 6 || forced == 7 || forced == 10 || forced == 11 || forced == 12 || forced == 13 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
     if (use_p3) {
         int rc;
         if (in_dtype == CFSAR_BF16)

@@ -312,7 +312,7 @@ def test_avgpool_and_attnpool_tokens(hip, dtype):
     assert maxdiff(tok.float().cpu(), ref_tok) < (2e-6 if dtype == "f32" else 3e-2)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 6, 7, 10, 11, 12])
+@pytest.mark.parametrize("variant", [1, 2, 6, 7, 10, 11, 12, 13])
 def test_gemm_every_kernel_variant(hip, variant):
     """Each bf16 GEMM kernel kept in gemm.hip (v1 / p3 / p6 / p6-persistent / p10 / p10-persistent / p12; the auto policy
     picks p12, p3 and v1) against the fp32 product of the bf16-rounded operands, on ragged M and N edges, through the
