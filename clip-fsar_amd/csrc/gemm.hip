@@ -1588,7 +1588,8 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
                        : out_dtype == CFSAR_F16 ? launch_p12_f16(a, s) : launch_p12<float, true>(a, s);
         if (rc != -2) return rc;
     }
-    if (in_dtype == CFSAR_BF16 && (forced == 12 || (forced == 0 && tiles4 >= 240 && N >= 256))) {
+    // (long-K GEMMs keep the 256x256 tile down to half a round of tiles: c_proj of ONE episode, 186 tiles, 77 vs 97 us on p3)
+    if (in_dtype == CFSAR_BF16 && (forced == 12 || (forced == 0 && N >= 256 && (tiles4 >= 240 || (tiles4 >= 128 && K >= 2048))))) {
         const int rc = out_dtype == CFSAR_BF16 ? launch_p12<__bf16>(a, s)
                        : out_dtype == CFSAR_F16 ? launch_p12_f16(a, s) : launch_p12<float>(a, s);
         if (rc != -2) return rc;
