@@ -1524,6 +1524,67 @@ static int launch_p12_f16(const GemmArgs& a0, hipStream_t s) {
     return launch_p12_inst<_Float16, CFSAR_ACT_NONE, true, true>(a, s);
 }
 
+// ============================================================================================================
+// Skinny fp32 GEMM (M <= 256 rows): the temporal head of ONE episode is (S+Q)*T = 80 rows against 512...2048-wide weights; the
+// 128x128 MFMA kernel gives that 4-16 workgroups with a long serial K loop (66 us per launch, 8 % of a single-episode forward).
+// Here a workgroup owns 8 output columns for all rows: 256 threads = 8 columns x 32 row groups, thread (c, g) accumulates rows
+// g, g+32, ... in registers with plain fp32 FMAs (A rows broadcast through L1, W rows read once per workgroup), so N/8
+// workgroups (256 for N = 2048) spread over the chip.  Same epilogue as cfsar_gemm: bias, QuickGELU / GELU(erf), fp32 residual.
+// ============================================================================================================
+template <int RPT>
+__global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(GemmArgs p) {
+    const int c = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int n = blockIdx.x * 8 + c;
+    const int nc = n < p.N ? n : p.N - 1;
+    const float* A = reinterpret_cast<const float*>(p.A);
+    const float* wr = reinterpret_cast<const float*>(p.W) + (size_t)nc * p.ldw;
+    float acc[RPT];
+    const float* ar[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        acc[i] = 0.f;
+        const int r = g + 32 * i;
+        ar[i] = A + (size_t)(r < p.M ? r : p.M - 1) * p.lda;
+    }
+    for (int k = 0; k < p.K; k += 4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const float4 a4 = *reinterpret_cast<const float4*>(ar[i] + k);
+            acc[i] = fmaf(a4.x, w4.x, acc[i]);
+            acc[i] = fmaf(a4.y, w4.y, acc[i]);
+            acc[i] = fmaf(a4.z, w4.z, acc[i]);
+            acc[i] = fmaf(a4.w, w4.w, acc[i]);
+        }
+    }
+    if (n >= p.N) return;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+    float* outp = reinterpret_cast<float*>(p.out);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = g + 32 * i;
+        if (r >= p.M) continue;
+        float v = apply_act(acc[i] + bv, p.act);
+        if (p.res) v += static_cast<const float*>(p.res)[(size_t)(r + p.row_off) * p.ldr + n];
+        if (p.relu) v = fmaxf(v, 0.f);
+        outp[(size_t)(r + p.row_off) * p.ldo + n] = v;
+    }
+}
+
+static int launch_skinny_f32(const GemmArgs& a, hipStream_t s) {
+    const dim3 grid((unsigned)((a.N + 7) / 8));
+    const int rpt = (a.M + 31) / 32;
+    switch (rpt) {
+        case 1: hipLaunchKernelGGL(skinny_gemm_f32_kernel<1>, grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(skinny_gemm_f32_kernel<2>, grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(skinny_gemm_f32_kernel<3>, grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(skinny_gemm_f32_kernel<4>, grid, dim3(256), 0, s, a); break;
+        case 5: case 6: hipLaunchKernelGGL(skinny_gemm_f32_kernel<6>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(skinny_gemm_f32_kernel<8>, grid, dim3(256), 0, s, a); break;
+    }
+    return cfsar_check_launch("cfsar_gemm(skinny f32)");
+}
+
 // dev tool (not in the public header): device buffer of 8 x u64 per 256x256 tile for the p6 phase timestamps; NULL = off
 extern "C" void cfsar_debug_set_gemm_trace(void* buf) { g_trace = static_cast<unsigned long long*>(buf); }
 // dev tool (not in the public header): override CFSAR_GEMM_VARIANT / CFSAR_GEMM_DEBUG at run time; -1 = use the environment
@@ -1579,6 +1640,10 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     static const int forced_env = [] { const char* e = getenv("CFSAR_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
     const int forced = g_variant_override >= 0 ? g_variant_override : forced_env;
     const long tiles4 = (long)((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
+    // fp32, at most 256 rows, no row remap: the skinny kernel (the temporal head of one or two episodes); 14 = force, 15 = never
+    if (in_dtype == CFSAR_F32 && out_dtype == CFSAR_F32 && res_dtype == CFSAR_F32 && row_group == 0 && res_mod == 0 && K % 4 == 0 &&
+        lda % 4 == 0 && ldw % 4 == 0 && M <= 256 && (forced == 14 || (forced == 0 && M <= 192)))
+        return launch_skinny_f32(a, s);
     // p12 measured fastest on all four ViT GEMMs (M = 252 160, same box, interleaved: QKV 888 vs 960 us (p10), out_proj 457 vs
     // 476, c_fc 1 288 vs 1 409 (p6), c_proj 1 143 vs 1 178) and on the RN50 1x1 convs with N >= 256 (tools/rn_gemm_ab.py).
     // 13 = the persistent form (one workgroup per CU walking its tiles: no retire -> dispatch gap; +3 % on QKV / c_fc), the auto
