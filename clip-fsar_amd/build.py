@@ -15,7 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libclipfsar_hip.so")
 SOURCES = ["runtime.hip", "gemm.hip", "rowops.hip", "attention.hip", "tail.hip", "conv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+# CFSAR_DEV=1: developer build -- compiles the ablation switches and the cfsar_debug_* hooks of include/clipfsar_hip_dev.h into
+# the same .so name (tools/*.py need it).  The product build (default) contains none of them; tests/test_abi.py checks that.
+DEV = os.environ.get("CFSAR_DEV", "0") == "1"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          "-Rpass-analysis=kernel-resource-usage"]      # per-kernel VGPR / scratch report -> build/resource_usage.json
 USAGE = os.path.join(HERE, "build", "resource_usage.json")
 
@@ -57,7 +60,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + (["-DCFSAR_DEV"] if DEV else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

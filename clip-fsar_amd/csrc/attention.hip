@@ -72,8 +72,7 @@ template <int NTV>
 constexpr int att_vt_stride(int NP, bool compact) { return compact ? (NTV * 16 + 8) * 2 : ((NP * 2 + 255) / 256) * 256 + 16; }
 template <int NKB, int NTV, int ATT_THREADS = 512, bool COMPACT = false>
 __global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_attn_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
-                                                            int ntok, int D, float scale_log2e, int dbg,
-                                                            unsigned long long* trace) {
+                                                            int ntok, int D, float scale_log2e) {
     constexpr int NP = NKB * 32;
     constexpr int NT = NKB * 2;                                    // 16-key tiles
     constexpr int VT_STRIDE = att_vt_stride<NTV>(NP, COMPACT);     // bytes
@@ -88,16 +87,6 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_a
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t ld = (size_t)3 * D;
     const __bf16* base = qkv + (size_t)f * ntok * ld + h * 64;
-    // dev tool: cycle stamps of (workgroup, wave) -> trace[((f*gridDim.x + h)*8 + wave)*16 + slot]; NULL = off
-    auto stamp = [&](int slot) {
-        if (trace && lane == 0) trace[(((size_t)f * gridDim.x + h) * 8 + wave) * 16 + slot] = __builtin_readcyclecounter();
-    };
-    stamp(0);
-    if (dbg & (16 | 32)) {                       // experiment: phase-shift every second first-round workgroup
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lin < 512 && ((lin >> ((dbg & 32) ? 0 : 8)) & 1))
-            for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
-    }
 
     // ---- stage K (swizzled rows, NP*8 16-byte chunks) and V^T: ALL global loads of a thread are issued before the first LDS
     // write (cycle stamps: the load -> write -> load -> write form spent 11.5 K of a workgroup's 28.8 K cycles here, three to
@@ -110,14 +99,14 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_a
         const int idx = tid + it * ATT_THREADS;
         const int r = idx >> 3, c = (idx & 7) ^ swz(r);
         kreg[it] = att_u32x4{0, 0, 0, 0};
-        if (idx < KROWS * 8 && r < ntok && !(dbg & 1)) kreg[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)r * ld + D + c * 8);
+        if (idx < KROWS * 8 && r < ntok) kreg[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)r * ld + D + c * 8);
     }
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {
         const int idx = tid + it * ATT_THREADS;
         const int kp = idx % (VKEYS / 2), dc = idx / (VKEYS / 2);
         vreg0[it] = vreg1[it] = att_u32x4{0, 0, 0, 0};
-        if (idx < (VKEYS / 2) * 8 && !(dbg & 1)) {
+        if (idx < (VKEYS / 2) * 8) {
             if (2 * kp < ntok) vreg0[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)(2 * kp) * ld + 2 * D + dc * 8);
             if (2 * kp + 1 < ntok) vreg1[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)(2 * kp + 1) * ld + 2 * D + dc * 8);
         }
@@ -144,9 +133,7 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_a
     if constexpr (COMPACT) {                 // the last V^T row is over-read by 16 bytes (keys 216-223 of d = 63): keep them finite
         if (tid < 4) *reinterpret_cast<att_u32x4*>(sVt + 64 * VT_STRIDE + tid * 16) = att_u32x4{0, 0, 0, 0};
     }
-    stamp(1);
     __syncthreads();
-    stamp(2);
 
     const int q16 = lane & 15, g = lane >> 4;
     const int nqt = (ntok + 15) >> 4;
@@ -161,8 +148,6 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_a
         for (int ks = 0; ks < 2; ++ks)
             qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + ks * 32 + g * 8);
 
-        const bool first = qt == wave;
-        if (first) stamp(3);
         // S^T tiles (tiles that hold only padded keys are skipped; their probabilities are 0)
         f32x4 s[NT];
 #pragma unroll
@@ -179,7 +164,6 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_a
             s[j] = acc;
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the K-fragment live ranges (no spills)
         }
-        if (first) stamp(4);
         // mask the padded keys of the last (partial) tile, row max over keys (in-lane, then across the 4 lane groups)
         float mx = -1e30f;
 #pragma unroll
@@ -200,7 +184,7 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_a
             if (j < nt_valid) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = (dbg & 2) ? fmaf(s[j][r], scale_log2e, -mxs) : __builtin_amdgcn_exp2f(fmaf(s[j][r], scale_log2e, -mxs));   // raw v_exp_f32
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[j][r], scale_log2e, -mxs));   // raw v_exp_f32
                     s[j][r] = pv;
                     sum += pv;
                 }
@@ -209,8 +193,6 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_a
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = __builtin_amdgcn_rcpf(sum);
-
-        if (first) stamp(5);
         // O^T = V^T . P^T
         f32x4 o[4];
 #pragma unroll
@@ -234,11 +216,8 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_a
             if (kb & 1) __builtin_amdgcn_sched_barrier(0);
         }
         // O^T[d][q]: lane owns query q16, d = 16dt + 4g + r
-        if (first) stamp(6);
-        store_o_tile(o, inv, qvalid && !((dbg & 4) && o[0][0] != 123.f), out + ((size_t)f * ntok + qrow) * D + h * 64, g);
-        if (first) stamp(7);
+        store_o_tile(o, inv, qvalid, out + ((size_t)f * ntok + qrow) * D + h * 64, g);
     }
-    stamp(8);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -292,31 +271,19 @@ __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float* __restri
     }
 }
 
-static unsigned long long* g_attn_trace = nullptr;   // dev tool (tools/attn_trace.py)
-
 template <int NKB, int NTV, int NTHR = 512, bool COMPACT = false>
 int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
     constexpr int NP = NKB * 32;
     constexpr int VT_STRIDE = att_vt_stride<NTV>(NP, COMPACT);
     constexpr int LDS = (COMPACT ? NTV * 16 : NP) * 128 + 64 * VT_STRIDE + (COMPACT ? 64 : 0);   // + tail pad: the last V^T row is over-read
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<NKB, NTV, NTHR, COMPACT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return cfsar_fail("cfsar_vit_attention: set LDS size: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<NKB, NTV, NTHR, COMPACT>), LDS, "cfsar_vit_attention")) return rc;
     const float scale_log2e = 0.125f * 1.4426950408889634f;
-    static const int dbg = [] { const char* e = getenv("CFSAR_ATTN_DEBUG"); return e ? atoi(e) : 0; }();   // dev ablations
     hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB, NTV, NTHR, COMPACT>), dim3(heads, F), dim3(NTHR), LDS, s,
-                       static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e, dbg, g_attn_trace);
+                       static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e);
     return cfsar_check_launch("cfsar_vit_attention(bf16)");
 }
 
 }  // namespace
-
-// dev tool (not in the public header): buffer of 16 x u64 per (workgroup, wave) for the bf16 kernel's phase stamps; NULL = off
-extern "C" void cfsar_debug_set_attn_trace(void* buf) { g_attn_trace = static_cast<unsigned long long*>(buf); }
 
 extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads,
                                    cfsar_stream_t stream) {
@@ -327,12 +294,8 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == CFSAR_BF16) {
         CFSAR_REQUIRE(ntok <= 288, "cfsar_vit_attention: ntok=%d > 288", ntok);
-        static const int variant = [] { const char* e = getenv("CFSAR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-        // CFSAR_ATTN_VARIANT=4 (dev): compact LDS image + 256-thread workgroups = three workgroups per CU (measured slower:
-        // 305 vs 255-277 us at 640 frames).  A pipelined multi-head form (LDS-DMA staging of the next head during the compute
-        // phase, one or two query tiles per wave) was measured equal to this kernel and removed; numbers and the per-phase cycle
-        // stamps are in profiles/r01_attention_ablation.md.
-        if (ntok == 197 && variant == 4) return launch_bf16<7, 13, 256, true>(qkv, out, F, ntok, D, heads, s);
+        // (A compact-LDS three-workgroups-per-CU form and a pipelined multi-head form were measured slower / equal in round 1 and
+        // removed; numbers and per-phase cycle stamps: profiles/r01_attention_ablation.md.)
         if (ntok == 197) return launch_bf16<7, 13>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 257) return launch_bf16<9, 17>(qkv, out, F, ntok, D, heads, s);     // ViT-L/14 @224
         if (ntok <= 224) return launch_bf16<7, 0>(qkv, out, F, ntok, D, heads, s);
@@ -341,13 +304,7 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
     if (dtype == CFSAR_F32) {
         const int lds = ntok * 64 * 4 * 2;
         CFSAR_REQUIRE(lds <= 160 * 1024, "cfsar_vit_attention: ntok=%d too large for the fp32 kernel", ntok);
-        static int attr_lds = 0;
-        if (lds > attr_lds) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attn_f32_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return cfsar_fail("cfsar_vit_attention: set LDS size: %s", hipGetErrorString(e));
-            attr_lds = lds;
-        }
+        if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_f32_kernel), lds, "cfsar_vit_attention")) return rc;
         hipLaunchKernelGGL(vit_attn_f32_kernel, dim3(heads, F), dim3(256), lds, s, static_cast<const float*>(qkv),
                            static_cast<float*>(out), ntok, D, 0.125f);
         return cfsar_check_launch("cfsar_vit_attention(f32)");

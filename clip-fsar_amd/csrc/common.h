@@ -24,6 +24,8 @@ template <> struct Vec2B<float> { typedef f32x4 v4; typedef f32x4 v8; };   // pl
 extern thread_local char cfsar_err_buf[512];
 int cfsar_fail(const char* fmt, ...);
 int cfsar_check_launch(const char* what);
+int cfsar_ensure_lds(const void* fn, int bytes, const char* what);   // per-(device, kernel) dynamic-LDS limit, cached
+int cfsar_num_cus();                                                 // compute units of the current device, cached
 
 #define CFSAR_REQUIRE(cond, ...)                    \
     do {                                            \

@@ -30,6 +30,14 @@ constexpr int ROWB = 128;                       // bytes of K per tile row per s
 constexpr int STAGE_BYTES = (BM + BN) * ROWB;   // 32 KiB
 constexpr int NTHREADS = 256;
 
+// Ablation switches exist only in dev builds (`CFSAR_DEV=1 python clip-fsar_amd/build.py`, include/clipfsar_hip_dev.h); in the
+// product build GDBG() is the constant 0 and every branch on it folds away.
+#ifdef CFSAR_DEV
+#define GDBG(p) ((p).dbg)
+#else
+#define GDBG(p) 0
+#endif
+
 struct GemmArgs {
     const char* A;
     const char* W;
@@ -44,9 +52,9 @@ struct GemmArgs {
     int row_group, row_gap, row_off, res_mod, res_off;
     int tiles_n;
     int ntiles;    // persistent p6: total number of 256x256 tiles
-    int stagger;   // unused (first-round phase offset experiment of the removed p4 kernel)
-    unsigned long long* trace;   // dev tool: per-tile phase timestamps (s_memtime), 8 slots per tile; normally NULL
-    int dbg;   // ablation bits (env CFSAR_GEMM_DEBUG): 1 = no in-loop DMA, 2 = no in-loop barrier, 4 = no epilogue
+#ifdef CFSAR_DEV
+    int dbg;   // ablation bits (dev builds only, cfsar_debug_set_gemm_variant): 1 = no in-loop DMA, 2 = no in-loop barrier, 4 = no epilogue
+#endif
     int conv_H, conv_W, conv_lgC;   // implicit 3x3 / pad 1 / stride 1 conv (p10 CONV): A = NHWC input [F,H,W,C], C = 1 << conv_lgC
 };
 
@@ -259,7 +267,7 @@ template <typename TO, int ACT, bool HAS_RES, bool REMAP, bool FULL, int NMI = 2
 __device__ __forceinline__ void epilogue_lds(f32x16 (*acc)[2], const GemmArgs& p, int mbase, int nbase, int lane,
                                              char* wbuf) {
     if constexpr (sizeof(TO) == 2 && !REMAP && X8) {
-        if (!(p.dbg & 128) && (p.ldo & 7) == 0 && (!HAS_RES || (p.ldr & 7) == 0) && p.N >= 8) {
+        if (!(GDBG(p) & 128) && (p.ldo & 7) == 0 && (!HAS_RES || (p.ldr & 7) == 0) && p.N >= 8) {
             epilogue_lds_x8<TO, ACT, HAS_RES, FULL, NMI>(acc, p, mbase, nbase, lane, wbuf);
             return;
         }
@@ -686,10 +694,10 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(p.dbg & 2)) __syncthreads();   // everyone's part of slice kt is in LDS; everyone is done reading slice kt-1
+        if (!(GDBG(p) & 2)) __syncthreads();   // everyone's part of slice kt is in LDS; everyone is done reading slice kt-1
         int st2 = st + 2;
         st2 = st2 >= NSTAGE2 ? st2 - NSTAGE2 : st2;
-        if (kt + 2 < nk && !(p.dbg & 1)) issue(st2, kt + 2);
+        if (kt + 2 < nk && !(GDBG(p) & 1)) issue(st2, kt + 2);
         const char* sX = smem + st * STAGE2;
         mma_slice_db<TI, MIW>(acc, sX, sX + BM2 * ROWB, offX, offW, sxX, sxW, hi);
         st = st + 1 >= NSTAGE2 ? 0 : st + 1;
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
     __syncthreads();                 // every wave is done with the ring: reuse it as per-wave transpose buffers
     const int mb = m0 + wm * (32 * MIW), nb = n0 + wn * 64;
     f32x16 (*accp)[2] = acc;
-    if (p.dbg & 4) {
+    if (GDBG(p) & 4) {
         if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[MIW - 1][1][3];
         return;
     }
@@ -718,13 +726,7 @@ __global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p3(GemmArgs p) {
 
 template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP, bool CONV = false, bool NARROW = false>
 int launch_p3_inst(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP, CONV, NARROW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
-        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP, CONV, NARROW>), NSTAGE2 * STAGE2, "cfsar_gemm")) return rc;
     const int tiles_m = (a.M + BM2 - 1) / BM2;
     hipLaunchKernelGGL((gemm_kernel_p3<TI, TO, ACT, HAS_RES, REMAP, CONV, NARROW>), dim3(tiles_m * a.tiles_n), dim3(NTHREADS2),
                        NSTAGE2 * STAGE2, s, a);
@@ -766,22 +768,13 @@ int launch_p3_f16(const GemmArgs& a0, hipStream_t s) {
 }
 
 // ============================================================================================================
-// v3 ("p6"): 256(M) x 256(N) tile, 512 threads (8 waves as 2(M) x 4(N), each wave 128 x 64 = 4x2 MFMA 32x32 tiles,
-// 128 accumulator VGPRs), the two M halves running one barrier apart (one group's MFMA phase overlaps the other's
-// fragment reads / LDS-DMA issue).  K in 64-byte slices (32 bf16) through a FOUR-stage LDS ring (4 x 32 KiB) filled by
-// asm LDS-DMA running three slices ahead (counted vmcnt).  64-byte LDS rows: chunk ^= (row>>2)&3 keeps ds_read_b128
-// conflict-free.  The round's default until p10 / p12; its siblings p4 (no ping-pong), p5 (256x128, two workgroups per CU),
-// p8 (one wave per SIMD + LDS-DMA) and p9 (p10 with 64-byte slices) measured within 3 % of it and were removed
-// (numbers: profiles/r01_gemm_ablation.md).
+// 256(M) x 256(N) tiles: shared constants and the tile walk of the p10 / p12 kernels below.  (Round 1 also carried p4 / p5 /
+// p6 / p8 / p9 siblings -- LDS-DMA operand paths, 64-byte K slices, ping-pong groups; measured within 3 % of each other and
+// behind p10 / p12, tables in profiles/r01_gemm_ablation.md -- all removed from the source.)
 // ============================================================================================================
 constexpr int BM4 = 256;
 constexpr int BN4 = 256;
-constexpr int ROWB4 = 64;
-constexpr int STAGE4 = (BM4 + BN4) * ROWB4;   // 32 KiB
-constexpr int NSTAGE4 = 4;
-constexpr int LDS4 = 8 * EPI_WAVE_BYTES > NSTAGE4 * STAGE4 ? 8 * EPI_WAVE_BYTES : NSTAGE4 * STAGE4;   // 139264 B
-
-__device__ __forceinline__ int swz4(int row) { return (row >> 2) & 3; }
+constexpr int LDS4 = 8 * EPI_WAVE_BYTES;     // 139264 B: the 8 wave-private epilogue regions (>= the two 64 KiB operand stages)
 
 // linear tile index -> (row band, column) walking `group` row bands before the next column of tiles (group <= 1: row-major)
 __device__ __forceinline__ void tile_of(int lin, int tiles_m, int tiles_n, int group, int& tm, int& tn) {
@@ -799,262 +792,16 @@ __device__ __forceinline__ void tile_of(int lin, int tiles_m, int tiles_n, int g
 }
 // short-K GEMMs (QKV, out_proj, c_fc): groups of 8 row bands (+2...+4 % measured); dbg 512 / 1024: 4 / 16; 2048: off
 __device__ __forceinline__ int tile_group(const GemmArgs& p, int ntiles) {
-    if (p.dbg & 2048) return 1;
-    if (p.dbg & 512) return 4;
-    if (p.dbg & 1024) return 16;
-    return ((p.dbg & 256) || (p.K <= 1024 && ntiles >= 512)) ? 8 : 1;
+    if (GDBG(p) & 2048) return 1;
+    if (GDBG(p) & 512) return 4;
+    if (GDBG(p) & 1024) return 16;
+    return ((GDBG(p) & 256) || (p.K <= 1024 && ntiles >= 512)) ? 8 : 1;
 }
 
-// PERSIST: launched with 256 workgroups (one per CU); each walks tiles b, b+256, ... -- no workgroup retire/dispatch and
-// store-drain latency between tiles (measured ~4-6 us of a ~34 us K=768 tile in the one-tile-per-workgroup form).
-template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP, bool PERSIST>
-__global__ __launch_bounds__(NTHREADS2) void gemm_kernel_p6(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BK = ROWB4 / (int)sizeof(TI);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int lr = lane & 31, hi = lane >> 5;
-    int offX[4], offW[2], sxX[4], sxW[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rx = wm * 128 + i * 32 + lr;
-        offX[i] = rx * ROWB4;
-        sxX[i] = swz4(rx);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rw = wn * 64 + i * 32 + lr;
-        offW[i] = BM4 * ROWB4 + rw * ROWB4;
-        sxW[i] = swz4(rw);
-    }
-    const int nk = p.K / BK;
-    const bool grpB = wave >= 4;
-
-    auto stamp = [&](int lin, int slot) {
-        if (p.trace && tid == 0) p.trace[(size_t)lin * 8 + slot] = __builtin_readcyclecounter();
-    };
-    // staging: each operand tile = 16 instructions of 16 rows x 64 B; wave w issues instructions {w, w+8} of X and of W
-    const char* srcX[2];
-    const char* srcW[2];
-    const int tgroup = tile_group(p, p.ntiles);
-    auto set_src = [&](int lin) {
-        int tm, tn;
-        tile_of(lin, p.ntiles / p.tiles_n, p.tiles_n, tgroup, tm, tn);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (i * 8 + wave) * 16 + (lane >> 2);
-            const int chunk = (lane & 3) ^ swz4(row);
-            int gm = tm * BM4 + row;
-            gm = gm < p.M ? gm : p.M - 1;
-            int gn = tn * BN4 + row;
-            gn = gn < p.N ? gn : p.N - 1;
-            srcX[i] = p.A + ((size_t)gm * p.lda) * sizeof(TI) + chunk * 16;
-            srcW[i] = p.W + ((size_t)gn * p.ldw) * sizeof(TI) + chunk * 16;
-        }
-    };
-    auto issue = [&](int stage, int kt) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)stage * (unsigned)STAGE4);
-        const size_t koff = (size_t)kt * ROWB4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) glds16_asm(srcX[i] + koff, base + i * 8192);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) glds16_asm(srcW[i] + koff, base + BM4 * ROWB4 + i * 8192);
-    };
-
-    // pre_issued: slices 0..2 of this tile were already issued (persistent form: during / after the previous epilogue)
-    auto do_tile = [&](int lin, int next_lin, bool pre_issued) {
-    int tm, tn;
-    tile_of(lin, p.ntiles / p.tiles_n, p.tiles_n, tgroup, tm, tn);
-    const int m0 = tm * BM4, n0 = tn * BN4;
-    stamp(lin, 0);
-    if (!pre_issued) set_src(lin);
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    // ---- ping-pong schedule.  Waves 0-3 (group A, top 128 rows) and 4-7 (group B, bottom 128 rows) share the four SIMDs
-    // pairwise (wave w and w+4).  Every wave alternates a MEMORY phase (12 ds_read_b128 of slice j's fragments + its 4
-    // LDS-DMA issues for slice j+3 + counted waits) and a COMPUTE phase (16 MFMAs), separated by s_barrier; group B runs
-    // one barrier behind group A, so on each SIMD one wave feeds the matrix pipe while its partner does LDS/DMA work.
-    // Barrier G(2j) .. G(2j+1): A memory j | B compute j-1;   G(2j+1) .. G(2j+2): A compute j | B memory j.
-    // Invariants (4 stages, DMA distance 3): a wave ends memory phase j only when its own DMA share of slice j+1 has
-    // landed (vmcnt(8) leaves slices j+2, j+3 in flight), so after G(2j) every share of slice j is in LDS for A's reads
-    // and after G(2j+1) for B's; slice j+3 overwrites the stage of slice j-1, last read by B before G(2j).
-    uint4 xf[2][4], wf[2][2];
-    auto mem_phase = [&](int j) {
-        const char* base = smem + (j & 3) * STAGE4;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                xf[s2][i] = *reinterpret_cast<const uint4*>(base + offX[i] + (((2 * s2 + hi) ^ sxX[i]) << 4));
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                wf[s2][i] = *reinterpret_cast<const uint4*>(base + offW[i] + (((2 * s2 + hi) ^ sxW[i]) << 4));
-        }
-        if (j + 3 < nk) {
-            issue((j + 3) & 3, j + 3);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else if (j + 2 < nk) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto compute_phase = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s2][ni]),
-                                                                          __builtin_bit_cast(bf16x8, xf[s2][mi]),
-                                                                          acc[mi][ni], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    if (!pre_issued) {
-        issue(0, 0);
-        if (nk > 1) issue(1, 1);
-        if (nk > 2) issue(2, 2);
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        // slices 0,1 were issued before the previous epilogue's stores, slice 2 after them: leaving only slice 2 in
-        // flight also drains those stores (they have had the whole epilogue to complete)
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                      // G0: slice 0 is in LDS for everyone
-    __builtin_amdgcn_sched_barrier(0);
-    stamp(lin, 1);
-    if (grpB) {
-        __builtin_amdgcn_s_barrier();                  // group B starts one barrier late
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (int j = 0; j < nk; ++j) {
-        mem_phase(j);
-        compute_phase();
-    }
-    if (!grpB) {
-        __builtin_amdgcn_s_barrier();                  // group A absorbs the stagger
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-    stamp(lin, 2);
-    if (p.dbg & 4) {
-        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[3][1][2] + acc[2][0][1];
-        return;
-    }
-    if constexpr (PERSIST) {
-        // Prefetch the next tile's slices 0 and 1 into stages 0/1 (bytes [0, 64 KiB)) BEFORE the epilogue, whose LDS
-        // staging is confined to [64 KiB, 64 KiB + 8 x 8704 B): the ~13 % pipeline-fill latency of a K = 768 tile hides
-        // behind the epilogue.  The epilogue runs in four 32-row passes per wave.
-        const bool has_next = next_lin < p.ntiles;
-        if (has_next) {
-            set_src(next_lin);
-            issue(0, 0);
-            if (nk > 1) issue(1, 1);
-        }
-        char* wbuf = smem + 65536 + wave * (32 * EPI_RS);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int mb = m0 + wm * 128 + mi * 32, nb = n0 + wn * 64;
-            if (mb + 32 <= p.M && nb + 64 <= p.N) epilogue_lds<TO, ACT, HAS_RES, REMAP, true, 1>(&acc[mi], p, mb, nb, lane, wbuf);
-            else epilogue_lds<TO, ACT, HAS_RES, REMAP, false, 1>(&acc[mi], p, mb, nb, lane, wbuf);
-            if (mi == 1) stamp(lin, 3);
-        }
-        stamp(lin, 4);
-        __syncthreads();                                   // staging reads done: stage 2 may be overwritten
-        if (has_next && nk > 2) issue(2, 2);
-        stamp(lin, 5);
-    } else {
-    char* wbuf = smem + wave * EPI_WAVE_BYTES;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 64;
-        const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
-        if constexpr (kBf16PackedEpilogue && sizeof(TO) == 2 && !HAS_RES && !REMAP) {
-            if (full) epilogue_lds_bf16<ACT, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
-            else epilogue_lds_bf16<ACT, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
-        } else {
-            if (full) epilogue_lds<TO, ACT, HAS_RES, REMAP, true>(&acc[2 * half], p, mb, nb, lane, wbuf);
-            else epilogue_lds<TO, ACT, HAS_RES, REMAP, false>(&acc[2 * half], p, mb, nb, lane, wbuf);
-        }
-        stamp(lin, 3 + half);
-    }
-    if (p.trace) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp(lin, 5);
-    }
-    }
-    };   // do_tile
-
-    if constexpr (PERSIST) {
-        // Block b lives on XCD b % 8; inside each chunk of G tiles the workgroups of one XCD take CONSECUTIVE raster
-        // positions, so the tiles an L2 sees at one time share X and W panels.
-        const int G = gridDim.x, b = blockIdx.x, per_xcd = G >> 3;
-        bool pre = false;
-        for (int lin = (b & 7) * per_xcd + (b >> 3); lin < p.ntiles; lin += G) {
-            do_tile(lin, lin + G, pre);
-            pre = true;
-        }
-    } else {
-        const int nwg = gridDim.x, b = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-        do_tile((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3), p.ntiles, false);
-    }
-}
-
-template <typename TI, typename TO, int ACT, bool HAS_RES, bool REMAP, bool PERSIST>
-int launch_p6_inst(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p6<TI, TO, ACT, HAS_RES, REMAP, PERSIST>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
-        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    const int grid = PERSIST ? 256 : a.ntiles;
-    hipLaunchKernelGGL((gemm_kernel_p6<TI, TO, ACT, HAS_RES, REMAP, PERSIST>), dim3(grid), dim3(NTHREADS2), LDS4, s, a);
-    return cfsar_check_launch("cfsar_gemm(p6)");
-}
-
-template <typename TO, bool PERSIST>
-int launch_p6(const GemmArgs& a0, hipStream_t s) {
-    GemmArgs a = a0;
-    a.tiles_n = (a.N + BN4 - 1) / BN4;
-    a.ntiles = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
-    const bool r = a.res != nullptr;
-    if (a.row_group > 0 || a.res_mod > 0 || a.act == CFSAR_ACT_GELU_ERF) return -2;
-    if (a.act == CFSAR_ACT_QUICKGELU)
-        return r ? -2 : launch_p6_inst<__bf16, TO, CFSAR_ACT_QUICKGELU, false, false, PERSIST>(a, s);
-    return r ? launch_p6_inst<__bf16, TO, CFSAR_ACT_NONE, true, false, PERSIST>(a, s)
-             : launch_p6_inst<__bf16, TO, CFSAR_ACT_NONE, false, false, PERSIST>(a, s);
-}
-
-}  // namespace
-
-static unsigned long long* g_trace = nullptr;
-static int g_variant_override = -1, g_dbg_override = -1;   // dev tool: in-process A/B (tools/gemm_ab.py)
+#ifdef CFSAR_DEV
+static int g_variant_override = 0, g_dbg_override = 0;   // dev tool: in-process A/B (tools/gemm_ab.py)
+#endif
 
 // ---- helpers shared by the register-staged kernels (p10, p12)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: loads/stores stay SSA values (no memcpy)
@@ -1116,9 +863,9 @@ __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
     for (int i = 0; i < 8; ++i) {
         const int row = (i * 4 + wave) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ swz(row);
-        int gm = ((p.dbg & 8) ? 0 : m0) + row;
+        int gm = ((GDBG(p) & 8) ? 0 : m0) + row;
         gm = gm < p.M ? gm : p.M - 1;
-        int gn = ((p.dbg & 8) ? 0 : n0) + row;
+        int gn = ((GDBG(p) & 8) ? 0 : n0) + row;
         gn = gn < p.N ? gn : p.N - 1;
         if constexpr (CONV) {
             const int x = gm % p.conv_W, y = (gm / p.conv_W) % p.conv_H;
@@ -1234,7 +981,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
             } else if constexpr (write) load_one(nxt, 0, std::integral_constant<int, j - 8>{}, xfA, wfA);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (j == 7 && write) {
-                if (!(p.dbg & 2)) __syncthreads();                      // hipcc adds lgkmcnt(0): this wave's ds_writes
+                if (!(GDBG(p) & 2)) __syncthreads();                      // hipcc adds lgkmcnt(0): this wave's ds_writes
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
@@ -1260,7 +1007,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
     }
     tile(kt, kt & 1, (kt + 1) & 1, F_{}, F_{});
     __syncthreads();
-    if (p.dbg & 4) {
+    if (GDBG(p) & 4) {
         if (acc[0][0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][1][3] + acc[0][3][1][2] + acc[1][2][0][1];
         if constexpr (PERSIST) continue;
         else return;
@@ -1273,7 +1020,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
             const int mb = m0 + wm * 128 + half * 64, nb = n0 + wn * 128 + nh * 64;
             const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
             if constexpr (sizeof(TO) == 2 && !HAS_RES) {
-                if ((p.dbg & 64) && !p.relu) {                          // A/B: packed bf16 staging + 16-byte stores
+                if ((GDBG(p) & 64) && !p.relu) {                          // A/B: packed bf16 staging + 16-byte stores
                     if (full) epilogue_lds_bf16<ACT, true>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
                     else epilogue_lds_bf16<ACT, false>(&acc[nh][2 * half], p, mb, nb, lane, wbuf);
                     continue;
@@ -1297,16 +1044,16 @@ __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
     }
 }
 
+// persistent kernels: one workgroup per CU, rounded down to a multiple of the 8 XCDs (the block -> XCD walk assumes it)
+static inline int persistent_grid() {
+    const int n = cfsar_num_cus() & ~7;
+    return n >= 8 ? n : 8;
+}
+
 template <typename TO, int ACT, bool HAS_RES, bool PERSIST, bool CONV = false>
 int launch_p10_inst(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p10<TO, ACT, HAS_RES, PERSIST, CONV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
-        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_kernel_p10<TO, ACT, HAS_RES, PERSIST, CONV>), dim3(PERSIST ? 256 : a.ntiles), dim3(256), LDS4, s, a);
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&gemm_kernel_p10<TO, ACT, HAS_RES, PERSIST, CONV>), LDS4, "cfsar_gemm")) return rc;
+    hipLaunchKernelGGL((gemm_kernel_p10<TO, ACT, HAS_RES, PERSIST, CONV>), dim3(PERSIST ? persistent_grid() : a.ntiles), dim3(256), LDS4, s, a);
     return cfsar_check_launch("cfsar_gemm(p10)");
 }
 
@@ -1472,7 +1219,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p12(GemmArgs p) {
     }
     tile(kt, kt & 1, (kt + 1) & 1, F_{}, F_{});
     __syncthreads();
-    if (p.dbg & 4) {
+    if (GDBG(p) & 4) {
         if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[3][1][2] + acc[2][0][1];
         if constexpr (PERSIST) continue;
         else return;
@@ -1491,14 +1238,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p12(GemmArgs p) {
 
 template <typename TO, int ACT, bool HAS_RES, bool PERSIST = false>
 int launch_p12_inst(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_p12<TO, ACT, HAS_RES, PERSIST>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
-        if (e != hipSuccess) return cfsar_fail("cfsar_gemm: set LDS size: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_kernel_p12<TO, ACT, HAS_RES, PERSIST>), dim3(PERSIST ? 256 : a.ntiles), dim3(512), LDS4, s, a);
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&gemm_kernel_p12<TO, ACT, HAS_RES, PERSIST>), LDS4, "cfsar_gemm")) return rc;
+    hipLaunchKernelGGL((gemm_kernel_p12<TO, ACT, HAS_RES, PERSIST>), dim3(PERSIST ? persistent_grid() : a.ntiles), dim3(512), LDS4, s, a);
     return cfsar_check_launch("cfsar_gemm(p12)");
 }
 
@@ -1585,10 +1326,12 @@ static int launch_skinny_f32(const GemmArgs& a, hipStream_t s) {
     return cfsar_check_launch("cfsar_gemm(skinny f32)");
 }
 
-// dev tool (not in the public header): device buffer of 8 x u64 per 256x256 tile for the p6 phase timestamps; NULL = off
-extern "C" void cfsar_debug_set_gemm_trace(void* buf) { g_trace = static_cast<unsigned long long*>(buf); }
-// dev tool (not in the public header): override CFSAR_GEMM_VARIANT / CFSAR_GEMM_DEBUG at run time; -1 = use the environment
+}  // namespace
+
+#ifdef CFSAR_DEV
+// dev builds only (include/clipfsar_hip_dev.h): force a kernel variant / ablation bits for in-process A/B; (0, 0) = product behaviour
 extern "C" void cfsar_debug_set_gemm_variant(int variant, int dbg) { g_variant_override = variant; g_dbg_override = dbg; }
+#endif
 
 extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const float* bias, const void* residual, int M,
                              int N, int K, int lda, int ldw, int ldo, int ldr, int in_dtype, int out_dtype, int act,
@@ -1625,22 +1368,20 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     a.row_group = row_group; a.row_gap = row_gap; a.row_off = row_off;
     a.res_mod = res_mod; a.res_off = res_off;
     a.tiles_n = (N + BN - 1) / BN;
-    static const int dbg = [] { const char* e = getenv("CFSAR_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
-    a.dbg = g_dbg_override >= 0 ? g_dbg_override : dbg;
-    static const int stag = [] { const char* e = getenv("CFSAR_GEMM_STAGGER"); return e ? atoi(e) : -1; }();
-    a.stagger = stag;
-    a.trace = g_trace;
     a.conv_H = a.conv_W = a.conv_lgC = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // CFSAR_GEMM_VARIANT (dev): 0 = auto, 1 = v1 (128x128, also the fp32 path), 2 = p3 (256x128, asm LDS-DMA), 6 = p6 (256x256
-    // ping-pong LDS-DMA), 7 = p6 persistent, 10 = p10 (one wave per SIMD, register-staged whole-line requests), 11 = p10
-    // persistent, 12 = p12 (p10's operand path, two waves per SIMD), 13 = p12 persistent.  auto: p12 for N >= 256 with enough 256x256 tiles to fill
-    // the chip; otherwise p3 (skinny / short-K bf16 GEMMs: its 256x128 tile wastes less of a narrow N and the 16-byte-per-lane
-    // bf16 epilogue fits its register budget, tools/rn_gemm_ab.py) when M >= 1024; v1 below.
-    static const int forced_env = [] { const char* e = getenv("CFSAR_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
-    const int forced = g_variant_override >= 0 ? g_variant_override : forced_env;
+    // Kernel choice.  Product builds take the measured policy below (`forced` is the constant 0 and its branches fold away); dev
+    // builds (CFSAR_DEV, include/clipfsar_hip_dev.h) can force a variant for in-process A/B: 1 = v1 (128x128, also the fp32 path),
+    // 2 = p3 (256x128, asm LDS-DMA), 10 / 11 = p10 (one wave per SIMD) / persistent, 12 / 13 = p12 (two waves per SIMD) /
+    // persistent, 14 / 15 = skinny fp32 kernel always / never, 20+ = the gemm_vit.hip kernel (see there).
+#ifdef CFSAR_DEV
+    a.dbg = g_dbg_override;
+    const int forced = g_variant_override;
+#else
+    constexpr int forced = 0;
+#endif
     const long tiles4 = (long)((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
-    // fp32, at most 256 rows, no row remap: the skinny kernel (the temporal head of one or two episodes); 14 = force, 15 = never
+    // fp32, at most 256 rows, no row remap: the skinny kernel (the temporal head of one or two episodes)
     if (in_dtype == CFSAR_F32 && out_dtype == CFSAR_F32 && res_dtype == CFSAR_F32 && row_group == 0 && res_mod == 0 && K % 4 == 0 &&
         lda % 4 == 0 && ldw % 4 == 0 && M <= 256 && (forced == 14 || (forced == 0 && M <= 192)))
         return launch_skinny_f32(a, s);
@@ -1666,23 +1407,12 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
         }
         return launch<__bf16, _Float16>(a, s);
     }
-    if (in_dtype == CFSAR_BF16 && forced == 10) {
-        const int rc = out_dtype == CFSAR_BF16 ? launch_p10<__bf16, false>(a, s) : launch_p10<float, false>(a, s);
+    if (in_dtype == CFSAR_BF16 && (forced == 10 || forced == 11)) {      // 11 = p10 persistent (one workgroup per CU)
+        const int rc = forced == 10 ? (out_dtype == CFSAR_BF16 ? launch_p10<__bf16, false>(a, s) : launch_p10<float, false>(a, s))
+                                    : (out_dtype == CFSAR_BF16 ? launch_p10<__bf16, true>(a, s) : launch_p10<float, true>(a, s));
         if (rc != -2) return rc;
     }
-    if (in_dtype == CFSAR_BF16 && forced == 11) {              // 11 = p10 persistent (one workgroup per CU)
-        const int rc = out_dtype == CFSAR_BF16 ? launch_p10<__bf16, true>(a, s) : launch_p10<float, true>(a, s);
-        if (rc != -2) return rc;
-    }
-    if (in_dtype == CFSAR_BF16 && forced == 7) {               // 7 = p6 persistent
-        const int rc = out_dtype == CFSAR_BF16 ? launch_p6<__bf16, true>(a, s) : launch_p6<float, true>(a, s);
-        if (rc != -2) return rc;
-    }
-    if (in_dtype == CFSAR_BF16 && forced == 6) {
-        const int rc = out_dtype == CFSAR_BF16 ? launch_p6<__bf16, false>(a, s) : launch_p6<float, false>(a, s);
-        if (rc != -2) return rc;
-    }
-    const bool use_p3 = forced == 2 || forced == 6 || forced == 7 || forced == 10 || forced == 11 || forced == 12 || forced == 13 || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
+    const bool use_p3 = (forced != 0 && forced != 1) || (forced == 0 && in_dtype == CFSAR_BF16 && M >= 1024);
     if (use_p3) {
         int rc;
         if (in_dtype == CFSAR_BF16)
@@ -1731,14 +1461,14 @@ extern "C" int cfsar_conv3x3_nhwc(const void* in, const void* W, void* out, cons
     a.row_group = a.row_gap = a.row_off = a.res_mod = a.res_off = 0;
     a.tiles_n = (Cout + BN4 - 1) / BN4;
     a.ntiles = (int)((M + BM4 - 1) / BM4) * a.tiles_n;
-    a.stagger = -1;
-    a.trace = nullptr;
+#ifdef CFSAR_DEV
     a.dbg = 0;
+#endif
     a.conv_H = H; a.conv_W = Wd;
     a.conv_lgC = 0;
     while ((1 << a.conv_lgC) < C) ++a.conv_lgC;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const int conv_variant = [] { const char* e = getenv("CFSAR_CONV_VARIANT"); return e ? atoi(e) : 0; }();
+    constexpr int conv_variant = 0;     // 3 / 4: force the 256x128 / 256x64 tile (A/B history: tools/rn_gemm_ab.py)
     if (out_dtype == CFSAR_BF16 && (conv_variant == 4 || (conv_variant == 0 && Cout <= 64))) {     // 256x64 tile
         a.tiles_n = (Cout + 63) / 64;
         return residual ? launch_p3_inst<__bf16, __bf16, CFSAR_ACT_NONE, true, false, true, true>(a, s)

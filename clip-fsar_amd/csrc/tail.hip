@@ -95,18 +95,21 @@ __global__ __launch_bounds__(128) void build_sequences_kernel(const float* __res
         if (tt < T) {
             src = feats + (((size_t)b * (S + Q) + sp) * T + tt) * E;
         } else {
-            int cls = (int)rl[sp];                         // .long() truncation (few_shot.py:2946)
-            cls = cls < 0 ? 0 : (cls >= n_test ? n_test - 1 : cls);
-            src = text_test + (size_t)cls * E;
+            const int cls = (int)rl[sp];                   // .long() truncation (few_shot.py:2946)
+            // an out-of-range class id is an IndexError in the reference (:2946).  A kernel cannot raise: the row is poisoned
+            // with NaN (never silently repaired) and the host wrapper validates the labels (models/base/few_shot.py)
+            src = (cls >= 0 && cls < n_test) ? text_test + (size_t)cls * E : nullptr;
         }
-        for (int e = tid; e < E; e += 128) xr[e] = src[e];
+        for (int e = tid; e < E; e += 128) xr[e] = src ? src[e] : __builtin_nanf("");
         return;
     }
     if (tid == 0) label_ranks(lab, S, rank);
     __syncthreads();
     int cnt = 0;
     for (int s = 0; s < S; ++s) cnt += (rank[s] == sp);
-    const float inv = 1.0f / (float)cnt;
+    // cnt == 0: the episode has fewer than `way` distinct labels (the reference would build fewer prototypes and fail on
+    // shapes downstream): NaN row, validated on the host
+    const float inv = cnt > 0 ? 1.0f / (float)cnt : __builtin_nanf("");
     for (int e = tid; e < E; e += 128) {
         float a = 0.f;
         for (int s = 0; s < S; ++s) {
@@ -114,9 +117,8 @@ __global__ __launch_bounds__(128) void build_sequences_kernel(const float* __res
             if (tt < T) {
                 a += feats[(((size_t)b * (S + Q) + s) * T + tt) * E + e];
             } else {
-                int cls = (int)rl[s];
-                cls = cls < 0 ? 0 : (cls >= n_test ? n_test - 1 : cls);
-                a += text_test[(size_t)cls * E + e];
+                const int cls = (int)rl[s];
+                a += (cls >= 0 && cls < n_test) ? text_test[(size_t)cls * E + e] : __builtin_nanf("");
             }
         }
         xr[e] = a * inv;
@@ -239,11 +241,10 @@ __global__ __launch_bounds__(256) void text_match_kernel(const float* __restrict
             float a = 0.f;
             for (int s = 0; s < S; ++s)
                 if (rank[s] == c) {
-                    int cls = (int)rl[s];
-                    cls = cls < 0 ? 0 : (cls >= n_test ? n_test - 1 : cls);
-                    a += text_test[(size_t)cls * E + e];
+                    const int cls = (int)rl[s];                                  // out of range: NaN, see build_sequences_kernel
+                    a += (cls >= 0 && cls < n_test) ? text_test[(size_t)cls * E + e] : __builtin_nanf("");
                 }
-            a /= (float)cnt;
+            a /= (float)cnt;                                                          // cnt == 0 -> NaN (0 / 0)
             tt += a * a;
             dot += a * img[e];
         }
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(128) void prototypes_kernel(const float* __restrict
     __syncthreads();
     int cnt = 0;
     for (int s = 0; s < S; ++s) cnt += (rank[s] == c);
-    const float inv = 1.0f / (float)cnt;
+    const float inv = cnt > 0 ? 1.0f / (float)cnt : __builtin_nanf("");      // see build_sequences_kernel
     for (int e = tid; e < E; e += 128) {
         float a = 0.f;
         for (int s = 0; s < S; ++s)
@@ -425,13 +426,7 @@ extern "C" int cfsar_seq_attention(const float* qkv, float* out, int n_a, int le
     CFSAR_REQUIRE(L <= 128 && head_dim <= 128, "cfsar_seq_attention: len=%d (max 128) head_dim=%d (max 128)", L, head_dim);
     const int lds = (3 * L * (head_dim + 1) + L * (L + 1)) * (int)sizeof(float);
     CFSAR_REQUIRE(lds <= 160 * 1024, "cfsar_seq_attention: len x head_dim too large for LDS");
-    static int attr_lds = 48 * 1024;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&seq_attention_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return cfsar_fail("cfsar_seq_attention: set LDS size: %s", hipGetErrorString(e));
-        attr_lds = lds;
-    }
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&seq_attention_kernel), lds, "cfsar_seq_attention")) return rc;
     hipLaunchKernelGGL(seq_attention_kernel, dim3(n_a + n_b, heads), dim3(128), lds, static_cast<hipStream_t>(stream), qkv,
                        out, n_a, len_a, n_b, len_b, heads, head_dim, scale, causal);
     return cfsar_check_launch("cfsar_seq_attention");
@@ -491,13 +486,7 @@ extern "C" int cfsar_cos_otam_logits(const float* Xq, const float* protos, float
     CFSAR_REQUIRE(B > 0 && Q > 0 && way > 0 && way <= 64 && T > 0 && T <= MAX_T && E > 0, "cfsar_cos_otam_logits: bad shape");
     const int lds = (T * E + T + way * T * T) * (int)sizeof(float);
     CFSAR_REQUIRE(lds <= 150 * 1024, "cfsar_cos_otam_logits: T*E too large for LDS");
-    static int attr_lds = 48 * 1024;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_otam_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return cfsar_fail("cfsar_cos_otam_logits: set LDS size: %s", hipGetErrorString(e));
-        attr_lds = lds;
-    }
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&cos_otam_kernel), lds, "cfsar_cos_otam_logits")) return rc;
     hipLaunchKernelGGL(cos_otam_kernel, dim3((unsigned)(B * Q)), dim3(256), lds, static_cast<hipStream_t>(stream), Xq,
                        protos, logits, dists_out, Q, way, T, E, lambda, single_direct);
     return cfsar_check_launch("cfsar_cos_otam_logits");

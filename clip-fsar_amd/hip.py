@@ -74,7 +74,7 @@ def _check(rc, what):
         raise RuntimeError("%s failed: %s" % (what, lib().cfsar_last_error().decode(errors="replace")))
 
 
-def _dev(t, dtype=None, name="tensor"):
+def _dev_ptr(t, dtype=None, name="tensor"):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError("clip_fsar_amd.hip: %s must be a HIP device tensor (no CPU path exists)" % name)
     if dtype is not None and t.dtype != dtype:
@@ -98,8 +98,24 @@ def _code(dtype):
     raise RuntimeError("clip_fsar_amd.hip: unsupported dtype %s" % dtype)
 
 
+_last_dev = [None]
+
+
+def _dev(t, dtype=None, name="tensor"):
+    p = _dev_ptr(t, dtype, name)
+    _last_dev[0] = t.device
+    return p
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Stream handle for the launch: the current stream OF THE DEVICE THE OPERANDS LIVE ON (the wrappers evaluate their
+    tensor arguments first), and that device must be the thread's current device -- HIP launches go to the current device,
+    so a mismatch would run the kernel on the wrong GPU."""
+    d = _last_dev[0]
+    if d is not None and d.index is not None and d.index != torch.cuda.current_device():
+        raise RuntimeError("clip_fsar_amd.hip: operands live on %s but the current device is cuda:%d -- wrap the call in "
+                           "torch.cuda.device(%d) (one process per GPU sets it once)" % (d, torch.cuda.current_device(), d.index))
+    return ctypes.c_void_p(torch.cuda.current_stream(d).cuda_stream)
 
 
 # ----------------------------------------------------------------------------------------------- N2 frame transform

@@ -153,6 +153,33 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
             self._engine_key = key
         return self._engine
 
+    def _validate_labels(self, support_labels, support_real_class, batched):
+        """The reference derives the classes of an episode from ``unique(support_labels)`` and indexes the text table with
+        ``real_support_labels`` (few_shot.py:2946-2962): an out-of-range class id raises IndexError there and an episode with
+        fewer distinct labels than TRAIN.WAY yields mis-shaped prototypes.  The kernels cannot raise (they poison the affected
+        rows with NaN), so the same conditions are checked here on the host: ONE small device->host copy per forward
+        (the label vectors, a few dozen floats).  VIDEO.HEAD.VALIDATE_LABELS = False skips it (no host sync at all; then
+        TRAIN.WAY must be set)."""
+        cfg = self.args
+        way_cfg = int(getattr(cfg.TRAIN, "WAY", 0) or 0)
+        if not bool(getattr(cfg.VIDEO.HEAD, "VALIDATE_LABELS", True)):
+            if not way_cfg:
+                raise ValueError("VIDEO.HEAD.VALIDATE_LABELS = False needs TRAIN.WAY (the way cannot be derived without a host sync)")
+            return way_cfg
+        sl = support_labels.detach().reshape(support_labels.shape[0] if batched else 1, -1).cpu()
+        rl = support_real_class.detach().reshape(sl.shape[0], -1).cpu()
+        n_test = len(self.class_real_test)
+        bad = (rl.long() < 0) | (rl.long() >= n_test)
+        if bool(bad.any()):
+            raise IndexError("real_support_labels holds class id %d outside TEST.CLASS_NAME (%d classes) -- the reference "
+                             "raises the same IndexError at few_shot.py:2946" % (int(rl.long()[bad][0]), n_test))
+        counts = [int(torch.unique(row).numel()) for row in sl]
+        way = way_cfg or counts[0]
+        for b, c in enumerate(counts):
+            if c != way:
+                raise ValueError("episode %d has %d distinct support labels, expected way = %d" % (b, c, way))
+        return way
+
     def forward(self, inputs):
         cfg = self.args
         if self.training:
@@ -166,7 +193,7 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
                                "(reference runs/test_net_few_shot.py:59-62 does the same)")
         T = int(cfg.DATA.NUM_INPUT_FRAMES)
         batched = support_images.dim() == 5
-        way = int(getattr(cfg.TRAIN, "WAY", 0)) or int(torch.unique(support_labels).numel())
+        way = self._validate_labels(support_labels, support_real_class, batched)
         eng = self._get_engine(support_images.device)
         logits, class_logits = eng.forward(
             support_images.float().contiguous(), target_images.float().contiguous(), support_labels, support_real_class,

@@ -31,10 +31,22 @@ def init_distributed_training(cfg):
     """Reference :262-277 creates one sub-group per machine; single-node runs need none.  If the launcher
     (torch.distributed.run) exported WORLD_SIZE > 1 and no group exists yet, create it here."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_gpu = torch.cuda.is_available() and int(getattr(cfg, "NUM_GPUS", 1) or 0) > 0
+    if use_gpu:
+        # one process per GPU: bind this rank to ITS device before any allocation or collective (the reference does it in
+        # utils/launcher.py:84-86 `torch.cuda.set_device`); build_model / test_epoch use the current device
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if local_rank >= torch.cuda.device_count():
+            raise RuntimeError("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
     if world > 1 and not is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = getattr(cfg, "DIST_BACKEND", "nccl") if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend=backend)
+        if use_gpu:
+            backend = getattr(cfg, "DIST_BACKEND", "nccl")
+            dist.init_process_group(backend=backend, device_id=torch.device("cuda", torch.cuda.current_device())
+                                    if backend == "nccl" else None)
+        else:
+            dist.init_process_group(backend="gloo")
 
 
 def all_reduce(tensors, average=True):

@@ -8,7 +8,10 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates; `tensor.data_ptr()`),
- *     including all workspaces: the library allocates nothing and keeps no global state;
+ *     including all workspaces: the library allocates no device memory and owns no stream.  Its only process-wide
+ *     state is a cache of per-device facts (CU count, the dynamic-LDS limit already raised for a kernel), keyed by
+ *     device ordinal, so one process may drive several GPUs; each call acts on the CURRENT HIP device, which must be
+ *     the one the operands and the stream belong to;
  *   - `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); all work is enqueued on it and
  *     no entry point synchronises with the host;
  *   - return value 0 = success; non-zero = error, message via cfsar_last_error() (thread-local);
@@ -22,6 +25,11 @@
 
 #ifdef __cplusplus
 extern "C" {
+#endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared between this push and the pop at the end
+ * of the header are exported (tests/test_abi.py compares `nm -D` with this file). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
 #endif
 
 #define CFSAR_F32 0
@@ -183,6 +191,10 @@ int cfsar_prototypes(const float* Xs, const float* support_labels, float* protos
  * logits [B, Q, way]; dists_out (optional, may be NULL) [B, Q, way, T, T].  T <= 32. */
 int cfsar_cos_otam_logits(const float* Xq, const float* protos, float* logits, float* dists_out, int B, int Q,
                           int way, int T, int E, float lambda, int single_direct, cfsar_stream_t stream);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,28 @@
+/*
+ * clipfsar_hip_dev.h -- DEVELOPER hooks of libclipfsar_hip.so.  NOT part of the product ABI.
+ *
+ * These symbols exist only in a library built with `CFSAR_DEV=1 python clip-fsar_amd/build.py` (-DCFSAR_DEV).  The default
+ * (product) build contains neither the hooks nor the ablation branches they switch: `nm -D libclipfsar_hip.so` shows the entry
+ * points of clipfsar_hip.h only (tests/test_abi.py).  Users: tools/gemm_ab.py and friends (in-process, interleaved A/B of
+ * kernel variants on the GPU box).
+ */
+#ifndef CLIPFSAR_HIP_DEV_H
+#define CLIPFSAR_HIP_DEV_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
+/* Force the kernel cfsar_gemm / cfsar_gemm_ex dispatch to (variant) and set the ablation bits (dbg) of the next launches;
+ * (0, 0) restores the product policy.  Variants: see the dispatch comment in csrc/gemm.hip and csrc/gemm_vit.hip. */
+void cfsar_debug_set_gemm_variant(int variant, int dbg);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIPFSAR_HIP_DEV_H */

@@ -1,0 +1,88 @@
+"""bench.py contract tests.
+
+CPU (`-m "not gpu"`): the self-spawn launcher (`python bench.py --gpus 2` with no launcher environment) rehearsed with
+`--dry-run` -- gloo process group, barrier, the one all-gather, max-over-ranks timing, ONE JSON line from rank 0 -- and the
+same protocol under `torch.distributed.run`.
+
+GPU (`-m gpu`): the real bench line carries `roofline` (+ `frac_end_to_end`), `parity` against the reference-generated
+cfg2 golden in the configuration that was timed, and the RCCL (backend "nccl") all-gather path at world size 1
+(`CFSAR_BENCH_FORCE_DIST=1`); `--gpus 2` self-spawn when the box has two GPUs.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(cmd, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert p.returncode == 0, "rc %d\nstdout:\n%s\nstderr:\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and l.rstrip().endswith("}")]
+    assert len(lines) == 1, "expected ONE JSON line, got %d:\n%s" % (len(lines), p.stdout[-2000:])
+    return json.loads(lines[0])
+
+
+def test_self_spawn_dry_run_gloo():
+    out = _run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--episodes-per-step", "2", "--dry-run"])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["gathered_rank_ids"] == [0, 1]                      # the all-gather saw both ranks' accuracy vectors
+    assert out["config"]["launcher"] == "bench.py self-spawn"
+    assert out["scaling"] == "weak" and out["higher_is_better"] is True
+
+
+def test_torchrun_dry_run_gloo():
+    port = 29600 + (os.getpid() % 300)
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--episodes-per-step", "1",
+                "--dry-run"])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["gathered_rank_ids"] == [0, 1]
+    assert out["config"]["launcher"] == "torch.distributed.run"
+
+
+def test_single_process_dry_run():
+    out = _run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--dry-run"])
+    assert out["n_gpus"] == 1 and out["dry_run"] is True
+
+
+needs_gpu = pytest.mark.skipif(not torch.cuda.is_available(), reason="no GPU")
+
+
+@pytest.mark.gpu
+@needs_gpu
+def test_bench_line_bf16_parity_roofline_rccl_ws1():
+    """The timed configuration (bf16, batched episodes, persistent GEMM kernels) is the one whose logits are compared with
+    the reference golden; the RCCL all-gather path runs (world size 1)."""
+    out = _run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--episodes-per-step", "16", "--no-cpu-baseline"],
+               env_extra={"CFSAR_BENCH_FORCE_DIST": "1"})
+    assert out["n_gpus"] == 1 and out["unit"] == "episodes/s" and out["value"] > 0
+    par = out["parity"]
+    assert par["checked"] and par["argmax_equal"] and par["max_abs_dlogits"] < 0.05, par
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] <= 1 and 0 < r["frac_end_to_end"] <= r["frac"] + 0.05
+    assert out["top1_acc_mean"] > 0.5
+
+
+@pytest.mark.gpu
+@needs_gpu
+def test_bench_line_fp32_meets_north_star_tolerance():
+    out = _run([sys.executable, BENCH, "--steps", "1", "--warmup", "1", "--episodes-per-step", "16", "--precision", "fp32",
+                "--no-cpu-baseline", "--no-kernel-events"])
+    par = out["parity"]
+    assert par["checked"] and par["argmax_equal"] and par["max_abs_dlogits"] < 1e-3, par     # north-star tolerance
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_bench_self_spawn_two_gpus_rccl():
+    out = _run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--episodes-per-step", "4"])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["launcher"] == "bench.py self-spawn"

@@ -43,4 +43,4 @@ for tag, n, k in shapes:
         med, mn = statistics.median(times[c]), min(times[c])
         print("%-4s M=%d N=%d K=%d  variant %2d dbg %3d : median %7.1f us (%6.1f TF)  min %7.1f us (%6.1f TF)" % (
             tag, M, n, k, c[0], c[1], med, 2.0 * M * n * k / med / 1e6, mn, 2.0 * M * n * k / mn / 1e6))
-L.cfsar_debug_set_gemm_variant(-1, -1)
+L.cfsar_debug_set_gemm_variant(0, 0)
