@@ -57,39 +57,44 @@ CONFIGS = {
     "rn50": dict(arch="RN50", shot=1, T=8, merge_before=False, gflop=11.997,
                  name="reference shipped backbone: 5-way 1-shot, 1 query/class, 8x224^2 frames, CLIP RN50"),
 }
-GEMM_KERNEL_NOTE = "bf16 MFMA GEMM kernels (QKV, out_proj, c_fc, c_proj, patch embed), csrc/gemm.hip"
+GEMM_KERNEL_NOTE = "16-bit MFMA GEMM kernels (QKV, out_proj, c_fc, c_proj: vit_gemm_kernel, csrc/gemm_vit.hip; patch embed: gemm.hip)"
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
 class GemmTimer:
-    """Wraps hip.gemm: brackets every bf16 GEMM launch with HIP events on the current stream (no host sync) and sums
-    algorithmic FLOPs; durations are read after the timed region."""
+    """Wraps the 16-bit MFMA GEMM entry points of clip_fsar_amd.hip (gemm, gemm_lnfold, gemm_residual_stats): brackets every
+    launch with HIP events on the current stream (no host sync) and sums algorithmic FLOPs; durations are read after the
+    timed region."""
 
     def __init__(self, hip_mod):
         self.hip = hip_mod
-        self.orig = hip_mod.gemm
         self.events = []
         self.flops = 0.0
         self.launches = 0
         self.enabled = False
 
     def install(self):
-        def gemm(A, W, out, *a, **k):
-            if not (self.enabled and A.dtype == torch.bfloat16):
-                return self.orig(A, W, out, *a, **k)
-            M = k.get("M") or A.shape[0]
-            N = k.get("N") or W.shape[0]
-            K = k.get("K") or A.shape[1]
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = self.orig(A, W, out, *a, **k)
-            e.record()
-            self.events.append((s, e))
-            self.flops += 2.0 * M * N * K
-            self.launches += 1
-            return r
-        self.hip.gemm = gemm
-        # engine.py binds `hip` as a module attribute, so patching the module function is enough
+        def wrap(name):
+            orig = getattr(self.hip, name)
+
+            def timed(A, W, out, *a, **k):
+                if not (self.enabled and A.dtype in (torch.bfloat16, torch.float16)):
+                    return orig(A, W, out, *a, **k)
+                M = k.get("M") or A.shape[0]
+                N = k.get("N") or W.shape[0]
+                K = k.get("K") or A.shape[1]
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = orig(A, W, out, *a, **k)
+                e.record()
+                self.events.append((s, e))
+                self.flops += 2.0 * M * N * K
+                self.launches += 1
+                return r
+            setattr(self.hip, name, timed)
+        # engine.py binds `hip` as a module attribute, so patching the module functions is enough
+        for name in ("gemm", "gemm_lnfold", "gemm_residual_stats"):
+            wrap(name)
 
     def result(self):
         ms = sum(s.elapsed_time(e) for s, e in self.events)
@@ -204,6 +209,8 @@ def parse_args(argv=None):
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--dev-gemm-variant", default=None,
+                    help="developer A/B only (needs CFSAR_DEV_LIB=1): 'variant[:dbg]' forced on every 16-bit GEMM, e.g. 13 = p12")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU / gloo rehearsal of the launch + collective + timing protocol with a no-op step "
                          "(tests/test_distributed_gloo.py); prints a line marked dry_run, never a benchmark result")
@@ -280,6 +287,9 @@ def run(args):
         from clip_fsar_amd import hip
         from clip_fsar_amd.engine import ClipFsarEngine
         hip.lib()
+        if args.dev_gemm_variant:
+            v = [int(x) for x in (args.dev_gemm_variant.split(":") + ["0"])[:2]]
+            hip.lib().cfsar_debug_set_gemm_variant(v[0], v[1])
         a = synth.ARCHS[ARCH]
         # identical weights on every rank, built locally (no broadcast needed)
         sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(ARCH, SEED).items()}

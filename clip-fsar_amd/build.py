@@ -13,11 +13,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libclipfsar_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "rowops.hip", "attention.hip", "tail.hip", "conv.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_vit.hip", "rowops.hip", "attention.hip", "tail.hip", "conv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# CFSAR_DEV=1: developer build -- compiles the ablation switches and the cfsar_debug_* hooks of include/clipfsar_hip_dev.h into
-# the same .so name (tools/*.py need it).  The product build (default) contains none of them; tests/test_abi.py checks that.
-DEV = os.environ.get("CFSAR_DEV", "0") == "1"
+# Developer build (`python clip-fsar_amd/build.py --dev`): the same sources with -DCFSAR_DEV -- ablation switches and the
+# cfsar_debug_* hooks of include/clipfsar_hip_dev.h -- as a SEPARATE library, libclipfsar_hip_dev.so, which clip_fsar_amd.hip
+# loads only when CFSAR_DEV_LIB=1 (tools/*.py set it).  The product library contains none of it; tests/test_abi.py checks that.
+DEV_LIB = os.path.join(HERE, "libclipfsar_hip_dev.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          "-Rpass-analysis=kernel-resource-usage"]      # per-kernel VGPR / scratch report -> build/resource_usage.json
 USAGE = os.path.join(HERE, "build", "resource_usage.json")
@@ -43,24 +44,26 @@ def _parse_usage(text: str) -> dict:
     return out
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _stale(lib=LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
         os.path.join(os.path.dirname(HERE), "include", "clipfsar_hip.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
-        return LIB
+def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
+    LIB_OUT = DEV_LIB if dev else LIB
+    if not force and not _stale(LIB_OUT):
+        return LIB_OUT
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    bdir = os.path.join(HERE, "build", "dev") if dev else os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + (["-DCFSAR_DEV"] if DEV else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
+        cmd = [HIPCC] + FLAGS + (["-DCFSAR_DEV"] if dev else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -75,14 +78,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose and rest.strip():
             print(rest)
     import json
-    with open(USAGE, "w") as f:
+    with open(USAGE if not dev else os.path.join(bdir, "resource_usage.json"), "w") as f:
         json.dump(usage, f, indent=0, sort_keys=True)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_OUT] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return LIB_OUT
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv))

@@ -21,6 +21,10 @@
 #include <utility>
 
 #include "common.h"
+#include "gemm_vit.h"
+#ifdef CFSAR_DEV
+#include "../../include/clipfsar_hip_dev.h"
+#endif
 
 namespace {
 
@@ -802,6 +806,12 @@ __device__ __forceinline__ int tile_group(const GemmArgs& p, int ntiles) {
 #ifdef CFSAR_DEV
 static int g_variant_override = 0, g_dbg_override = 0;   // dev tool: in-process A/B (tools/gemm_ab.py)
 #endif
+// product policy of the gemm_vit.hip kernel (measured, M = 252 160: profiles/r02_gemm_ab.md): the LDS-DMA operand path for the
+// short-K GEMMs (QKV 859 vs 871 us register-staged vs 890 p12; c_fc 1 279 vs 1 335 vs 1 292), the register-staged path (loads two
+// K tiles ahead) for K > 1 024 (c_proj 1 093 vs 1 156 us with DMA), write-through (sc1) stores where the output is not read back
+// by the same launch (QKV 850 vs 859, c_fc 1 273 vs 1 279; the in-place residual update is slower with it: 365 vs 350)
+constexpr bool kUseVitKernel = true;
+constexpr int kVitGroup = 8, kVitColfast = 0;
 
 // ---- helpers shared by the register-staged kernels (p10, p12)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: loads/stores stay SSA values (no memcpy)
@@ -1385,6 +1395,29 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     if (in_dtype == CFSAR_F32 && out_dtype == CFSAR_F32 && res_dtype == CFSAR_F32 && row_group == 0 && res_mod == 0 && K % 4 == 0 &&
         lda % 4 == 0 && ldw % 4 == 0 && M <= 256 && (forced == 14 || (forced == 0 && M <= 192)))
         return launch_skinny_f32(a, s);
+    // The ViT-block GEMMs at batch scale (bias [+ QuickGELU] -> bf16, or bias + fp16 residual -> fp16; >= two 256x256 tiles per
+    // CU): the persistent kernel of gemm_vit.hip whose operand pipeline runs through the epilogues.  Dev builds: variant
+    // 20 + 4 * opath + store forces it on any shape; dbg bit 256 = column-fastest tile walk, bits 9-11 = band group (see below).
+    if (in_dtype == CFSAR_BF16 && row_group == 0 && res_mod == 0 && row_off == 0 &&
+        ((forced == 0 && kUseVitKernel && tiles4 >= 512) || (forced >= 20 && forced < 28))) {
+        VitGemmCall c;
+        c.A = A; c.W = W; c.out = out; c.bias = bias; c.res = residual;
+        c.rowstats = nullptr; c.cvec = nullptr; c.stats_out = nullptr;
+        c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = ldr;
+        c.out_dtype = out_dtype; c.res_dtype = res_dtype; c.act = act; c.relu = relu;
+        c.opath = K <= 1024 ? 1 : 0;
+        c.store = residual ? 0 : 2;
+        c.group = kVitGroup; c.colfast = kVitColfast; c.dbg = 0;
+#ifdef CFSAR_DEV
+        if (forced >= 20) { c.opath = (forced - 20) >> 2; c.store = (forced - 20) & 3; }
+        c.dbg = g_dbg_override;
+        if (g_dbg_override & 256) c.colfast = 1;
+        constexpr int groups[8] = {0, 4, 16, 2, 32, 1, 3, 6};
+        if ((g_dbg_override >> 9) & 7) c.group = groups[(g_dbg_override >> 9) & 7];
+#endif
+        const int rc = cfsar_gemm_vit_try(c, s);
+        if (rc != -2) return rc;
+    }
     // p12 measured fastest on all four ViT GEMMs (M = 252 160, same box, interleaved: QKV 888 vs 960 us (p10), out_proj 457 vs
     // 476, c_fc 1 288 vs 1 409 (p6), c_proj 1 143 vs 1 178) and on the RN50 1x1 convs with N >= 256 (tools/rn_gemm_ab.py).
     // 13 = the persistent form (one workgroup per CU walking its tiles: no retire -> dispatch gap; +3 % on QKV / c_fc), the auto

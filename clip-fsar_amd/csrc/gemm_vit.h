@@ -1,0 +1,42 @@
+// Internal interface between the cfsar_gemm_ex dispatcher (gemm.hip) and the persistent ViT GEMM kernel (gemm_vit.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct VitGemmArgs {          // kernel argument block
+    const char* A;            // activations [M, lda] bf16
+    const char* W;            // weights [N, ldw] bf16 (nn.Linear layout)
+    void* out;                // [M, ldo] bf16 (no residual) or fp16 (residual stream)
+    const float* bias;        // [N]
+    const void* res;          // fp16 residual [M, ldr] or NULL
+    const float* rowstats;    // LN-folded mode: [M, 4] = (mean, std, 1 / std, -) per row of A, else NULL
+    const float* cvec;        // LN-folded mode: c_n = sum_k W'_nk, [N]
+    float* stats_out;         // residual mode, optional: [M, stats_slots, 2] partial (sum, sum of squares) of the stored rows
+    int stats_slots;          // N / 64
+    int M, N, K;
+    int lda, ldw, ldo, ldr;
+    int act;
+    int tiles_n, ntiles;      // 256 x 256 output tiles
+    int group, colfast;       // tile walk inside an XCD's range (see tile_of)
+#ifdef CFSAR_DEV
+    int dbg;                  // ablations: 4 = no epilogue, 8 = every workgroup reads tile (0, 0)
+#endif
+};
+
+struct VitGemmCall {          // host-side request
+    const void* A;
+    const void* W;
+    void* out;
+    const float* bias;
+    const void* res;
+    const float* rowstats;
+    const float* cvec;
+    float* stats_out;
+    int M, N, K, lda, ldw, ldo, ldr;
+    int out_dtype, res_dtype, act, relu;
+    int opath, store;         // operand path (0 register-staged, 1 LDS-DMA), store policy (0 default, 1 nt, 2 sc1; dev builds)
+    int group, colfast;
+    int dbg;
+};
+
+// 0 = launched, > 0 = error (cfsar_last_error), -2 = outside this kernel's contract (caller falls back)
+int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s);

@@ -1,0 +1,629 @@
+// The bf16 GEMMs of the CLIP ViT blocks at batch scale: QKV / c_fc (bias [+ QuickGELU], bf16 out) and out_proj / c_proj
+// (bias + fp16 residual stream, fp16 out) -- few_shot.py:623,626-628,633-640 -- as ONE persistent kernel whose operand
+// pipeline never drains between output tiles.
+//
+// What it keeps from gemm_kernel_p12 (gemm.hip): 256 x 256 output tile, 512 threads = two waves per SIMD (2(M) x 4(N) waves,
+// 128 x 64 wave tiles, 128 accumulators), 128-byte K tiles fetched as whole cache lines, two 64 KiB LDS stages with
+// XOR-swizzled 128-byte rows, one barrier per K tile, operands swapped so a lane owns 4 consecutive output columns.
+//
+// What is new (round 2; the numbers that motivated it are in profiles/r02_gemm_pmc_baseline.md):
+//   * The epilogue no longer aliases the operand stages.  Each wave transposes ONE 32-row x 64-column slab at a time through a
+//     private 4 KiB region above the stages (values packed to 2 bytes BEFORE the LDS round trip, 8-byte conflict-free writes,
+//     16-byte reads, whole 128-byte output lines per 8 lanes).  p12 staged 17 KiB of fp32 per wave over the stages, so every
+//     tile paid a pipeline drain + a 7 K-cycle refill (measured) around a 6.8 K-cycle epilogue.
+//   * Because the stages stay intact, the last K tile of an output tile already stages K tile 0 of the NEXT output tile (and, on
+//     the register path, holds K tile 1 in flight through the epilogue): the refill disappears and the L2 -> LDS stream keeps
+//     running while the epilogue's VALU / store work executes.
+//   * Two operand paths behind one schedule (OPATH): 0 = global_load -> VGPR -> ds_write_b128 (p12's; loads run two K tiles ahead),
+//     1 = LDS-DMA (global_load_lds_dwordx4 issued from inline asm, one K tile ahead, no ds_write traffic, 32 fewer VGPRs).
+//   * Tile walk and store cache policy are parameters (the XCD's L2 holds 4 MiB: what matters is which tiles its 32 CUs work
+//     on at the same time and whether 128 KiB of output per tile is allowed to evict the operands).
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "gemm_vit.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+constexpr int TM = 256, TN = 256;              // output tile
+constexpr int ROWB = 128;                      // bytes of K per row per K tile (64 bf16)
+constexpr int STAGE = (TM + TN) * ROWB;        // 64 KiB: X rows [0, 32 KiB), W rows [32 KiB, 64 KiB)
+constexpr int EPI_OFF = 2 * STAGE;             // wave-private epilogue slabs above the two stages
+constexpr int EPI_SLAB = 32 * 128;             // 32 rows x 64 two-byte values
+constexpr int LDS_BYTES = EPI_OFF + 8 * EPI_SLAB;   // 163 840 B = all of a CU's LDS
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+// LDS-DMA, 16 B per lane: LDS[m0 + lane*16 .. +16] = *(src).  M0 is compiler-reserved: saved / restored inside the statement.
+__device__ __forceinline__ void glds16_asm(const char* src, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_addr)
+        : "memory");
+}
+
+// x * sigmoid(1.702 x) for four values, few_shot.py:614-616.
+// gfx950 / ROCm 7.2 finding (this kernel's LN-folded c_fc returned exact zeros in lanes 48-63 of some accumulators; value dump in
+// tools/dbg_lnfold.py): hipcc recycles the SOURCE register of a transcendental in the very next instruction
+// ("v_rcp_f32 v228, v163 ; v_add_f32 v163, 1.0, v175").  v_exp_f32 / v_rcp_f32 run in the quarter-rate transcendental pipe; with
+// several of them queued back to back the pipe reads its operand after the following full-rate VALU instruction has already
+// rewritten it, for the last lane group.  (A lone v_rcp + overwrite does not show it: tools/ubench/trans_war.hip.)  The empty asm
+// statement below takes the transcendental INPUTS and the final products as operands: the inputs must stay intact until the
+// products exist, i.e. until every transcendental has executed.  It emits no instruction.
+__device__ __forceinline__ void quick_gelu4(float (&v)[4]) {
+    float z[4], d[4], o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) z[j] = -1.702f * 1.4426950408889634f * v[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = 1.0f + __builtin_amdgcn_exp2f(z[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = v[j] * __builtin_amdgcn_rcpf(d[j]);
+    asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])
+                 : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = o[j];
+}
+
+// 16-byte global store with a cache policy: 0 = default (write-back, line stays in this XCD's L2), 1 = nt, 2 = sc1
+// (write-through: the line is not kept, MI355X_MICROARCH.md "stores of each flavour")
+template <int POLICY>
+__device__ __forceinline__ void store16(void* dst, u32x4 v) {
+    if constexpr (POLICY == 1) {
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
+    } else if constexpr (POLICY == 2) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+    } else {
+        *reinterpret_cast<u32x4*>(dst) = v;
+    }
+}
+
+// linear tile index (inside one XCD's contiguous range) -> (row band, column tile).  `group` row bands are finished before
+// the next group starts; inside a group either the band index runs fastest (colfast = 0: concurrent workgroups cover
+// group x 32/group tiles) or the column index does (colfast = 1: ~32/tiles_n bands x every column at a time).
+__device__ __forceinline__ void tile_of(int lin, int tiles_m, int tiles_n, int group, int colfast, int& tm, int& tn) {
+    const int per = group * tiles_n;
+    const int gid = lin / per, first = gid * group;
+    const int gsz = tiles_m - first < group ? tiles_m - first : group;
+    const int rem = lin - gid * per;
+    if (colfast) {
+        tm = first + rem / tiles_n;
+        tn = rem - (rem / tiles_n) * tiles_n;
+    } else {
+        tm = first + rem % gsz;
+        tn = rem / gsz;
+    }
+}
+
+// ---- epilogue: the wave's 128 x 64 accumulator tile -> global, 32 rows at a time through the wave's 4 KiB slab.
+// Accumulator layout (operands swapped): acc[mi][ni][4g + j] = C[row 32 mi + (lane & 31)][col 32 ni + 8 g + 4 (lane >> 5) + j].
+// The bias is already IN the accumulators (they are initialised with it, see the kernel), so a pass is: [activation] -> pack to
+// 2 bytes -> 8 ds_write_b64 -> 4 ds_read_b128 -> [+ residual] -> 4 global stores of 16 bytes per lane.
+// Write: the lane's 4 columns of group (ni, g) go to 8-byte slot ((2 q + hi) ^ (row & 15)) of row `row` (q = 4 ni + g): 16
+// consecutive lanes hit 16 different slots -> conflict-free ds_write_b64.  Read: lane (rr = lane >> 3, Q = lane & 7) takes the
+// 16-byte chunk Q of rows rr, rr + 8, ...: its two halves are slots (2Q) ^ f and (2Q + 1) ^ f, i.e. the aligned pair (Q ^ (f >> 1))
+// with the halves swapped when f is odd -> one conflict-free ds_read_b128 + a per-lane-constant select.  8 lanes then store one
+// whole 128-byte line, 8 rows per wave-instruction.  FULL: every row and column of the wave tile is inside the matrix
+// (straight-line code, no predicates); otherwise rows are clamped for the loads and the stores are predicated.
+// ROWSCALE (LN-folded consumer, see the kernel): the accumulator of row 32 mi + lr is multiplied by rscale[mi] = 1 / std(row)
+// before the activation.  STATS (residual producer): per row, the sum and the sum of squares of the 64 STORED (rounded) values of
+// this wave are written to stats_out[row][slot = column / 64] -- the LayerNorm statistics of the next LN-folded GEMM come from
+// these partials (cfsar_ln_stats_finalize), so the residual stream is never re-read for them.
+template <typename TO, int ACT, bool HAS_RES, int STORE, bool FULL, bool ROWSCALE = false>
+__device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemmArgs& p, int mb, int nb, int lane, char* slab,
+                                              const float (&rscale)[4]) {
+    typedef typename Vec2B<TO>::v4 TO4;
+    typedef typename Vec2B<TO>::v8 TO8;
+    const int lr = lane & 31, hi = lane >> 5;
+    const int rr = lane >> 3, Q = lane & 7;
+    const bool colok = FULL || nb + 64 <= p.N;              // whole-wave predicate (N % 64 == 0)
+    const int ncl = colok ? nb : p.N - 64;                  // clamped column base: loads stay in bounds
+    char* wr = slab + lr * 128;
+    const int wsw = lr & 15;
+    const bool swap_halves = rr & 1;
+    // byte offset of (row mb + rr, column ncl + 8 Q); rows advance by 8 per read-back step (M * ldo * 2 < 4 GiB: launcher)
+    const unsigned ostep = (unsigned)p.ldo * 16u, rstep = (unsigned)p.ldr * 16u;
+    char* outp = reinterpret_cast<char*>(p.out) + ((size_t)(mb + rr) * p.ldo + ncl + 8 * Q) * 2;
+    const char* resp = HAS_RES ? reinterpret_cast<const char*>(p.res) + ((size_t)(mb + rr) * p.ldr + ncl + 8 * Q) * 2 : nullptr;
+    const int rd0 = rr * 128 + ((Q ^ ((rr >> 1) & 7)) << 4);       // row rr + 8 it: + it * 1024, chunk ^ (4 it & 7) << 4
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        u32x4 rv[4];
+        bool rowok[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int step = mi * 4 + it;
+            rowok[it] = FULL || mb + rr + step * 8 < p.M;
+            if constexpr (HAS_RES) {
+                if (FULL || rowok[it]) rv[it] = *reinterpret_cast<const u32x4*>(resp + (size_t)step * rstep);
+                else rv[it] = u32x4{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                TO4 o;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = acc[mi][ni][4 * g + j];
+                    if constexpr (ROWSCALE) v[j] *= rscale[mi];
+                }
+                if constexpr (ACT == CFSAR_ACT_QUICKGELU) quick_gelu4(v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (TO)v[j];
+                const int slot = (2 * (ni * 4 + g) + hi) ^ wsw;
+                *reinterpret_cast<TO4*>(wr + slot * 8) = o;
+            }
+        u32x4 d[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)                       // row r = 8 it + rr: (r >> 1) & 7 = ((rr >> 1) + 4 it) & 7
+            d[it] = *reinterpret_cast<const u32x4*>(slab + it * 1024 + (rd0 ^ ((it & 1) << 6)));
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            u32x4 x = d[it];
+            if (swap_halves) x = u32x4{x[2], x[3], x[0], x[1]};
+            if constexpr (HAS_RES) {
+                const TO8 a = __builtin_bit_cast(TO8, x), b = __builtin_bit_cast(TO8, rv[it]);
+                TO8 s;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] = (TO)((float)a[j] + (float)b[j]);
+                x = __builtin_bit_cast(u32x4, s);
+                if (p.stats_out) {                           // wave-uniform
+                    float ps = 0.f, pq = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float f = (float)s[j];
+                        ps += f;
+                        pq = fmaf(f, f, pq);
+                    }
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) {        // the 8 lanes Q = 0..7 of a row are consecutive
+                        ps += __shfl_xor(ps, o, 64);
+                        pq += __shfl_xor(pq, o, 64);
+                    }
+                    if (Q == 0 && (FULL || (rowok[it] && colok)))
+                        *reinterpret_cast<float2*>(p.stats_out + ((size_t)(mb + rr + (mi * 4 + it) * 8) * p.stats_slots + (nb >> 6)) * 2) =
+                            make_float2(ps, pq);
+                }
+            }
+            if (FULL || (rowok[it] && colok)) store16<STORE>(outp + (size_t)(mi * 4 + it) * ostep, x);
+        }
+    }
+}
+
+// OPATH 0: register-staged operands (global_load_dwordx4 -> VGPR -> ds_write_b128), loads two K tiles ahead.
+// OPATH 1: LDS-DMA operands (global_load_lds_dwordx4), one K tile ahead.
+// MODE 0: out = act(A W^T + bias)                      (TI = bf16 operands)
+// MODE 1: x   = x + A W^T + bias, fp16 in place        (TI = bf16; optional row-statistics partials, see epilogue_rows)
+// MODE 2: out = act(LayerNorm(x) W^T + bias) computed WITHOUT materialising LayerNorm(x) (few_shot.py:605-611, 626-640):
+//         with W' = W diag(gamma) (fp16, folded at init), c_n = sum_k W'_nk, d_n = sum_k beta_k W_nk + bias_n and the row's
+//         (mean, std):   LN(x) W^T + bias = (x W'^T - mean c) / std + d.
+//         The MFMAs run on the raw fp16 residual stream (TI = f16: same rate as bf16, 3 more mantissa bits); the accumulators
+//         start at d_n * std_m, one extra MFMA per 32x32 tile adds the rank-1 term -mean_m c_n (operands split into fp16
+//         hi + lo parts: ~22 bits), and the epilogue multiplies the row by 1 / std_m.
+template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE>
+__global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
+    constexpr bool HAS_RES = MODE == 1;
+    constexpr bool LNFOLD = MODE == 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lr = lane & 31, hi = lane >> 5;
+
+    // ---- tile walk: virtual block ids b, b + grid, ...; id -> XCD-contiguous linear index -> (band, column)
+    const int nt = p.ntiles, grid = (int)gridDim.x;
+    const int xq = nt >> 3, xr = nt & 7;
+    const int tiles_m = nt / p.tiles_n;
+    auto origin = [&](int b, int& m0, int& n0) __attribute__((always_inline)) {
+        const int xcd = b & 7;
+        const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
+        int tm, tn;
+        tile_of(lin, tiles_m, p.tiles_n, p.group, p.colfast, tm, tn);
+        m0 = tm * TM;
+        n0 = tn * TN;
+#ifdef CFSAR_DEV
+        if (p.dbg & 8) { m0 = 0; n0 = 0; }     // ablation: every workgroup reads tile (0, 0) (cache-hot operands)
+#endif
+    };
+    // per-lane source offsets of the 4 + 4 staging pieces (8 rows x 128 B each; wave w owns pieces {w, w+8, w+16, w+24})
+    auto offsets = [&](int m0, int n0, unsigned (&ox)[4], unsigned (&ow)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 8 + wave) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ swz(row);
+            int gm = m0 + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            int gn = n0 + row;
+            gn = gn < p.N ? gn : p.N - 1;
+            ox[i] = (unsigned)gm * (unsigned)p.lda * 2u + chunk * 16;
+            ow[i] = (unsigned)gn * (unsigned)p.ldw * 2u + chunk * 16;
+        }
+    };
+
+    const int wr_off = wave * 1024 + lane * 16;          // register path: + piece i * 8192 (+ TM*ROWB for W) inside a stage
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);   // DMA path: same layout
+    int rdX[4], rdW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rx = wm * 128 + i * 32 + lr;
+        rdX[i] = rx * ROWB + ((hi ^ swz(rx)) << 4);                        // sub-step ss: ^ (ss << 5)
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rw = wn * 64 + i * 32 + lr;
+        rdW[i] = TM * ROWB + rw * ROWB + ((hi ^ swz(rw)) << 4);
+    }
+
+    const int nk = p.K / 64;
+    f32x16 acc[4][2];
+    // The accumulators START at the bias: lane columns 32 ni + 8 g + 4 hi + j of the wave's 64 -> no bias add in the epilogue.
+    // The 8 x 16-byte loads for the NEXT output tile are issued before the current epilogue and consumed after it.
+    float4 bnext[2][4];
+    float4 rsn[LNFOLD ? 4 : 1];          // LNFOLD: (mean, std, 1/std, -) of rows 32 mi + lr of the next tile (cfsar_ln_stats_finalize)
+    float cn[LNFOLD ? 2 : 1];            // LNFOLD: c of columns 32 ni + lr
+    float rscale[4] = {1.f, 1.f, 1.f, 1.f};
+    auto load_bias = [&](int m0_, int n0_) __attribute__((always_inline)) {
+        int nb_ = n0_ + wn * 64;
+        nb_ = nb_ + 64 <= p.N ? nb_ : p.N - 64;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bnext[ni][g] = *reinterpret_cast<const float4*>(p.bias + nb_ + ni * 32 + 8 * g + 4 * hi);
+        if constexpr (LNFOLD) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                int m = m0_ + wm * 128 + mi * 32 + lr;
+                m = m < p.M ? m : p.M - 1;
+                rsn[mi] = *reinterpret_cast<const float4*>(p.rowstats + (size_t)m * 4);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) cn[ni] = p.cvec[nb_ + ni * 32 + lr];
+        }
+    };
+    u32x4 GX[4], GW[4];
+    uint4 xfA[4], wfA[2], xfB[4], wfB[2];
+    auto gloadX = [&](const unsigned (&ox)[4], int kt, auto J) __attribute__((always_inline)) {
+        GX[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.A + (size_t)kt * ROWB + ox[decltype(J)::value]);
+    };
+    auto gloadW = [&](const unsigned (&ow)[4], int kt, auto J) __attribute__((always_inline)) {
+        GW[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.W + (size_t)kt * ROWB + ow[decltype(J)::value]);
+    };
+    auto swriteX = [&](int stage, auto J) __attribute__((always_inline)) {
+        *reinterpret_cast<u32x4*>(smem + stage * STAGE + wr_off + decltype(J)::value * 8192) = GX[decltype(J)::value];
+    };
+    auto swriteW = [&](int stage, auto J) __attribute__((always_inline)) {
+        *reinterpret_cast<u32x4*>(smem + stage * STAGE + TM * ROWB + wr_off + decltype(J)::value * 8192) = GW[decltype(J)::value];
+    };
+    auto dmaX = [&](const unsigned (&ox)[4], int kt, int stage, auto J) __attribute__((always_inline)) {
+        glds16_asm(p.A + (size_t)kt * ROWB + ox[decltype(J)::value],
+                   ldsw + (unsigned)stage * (unsigned)STAGE + (unsigned)decltype(J)::value * 8192u);
+    };
+    auto dmaW = [&](const unsigned (&ow)[4], int kt, int stage, auto J) __attribute__((always_inline)) {
+        glds16_asm(p.W + (size_t)kt * ROWB + ow[decltype(J)::value],
+                   ldsw + (unsigned)stage * (unsigned)STAGE + (unsigned)(TM * ROWB) + (unsigned)decltype(J)::value * 8192u);
+    };
+    // read order = order of first use by the MFMA sequence (ni-major): x0 w0 x1 x2 x3 w1
+    auto load_one = [&](int stage, int ss, auto J, uint4 (&xf)[4], uint4 (&wf)[2]) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        const char* base = smem + stage * STAGE;
+        const int x2 = ss << 5;
+        constexpr int isx[6] = {1, 0, 1, 1, 1, 0};
+        constexpr int idx[6] = {0, 0, 1, 2, 3, 1};
+        if constexpr (isx[j] != 0) xf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdX[idx[j]] ^ x2));
+        else wf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdW[idx[j]] ^ x2));
+    };
+    auto mfma_one = [&](auto J, uint4 (&xf)[4], uint4 (&wf)[2]) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        constexpr int ni = j >> 2, mi = j & 3;
+        if constexpr (std::is_same<TI, _Float16>::value)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ni]), __builtin_bit_cast(f16x8, xf[mi]),
+                                                                 acc[mi][ni], 0, 0, 0);
+        else
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]),
+                                                                  acc[mi][ni], 0, 0, 0);
+    };
+    // One 128-byte K tile = 4 sub-steps of 8 MFMAs; `cur` / `nxt` = LDS stages of this K tile / the following one.
+    //   LOAD : operands of a later K tile are fetched: (ox, ow, ksrc) name them (register path: two K tiles ahead -> VGPRs;
+    //          DMA path: one K tile ahead -> stage nxt)
+    //   WRITE: (register path) the VGPRs hold the following K tile: write it to stage nxt
+    //   SYNC : barrier after MFMA 1 of sub-step 3 (the following K tile is complete in LDS for every wave)
+    //   FRAGS: prefetch the first fragments of the following K tile after the barrier (off at an output-tile boundary: the
+    //          epilogue runs in between)
+    auto step = [&](int cur, int nxt, const unsigned (&ox)[4], const unsigned (&ow)[4], int ksrc, auto LOAD, auto WRITE, auto SYNC, auto FRAGS) __attribute__((always_inline)) {
+        constexpr bool load = decltype(LOAD)::value, write = decltype(WRITE)::value, sync = decltype(SYNC)::value,
+                       frags = decltype(FRAGS)::value;
+        static_for<8>([&](auto J) {                                     // sub-step 0
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfA, wfA);
+            if constexpr (j < 6) load_one(cur, 1, J, xfB, wfB);
+            if constexpr (j >= 4) {
+                if constexpr (OPATH == 0) { if constexpr (write) swriteX(nxt, std::integral_constant<int, j - 4>{}); }
+                else { if constexpr (load) dmaX(ox, ksrc, nxt, std::integral_constant<int, j - 4>{}); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<8>([&](auto J) {                                     // sub-step 1
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfB, wfB);
+            if constexpr (j < 6) load_one(cur, 2, J, xfA, wfA);
+            if constexpr (j >= 4) {
+                if constexpr (OPATH == 0) { if constexpr (load) gloadX(ox, ksrc, std::integral_constant<int, j - 4>{}); }
+                else { if constexpr (load) dmaW(ow, ksrc, nxt, std::integral_constant<int, j - 4>{}); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<8>([&](auto J) {                                     // sub-step 2
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfA, wfA);
+            if constexpr (j < 6) load_one(cur, 3, J, xfB, wfB);
+            if constexpr (j >= 4 && OPATH == 0 && write) swriteW(nxt, std::integral_constant<int, j - 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<8>([&](auto J) {                                     // sub-step 3
+            constexpr int j = decltype(J)::value;
+            mfma_one(J, xfB, wfB);
+            if constexpr (j < 2) {
+                if constexpr (OPATH == 0 && load) {
+                    gloadW(ow, ksrc, std::integral_constant<int, 2 * j>{});
+                    gloadW(ow, ksrc, std::integral_constant<int, 2 * j + 1>{});
+                }
+            } else if constexpr (frags) load_one(nxt, 0, std::integral_constant<int, j - 2>{}, xfA, wfA);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j == 1 && sync) {
+                if constexpr (OPATH == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+                __syncthreads();                                        // (register path: hipcc adds lgkmcnt(0) for the ds_writes)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    int b = blockIdx.x;
+    if (b >= nt) return;
+    int m0, n0;
+    origin(b, m0, n0);
+    unsigned offX[4], offW[4];
+    offsets(m0, n0, offX, offW);
+    load_bias(m0, n0);
+    // ---- pipeline fill for the first output tile of this workgroup
+    if constexpr (OPATH == 0) {
+        static_for<4>([&](auto J) { gloadX(offX, 0, J); });
+        static_for<4>([&](auto J) { gloadW(offW, 0, J); });
+        static_for<4>([&](auto J) { swriteX(0, J); });
+        static_for<4>([&](auto J) { swriteW(0, J); });
+        static_for<4>([&](auto J) { gloadX(offX, 1, J); });
+        static_for<4>([&](auto J) { gloadW(offW, 1, J); });
+    } else {
+        static_for<4>([&](auto J) { dmaX(offX, 0, 0, J); });
+        static_for<4>([&](auto J) { dmaW(offW, 0, 0, J); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    int sb = 0;                                   // stage that holds K tile 0 of the current output tile
+    char* slab = smem + EPI_OFF + wave * EPI_SLAB;
+    for (;;) {
+        const int bn = b + grid;
+        const bool has_next = bn < nt;
+        int m0n = m0, n0n = n0;
+        if (has_next) origin(bn, m0n, n0n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float sc = LNFOLD ? rsn[LNFOLD ? i : 0].y : 1.0f;      // std of row 32 i + lr
+                    acc[i][j][4 * g] = bnext[j][g].x * sc;
+                    acc[i][j][4 * g + 1] = bnext[j][g].y * sc;
+                    acc[i][j][4 * g + 2] = bnext[j][g].z * sc;
+                    acc[i][j][4 * g + 3] = bnext[j][g].w * sc;
+                }
+        if constexpr (LNFOLD) {
+            // rank-1 term  acc[n][m] -= c_n mean_m  as ONE MFMA per 32x32 tile: k slots 0..2 of the lanes with hi == 0 carry
+            // (c_hi, c_hi, c_lo) x (-mean_hi, -mean_lo, -mean_hi); every other k slot is zero
+            f16x8 cw[2], mx[4];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const _Float16 h = (_Float16)cn[ni], l = (_Float16)(cn[ni] - (float)h);
+                cw[ni] = f16x8{h, h, l, 0, 0, 0, 0, 0};
+                if (hi) cw[ni] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const float nm = -rsn[mi].x;
+                const _Float16 h = (_Float16)nm, l = (_Float16)(nm - (float)h);
+                mx[mi] = f16x8{h, l, h, 0, 0, 0, 0, 0};
+                rscale[mi] = rsn[mi].z;
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cw[ni], mx[mi], acc[mi][ni], 0, 0, 0);
+        }
+        static_for<6>([&](auto J) { load_one(sb, 0, J, xfA, wfA); });
+        int kt = 0;
+        // The tail steps ALWAYS prefetch (one straight-line MFMA stream: a fork on has_next would merge two 128-register
+        // accumulator sets through phi copies).  After the last output tile of this workgroup the "next" origin is the current
+        // one, so the surplus loads re-read valid memory and the surplus LDS writes land in the free stage.
+        if constexpr (OPATH == 0) {
+            for (; kt < nk - 2; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 2, T_{}, T_{}, T_{}, T_{});
+            offsets(m0n, n0n, offX, offW);              // this tile's remaining K tiles are already in registers / LDS
+            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, T_{}, T_{}, T_{});           // loads K tile 0 of the next tile
+            ++kt;
+            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 1, T_{}, T_{}, T_{}, F_{});           // writes it, loads K tile 1
+        } else {
+            for (; kt < nk - 1; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 1, T_{}, F_{}, T_{}, T_{});
+            offsets(m0n, n0n, offX, offW);
+            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, F_{});           // K tile 0 of the next tile
+        }
+        load_bias(m0n, n0n);                                             // lands during the epilogue
+#ifdef CFSAR_DEV
+        if (p.dbg & 4) {                                                // ablation: no epilogue (keep the accumulators live)
+            if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[3][1][2] + acc[2][0][1];
+        } else
+#endif
+        {
+            const int mb = m0 + wm * 128, nb = n0 + wn * 64;
+            if (mb + 128 <= p.M && nb + 64 <= p.N) epilogue_rows<TO, ACT, HAS_RES, STORE, true, LNFOLD>(acc, p, mb, nb, lane, slab, rscale);
+            else epilogue_rows<TO, ACT, HAS_RES, STORE, false, LNFOLD>(acc, p, mb, nb, lane, slab, rscale);
+        }
+        if (!has_next) break;
+        sb = (sb + nk) & 1;
+        b = bn;
+        m0 = m0n;
+        n0 = n0n;
+    }
+}
+
+int persistent_grid() {
+    const int n = cfsar_num_cus() & ~7;         // one workgroup per CU; the block -> XCD walk assumes a multiple of 8
+    return n >= 8 ? n : 8;
+}
+
+template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE>
+int launch_inst(const VitGemmArgs& a, hipStream_t s) {
+    auto* fn = &vit_gemm_kernel<TI, TO, ACT, MODE, OPATH, STORE>;
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(fn), LDS_BYTES, "cfsar_gemm(vit)")) return rc;
+    const int grid = a.ntiles < persistent_grid() ? ((a.ntiles + 7) & ~7) : persistent_grid();
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), LDS_BYTES, s, a);
+    return cfsar_check_launch("cfsar_gemm(vit)");
+}
+
+// mode: 0 bias -> bf16, 1 residual -> fp16 in place, 2 LN-folded (fp16 operands) -> bf16
+template <int OPATH, int STORE>
+int launch_path(const VitGemmArgs& a, int mode, hipStream_t s) {
+    if (mode == 1) return launch_inst<__bf16, _Float16, CFSAR_ACT_NONE, 1, OPATH, STORE>(a, s);
+    if (mode == 2) {
+        if (a.act == CFSAR_ACT_QUICKGELU) return launch_inst<_Float16, __bf16, CFSAR_ACT_QUICKGELU, 2, OPATH, STORE>(a, s);
+        return launch_inst<_Float16, __bf16, CFSAR_ACT_NONE, 2, OPATH, STORE>(a, s);
+    }
+    if (a.act == CFSAR_ACT_QUICKGELU) return launch_inst<__bf16, __bf16, CFSAR_ACT_QUICKGELU, 0, OPATH, STORE>(a, s);
+    return launch_inst<__bf16, __bf16, CFSAR_ACT_NONE, 0, OPATH, STORE>(a, s);
+}
+
+}  // namespace
+
+// Returns -2 when the call is outside this kernel's contract (the caller falls back to the generic kernels of gemm.hip).
+int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
+    const bool lnfold = c.rowstats != nullptr;
+    const bool f16res = !lnfold && c.out_dtype == CFSAR_F16 && c.res && c.res_dtype == CFSAR_F16 && c.act == CFSAR_ACT_NONE;
+    const bool bf16plain = c.out_dtype == CFSAR_BF16 && !c.res && (c.act == CFSAR_ACT_NONE || c.act == CFSAR_ACT_QUICKGELU);
+    if (!(f16res || bf16plain) || !c.bias || c.relu) return -2;
+    if (lnfold && (!bf16plain || !c.cvec)) return -2;
+    if (c.stats_out && !f16res) return -2;
+    if (c.K % 64 != 0 || c.K < 128 || c.N % 64 != 0 || c.ldo % 8 != 0 || (c.res && c.ldr % 8 != 0)) return -2;
+    if ((size_t)c.M * c.lda * 2 >= (1ull << 32) || (size_t)c.N * c.ldw * 2 >= (1ull << 32) ||
+        (size_t)c.M * c.ldo * 2 >= (1ull << 32)) return -2;                                                 // 32-bit byte offsets
+    VitGemmArgs a;
+    a.A = static_cast<const char*>(c.A);
+    a.W = static_cast<const char*>(c.W);
+    a.out = c.out;
+    a.bias = c.bias;
+    a.res = c.res;
+    a.rowstats = c.rowstats;
+    a.cvec = c.cvec;
+    a.stats_out = c.stats_out;
+    a.stats_slots = c.N / 64;
+    a.M = c.M; a.N = c.N; a.K = c.K;
+    a.lda = c.lda; a.ldw = c.ldw; a.ldo = c.ldo; a.ldr = c.ldr;
+    a.act = c.act;
+    a.tiles_n = (c.N + TN - 1) / TN;
+    a.ntiles = ((c.M + TM - 1) / TM) * a.tiles_n;
+    a.group = c.group > 0 ? c.group : 8;
+    a.colfast = c.colfast;
+#ifdef CFSAR_DEV
+    a.dbg = c.dbg;
+#endif
+    const int mode = lnfold ? 2 : (f16res ? 1 : 0);
+    switch (c.opath * 4 + c.store) {
+        case 0: return launch_path<0, 0>(a, mode, s);
+        case 2: return launch_path<0, 2>(a, mode, s);
+        case 4: return launch_path<1, 0>(a, mode, s);
+        case 6: return launch_path<1, 2>(a, mode, s);
+#ifdef CFSAR_DEV
+        case 1: return launch_path<0, 1>(a, mode, s);
+        case 5: return launch_path<1, 1>(a, mode, s);
+#endif
+        default: return -2;
+    }
+}
+
+namespace {
+#ifdef CFSAR_DEV
+int g_force_opath = -1, g_force_store = -1;
+#endif
+int vit_policy_opath(int K) {                                   // measured, see the policy comment in gemm.hip
+#ifdef CFSAR_DEV
+    if (g_force_opath >= 0) return g_force_opath;
+#endif
+    return K <= 1024 ? 1 : 0;
+}
+int vit_policy_store(int dflt) {
+#ifdef CFSAR_DEV
+    if (g_force_store >= 0) return g_force_store;
+#endif
+    return dflt;
+}
+}
+#ifdef CFSAR_DEV
+#include "../../include/clipfsar_hip_dev.h"
+// dev builds only: operand path / store policy of cfsar_gemm_lnfold and cfsar_gemm_residual_stats; -1 = product policy
+extern "C" void cfsar_debug_set_vit_paths(int opath, int store) { g_force_opath = opath; g_force_store = store; }
+#endif
+
+// out = act(LayerNorm(x; gamma, beta) W^T + bias) with the LayerNorm folded into the GEMM (MODE 2 above).  See the header.
+extern "C" int cfsar_gemm_lnfold(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
+                                 const float* rowstats, int M, int N, int K, int lda, int ldw, int ldo, int act,
+                                 cfsar_stream_t stream) {
+    CFSAR_REQUIRE(x && Wg && out && cvec && dvec && rowstats, "cfsar_gemm_lnfold: null pointer");
+    CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_lnfold: bad shape M=%d N=%d K=%d (K %% 64, N %% 64, K >= 128)", M, N, K);
+    CFSAR_REQUIRE(lda >= K && ldw >= K && ldo >= N && lda % 8 == 0 && ldw % 8 == 0 && ldo % 8 == 0, "cfsar_gemm_lnfold: bad leading dimension");
+    CFSAR_REQUIRE(act == CFSAR_ACT_NONE || act == CFSAR_ACT_QUICKGELU, "cfsar_gemm_lnfold: bad act %d", act);
+    VitGemmCall c;
+    c.A = x; c.W = Wg; c.out = out; c.bias = dvec; c.res = nullptr; c.rowstats = rowstats; c.cvec = cvec; c.stats_out = nullptr;
+    c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = 0;
+    c.out_dtype = CFSAR_BF16; c.res_dtype = CFSAR_F32; c.act = act; c.relu = 0;
+    c.opath = vit_policy_opath(K); c.store = vit_policy_store(2); c.group = 8; c.colfast = 0; c.dbg = 0;
+    const int rc = cfsar_gemm_vit_try(c, static_cast<hipStream_t>(stream));
+    return rc == -2 ? cfsar_fail("cfsar_gemm_lnfold: operands too large for 32-bit offsets") : rc;
+}
+
+// x = x + A W^T + bias (fp16 residual stream, in place) and, if stats_partial != NULL, the per-row partial LayerNorm
+// statistics of the NEW x: stats_partial[m][n / 64] = (sum, sum of squares) over columns [64 (n/64), +64).  See the header.
+extern "C" int cfsar_gemm_residual_stats(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M,
+                                         int N, int K, int lda, int ldw, int ldx, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(A && W && x && bias, "cfsar_gemm_residual_stats: null pointer");
+    CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_residual_stats: bad shape M=%d N=%d K=%d", M, N, K);
+    CFSAR_REQUIRE(lda >= K && ldw >= K && ldx >= N && lda % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, "cfsar_gemm_residual_stats: bad leading dimension");
+    VitGemmCall c;
+    c.A = A; c.W = W; c.out = x; c.bias = bias; c.res = x; c.rowstats = nullptr; c.cvec = nullptr; c.stats_out = stats_partial;
+    c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldx; c.ldr = ldx;
+    c.out_dtype = CFSAR_F16; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
+    c.opath = vit_policy_opath(K); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;
+    const int rc = cfsar_gemm_vit_try(c, static_cast<hipStream_t>(stream));
+    return rc == -2 ? cfsar_fail("cfsar_gemm_residual_stats: operands too large for 32-bit offsets") : rc;
+}

@@ -305,6 +305,70 @@ int launch_ln(const TI* x, long long in_stride, TO* out, long long out_stride, c
 
 }  // namespace
 
+namespace {
+// rowstats[m] = (mean, std, 1 / std, 0) from `slots` partial (sum, sum of squares) pairs per row; biased variance, eps inside the
+// square root (few_shot.py:605-611 = F.layer_norm).  One thread per row; a row's partials are one contiguous 8 * slots bytes.
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ partial, float* __restrict__ rowstats,
+                                                                int M, int slots, float invD, float eps) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float2* pp = reinterpret_cast<const float2*>(partial) + (size_t)m * slots;
+    float s = 0.f, q = 0.f;
+    for (int i = 0; i < slots; ++i) {
+        const float2 v = pp[i];
+        s += v.x;
+        q += v.y;
+    }
+    const float mean = s * invD;
+    const float var = fmaxf(q * invD - mean * mean, 0.f);
+    const float sd = sqrtf(var + eps);
+    *reinterpret_cast<float4*>(rowstats + (size_t)m * 4) = make_float4(mean, sd, 1.0f / sd, 0.f);
+}
+
+// the same statistics straight from fp16 rows (the output of ln_pre: the first LN-folded GEMM of the tower has no producer
+// GEMM before it).  One wave per row, 16-byte loads.
+__global__ __launch_bounds__(256) void row_stats_f16_kernel(const _Float16* __restrict__ x, float* __restrict__ rowstats, int M,
+                                                            int D, long long ld, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const _Float16* xr = x + (size_t)m * ld;
+    float s = 0.f, q = 0.f;
+    for (int k = lane * 8; k < D; k += 512) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(xr + k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+            s += f;
+            q = fmaf(f, f, q);
+        }
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) {
+        const float mean = s / (float)D;
+        const float var = fmaxf(q / (float)D - mean * mean, 0.f);
+        const float sd = sqrtf(var + eps);
+        *reinterpret_cast<float4*>(rowstats + (size_t)m * 4) = make_float4(mean, sd, 1.0f / sd, 0.f);
+    }
+}
+}  // namespace
+
+extern "C" int cfsar_ln_stats_finalize(const float* partial, float* rowstats, int M, int slots, int D, float eps,
+                                       cfsar_stream_t stream) {
+    CFSAR_REQUIRE(partial && rowstats && M > 0 && slots > 0 && D > 0, "cfsar_ln_stats_finalize: bad argument");
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       partial, rowstats, M, slots, 1.0f / (float)D, eps);
+    return cfsar_check_launch("cfsar_ln_stats_finalize");
+}
+
+extern "C" int cfsar_row_stats(const void* x, float* rowstats, int M, int D, int ld, float eps, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(x && rowstats && M > 0 && D > 0 && D % 8 == 0 && ld >= D && ld % 8 == 0, "cfsar_row_stats: bad argument");
+    hipLaunchKernelGGL(row_stats_f16_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const _Float16*>(x), rowstats, M, D, (long long)ld, eps);
+    return cfsar_check_launch("cfsar_row_stats");
+}
+
 extern "C" int cfsar_im2col_patches(const float* frames, void* out, int out_dtype, int F, int H, int W, int P,
                                     int k_pad, cfsar_stream_t stream) {
     CFSAR_REQUIRE(frames && out, "cfsar_im2col_patches: null pointer");

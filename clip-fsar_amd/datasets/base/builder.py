@@ -50,8 +50,10 @@ def build_dataset(name, cfg, split):
 def build_loader(cfg, split):
     assert split in ("test", "val", "train")
     name = getattr(cfg.TEST, "DATASET", "Synthetic_few_shot")
-    if name in ("Ssv2_few_shot", "Kinetics_few_shot"):
-        name = "Synthetic_few_shot"                       # no video files exist here: same contract, synthetic frames
+    if name in ("Ssv2_few_shot", "Kinetics_few_shot") and DATASET_REGISTRY.get(name) is None:
+        # never substitute synthetic frames for a real dataset silently: say what is missing
+        raise FileNotFoundError("TEST.DATASET = %r needs the video-episode pipeline (datasets/base/ssv2_few_shot.py here) and "
+                                "DATA.DATA_ROOT_DIR / DATA.ANNO_DIR; for synthetic episodes set TEST.DATASET: Synthetic_few_shot" % name)
     ds = build_dataset(name, cfg, split)
     idx = du.shard_episodes(len(ds))
     sub = torch.utils.data.Subset(ds, idx)

@@ -3,12 +3,14 @@
 PyTorch is used only for device memory and the stream; every arithmetic step is a call into
 libclipfsar_hip.so (clip_fsar_amd.hip).  Two numeric modes:
 
-  * ``precision="bf16"``  -- throughput mode: bf16 MFMA GEMMs / attention with fp32 accumulation, fp32 residual
-    stream, fp32 LayerNorm / softmax statistics; the tail (features -> logits) is always fp32;
+  * ``precision="bf16"``  -- throughput mode: bf16 MFMA GEMMs / attention with fp32 accumulation, residual
+    stream in IEEE fp16 (as CLIP's own GPU path), fp32 LayerNorm / softmax statistics, the two LayerNorms of a block folded
+    into the QKV / c_fc GEMMs (fp16 MFMA operands there, bf16 elsewhere); the tail (features -> logits) is always fp32;
   * ``precision="fp32"``  -- validation mode: fp32-input MFMA GEMMs (exact fp32 FMA chains) and an fp32 VALU
     attention kernel; meets the 1e-3 logits tolerance against the reference's fp32 PyTorch path.
 
-Layout in HBM (row-major): tokens x [F*N, D] fp32 (frame-major, token-minor; token 0 = class token),
+Layout in HBM (row-major): tokens x [F*N, D] (fp32 in the validation mode, fp16 in the bf16 mode; frame-major, token-minor;
+token 0 = class token),
 packed qkv [F*N, 3D], MLP hidden [F*N, 4D] in the compute dtype; features [B, S+Q, T, E] fp32.
 """
 from __future__ import annotations
@@ -79,6 +81,24 @@ class HipViT:
                 w_out=g(b + "attn.out_proj.weight").to(cd).contiguous(), b_out=g(b + "attn.out_proj.bias"),
                 w_fc=g(b + "mlp.c_fc.weight").to(cd).contiguous(), b_fc=g(b + "mlp.c_fc.bias"),
                 w_pr=g(b + "mlp.c_proj.weight").to(cd).contiguous(), b_pr=g(b + "mlp.c_proj.bias")))
+        # LayerNorm folding (bf16 mode with the fp16 stream): ln_1 / ln_2 never run as kernels.  QKV and c_fc take the raw fp16
+        # residual stream and apply LN algebraically (include/clipfsar_hip.h: cfsar_gemm_lnfold):
+        #     LN(x) W^T + b = (x (W diag(gamma))^T - mean c) / std + d,    c_n = sum_k Wg[n,k],   d = W beta + b;
+        # out_proj / c_proj emit the row statistics of the stream they write (cfsar_gemm_residual_stats).  Weight folding is
+        # init-time host logic (like the BatchNorm folding of the RN50 tower).  CFSAR_LN_FOLD=0 keeps the separate LN kernels.
+        self.fold = (precision == "bf16" and self.xd == torch.float16 and D % 64 == 0 and D >= 128
+                     and os.environ.get("CFSAR_LN_FOLD", "1") != "0")
+        if self.fold:
+            for i, blk in enumerate(self.blocks):
+                b = "transformer.resblocks.%d." % i
+                for tag, wname, bname, ln in (("qkv", "attn.in_proj_weight", "attn.in_proj_bias", "ln1"),
+                                              ("fc", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln2")):
+                    W = g(b + wname)
+                    gamma, beta = blk[ln]
+                    Wg = (W * gamma[None, :]).to(torch.float16).contiguous()
+                    blk["wg_" + tag] = Wg
+                    blk["c_" + tag] = Wg.double().sum(1).float().contiguous()          # of the ROUNDED folded weights
+                    blk["d_" + tag] = (W.double() @ beta.double() + g(b + bname).double()).float().contiguous()
         self._cap = 0
         self._ws = None
 
@@ -94,6 +114,9 @@ class HipViT:
                 o=torch.empty(M, D, device=dev, dtype=cd),
                 u=torch.empty(M, 4 * D, device=dev, dtype=cd),
                 c=torch.empty(F_, D, device=dev, dtype=torch.float32))
+            if self.fold:
+                self._ws["part"] = torch.empty(M, D // 64, 2, device=dev, dtype=torch.float32)    # partial row statistics
+                self._ws["rstat"] = torch.empty(M, 4, device=dev, dtype=torch.float32)            # (mean, std, 1/std, -)
             self._cap = F_
         return self._ws
 
@@ -130,7 +153,20 @@ class HipViT:
         hip.layernorm(x, x, self.ln_pre[0], self.ln_pre[1], M, D)                     # ln_pre (:677), in place
         if taps is not None:
             taps["ln_pre"] = x[:M].clone()
-        for i, b in enumerate(self.blocks):                                           # :679-681
+        if self.fold:
+            part, rstat, S = ws["part"], ws["rstat"], D // 64
+            hip.row_stats(x, rstat, M, D)                                             # statistics of ln_pre's output
+            for i, b in enumerate(self.blocks):                                       # :679-681, LayerNorms folded away
+                hip.gemm_lnfold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], rstat, M=M)
+                hip.vit_attention(qkv, o, F_, N, D, self.H)
+                hip.gemm_residual_stats(o, b["w_out"], x, b["b_out"], part, M=M)      # x += out_proj(attn); stats of the new x
+                hip.ln_stats_finalize(part, rstat, M, S, D)
+                hip.gemm_lnfold(x, b["wg_fc"], u, b["c_fc"], b["d_fc"], rstat, act=hip.ACT_QUICKGELU, M=M)
+                hip.gemm_residual_stats(u, b["w_pr"], x, b["b_pr"], part, M=M)        # x += c_proj(gelu(c_fc))
+                hip.ln_stats_finalize(part, rstat, M, S, D)
+                if taps is not None:
+                    taps["block%d" % i] = x[:M].clone()
+        for i, b in enumerate(self.blocks if not self.fold else []):                  # :679-681
             hip.layernorm(x, h, b["ln1"][0], b["ln1"][1], M, D)
             hip.gemm(h, b["w_qkv"], qkv, bias=b["b_qkv"], M=M)
             hip.vit_attention(qkv, o, F_, N, D, self.H)

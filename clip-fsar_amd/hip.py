@@ -14,7 +14,9 @@ F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclipfsar_hip.so")
+# CFSAR_DEV_LIB=1 (developer tools only): the -DCFSAR_DEV build with the cfsar_debug_* hooks (clip-fsar_amd/build.py --dev)
+DEV_LIB = os.environ.get("CFSAR_DEV_LIB", "0") == "1"
+LIB_PATH = os.path.join(_HERE, "libclipfsar_hip_dev.so" if DEV_LIB else "libclipfsar_hip.so")
 _lib = None
 
 _c_int, _c_p, _c_f, _c_i64 = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_int64
@@ -30,6 +32,10 @@ SIGNATURES = {
     "cfsar_cls_rows_ex": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_gemm": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 15 + [_c_p],
     "cfsar_gemm_ex": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 17 + [_c_p],
+    "cfsar_gemm_lnfold": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
+    "cfsar_gemm_residual_stats": [_c_p] * 5 + [_c_int] * 6 + [_c_p],
+    "cfsar_ln_stats_finalize": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p],
+    "cfsar_row_stats": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p],
     "cfsar_nchw_to_nhwc": [_c_p, _c_p] + [_c_int] * 5 + [_c_p],
     "cfsar_im2col3x3_nhwc": [_c_p, _c_p] + [_c_int] * 7 + [_c_p],
     "cfsar_avgpool2x2_nhwc": [_c_p, _c_p] + [_c_int] * 5 + [_c_p],
@@ -65,6 +71,11 @@ def lib():
             fn.restype = _c_int
         L.cfsar_last_error.restype = ctypes.c_char_p
         L.cfsar_last_error.argtypes = []
+        if DEV_LIB:
+            L.cfsar_debug_set_gemm_variant.argtypes = [ctypes.c_int, ctypes.c_int]
+            L.cfsar_debug_set_gemm_variant.restype = None
+            L.cfsar_debug_set_vit_paths.argtypes = [ctypes.c_int, ctypes.c_int]
+            L.cfsar_debug_set_vit_paths.restype = None
         _lib = L
     return _lib
 
@@ -177,6 +188,34 @@ def gemm(A, W, out, bias=None, residual=None, act=ACT_NONE, M=None, N=None, K=No
                             _opt(bias, torch.float32, "bias"), _opt(residual, torch.float32, "residual"),
                             M, N, K, lda, ldw, ldo, ldr, _code(A.dtype), _code(out.dtype), act,
                             row_group, row_gap, row_off, res_mod, res_off, _stream()), "cfsar_gemm")
+
+
+def gemm_lnfold(x, Wg, out, cvec, dvec, rowstats, act=ACT_NONE, M=None):
+    """out = act(LayerNorm(x) @ W.T + bias) with the LayerNorm folded into the GEMM (include/clipfsar_hip.h: cfsar_gemm_lnfold)."""
+    M = x.shape[0] if M is None else M
+    _check(lib().cfsar_gemm_lnfold(_dev(x, torch.float16, "x"), _dev(Wg, torch.float16, "Wg"), _dev(out, torch.bfloat16, "out"),
+                                   _dev(cvec, torch.float32, "cvec"), _dev(dvec, torch.float32, "dvec"),
+                                   _dev(rowstats, torch.float32, "rowstats"), M, Wg.shape[0], Wg.shape[1], x.shape[1],
+                                   Wg.shape[1], out.shape[1], act, _stream()), "cfsar_gemm_lnfold")
+
+
+def gemm_residual_stats(A, W, x, bias, stats_partial=None, M=None):
+    """x += A @ W.T + bias in place (fp16 stream) + optional partial LayerNorm statistics of the new x."""
+    M = A.shape[0] if M is None else M
+    _check(lib().cfsar_gemm_residual_stats(_dev(A, torch.bfloat16, "A"), _dev(W, torch.bfloat16, "W"), _dev(x, torch.float16, "x"),
+                                           _dev(bias, torch.float32, "bias"), _opt(stats_partial, torch.float32, "stats_partial"),
+                                           M, W.shape[0], W.shape[1], A.shape[1], W.shape[1], x.shape[1], _stream()),
+           "cfsar_gemm_residual_stats")
+
+
+def ln_stats_finalize(partial, rowstats, M, slots, D, eps=1e-5):
+    _check(lib().cfsar_ln_stats_finalize(_dev(partial, torch.float32, "partial"), _dev(rowstats, torch.float32, "rowstats"), M,
+                                         slots, D, eps, _stream()), "cfsar_ln_stats_finalize")
+
+
+def row_stats(x, rowstats, M, D, eps=1e-5):
+    _check(lib().cfsar_row_stats(_dev(x, torch.float16, "x"), _dev(rowstats, torch.float32, "rowstats"), M, D, x.shape[1], eps,
+                                 _stream()), "cfsar_row_stats")
 
 
 def vit_attention(qkv, out, F_, ntok, D, heads):

@@ -36,6 +36,23 @@ def _flag(ns, name):
     return bool(hasattr(ns, name) and getattr(ns, name))
 
 
+def _load_state_dict_file(path):
+    """A plain ``torch.save``d state dict, a reference ``.pyth`` ({'model_state': ...}), or OpenAI CLIP's TorchScript archive
+    (``ViT-B-16.pt`` is a ``torch.jit.save``d module; the reference's ``clip.load`` handles it the same way, few_shot.py:296-330)."""
+    try:
+        obj = torch.load(path, map_location="cpu")
+    except (RuntimeError, Exception) as exc:                       # TorchScript archive: torch.load refuses or returns a module
+        try:
+            obj = torch.jit.load(path, map_location="cpu")
+        except Exception:
+            raise exc
+    if hasattr(obj, "state_dict") and not isinstance(obj, dict):
+        obj = obj.state_dict()
+    if isinstance(obj, dict) and "model_state" in obj:
+        obj = obj["model_state"]
+    return {k: v for k, v in obj.items() if isinstance(v, torch.Tensor)}
+
+
 def _nested_params(module: nn.Module, flat: dict):
     """Materialise dotted parameter names (e.g. 'transformer.resblocks.0.attn.in_proj_weight') as nested plain
     nn.Module containers holding nn.Parameters.  The containers have no forward: they exist for state_dict naming."""
@@ -88,7 +105,7 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
         vis = synth.visual_state_dict(name, seed)
         wpath = getattr(cfg.VIDEO.HEAD, "CLIP_VISUAL_WEIGHTS", None)
         if wpath:
-            loaded = torch.load(wpath, map_location="cpu")
+            loaded = _load_state_dict_file(wpath)
             loaded = {k[len("visual."):] if k.startswith("visual.") else k: v for k, v in loaded.items()}
             vis = {k: (loaded[k].float().numpy() if loaded[k].is_floating_point() else loaded[k].numpy()) for k in vis}
         self.backbone = nn.Module()
@@ -129,7 +146,7 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
             tsd = ctext.text_tower_state_dict(width=768 if self.mid_dim == 768 else 512, layers=12, embed=self.mid_dim,
                                               seed=seed)
         else:
-            tsd = {k: v for k, v in torch.load(src, map_location="cpu").items() if not k.startswith("visual.")}
+            tsd = {k: v for k, v in _load_state_dict_file(src).items() if not k.startswith("visual.")}
         template = cfg.TEST.PROMPT if (hasattr(cfg.TEST, "PROMPT") and cfg.TEST.PROMPT) else None
         bpe = getattr(cfg.VIDEO.HEAD, "BPE_PATH", None)
         tok = ctext.ClipBpeTokenizer(bpe)
@@ -140,12 +157,29 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
             self.text_features_test = enc.encode(tok.tokenize(ctext.prompts(self.class_real_test, template))).cpu()
 
     # ------------------------------------------------------------------ engine (device-side packed weights)
+    def invalidate_engine(self):
+        """Drop the device-side packed weights; the next forward rebuilds them from the current parameters and text tables.
+        ``load_state_dict`` and in-place ops on a Parameter are detected automatically (tensor version counters); call this
+        after writing through ``param.data`` (e.g. ``scale.data.fill_()``, as the reference itself does at :2734), which bumps
+        no counter."""
+        self._engine = None
+        self._engine_key = None
+
     def _get_engine(self, device):
         from ...engine import ClipFsarEngine        # imported lazily: constructing the head needs no GPU
-        key = (str(device), self.precision, tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers()))
         if self.text_features_train is None or self.text_features_test is None:
             self._encode_text_tables(device)
+        tables = tuple((id(t), t.data_ptr(), t._version, tuple(t.shape)) for t in (self.text_features_train, self.text_features_test))
+        key = (str(device), self.precision, tables,
+               tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers()))
         if self._engine is None or self._engine_key != key:
+            if self.precision == "bf16" and not getattr(self, "_warned_bf16", False):
+                import logging
+                logging.getLogger(__name__).warning(
+                    "CNN_OTAM_CLIPFSAR (HIP): VIDEO.HEAD.PRECISION = 'bf16' (throughput mode) -- logits deviate from the "
+                    "reference's fp32 path by ~5e-3 (measured on the BASELINE configs, profiles/); set PRECISION: fp32 for the "
+                    "validation mode that meets the 1e-3 tolerance")
+                self._warned_bf16 = True
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             self._engine = ClipFsarEngine(self.arch, sd, self.text_features_train, self.text_features_test,
                                           depth=self.depth, precision=self.precision, device=device,

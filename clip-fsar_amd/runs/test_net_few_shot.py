@@ -81,6 +81,19 @@ def test_epoch(val_loader, model, val_meter, cur_epoch, cfg, writer=None):
     return result
 
 
+@torch.no_grad()
+def eval_epoch(val_loader, model, val_meter, cur_epoch, cfg, writer=None):
+    """The validation pass the reference's training script runs between epochs (reference runs/train_net_few_shot.py:279-451,
+    few-shot branch :355-420): same inputs, same meter updates and log lines, same per-episode statistics as ``test_epoch``
+    (the two loops compute identical quantities there; ``test_epoch`` adds the per-class tallies).  Here it IS ``test_epoch``
+    on the sharded loader, returning the epoch's (top1_err, top5_err, loss) so a training driver can track the best epoch
+    (reference :452-458 reads ``val_meter.min_top1_err``)."""
+    result = test_epoch(val_loader, model, val_meter, cur_epoch, cfg, writer)
+    if writer is not None and du.is_master_proc():
+        writer.add_scalars({"Val/Top1_err": 100.0 - result["top1_acc"]}, global_step=cur_epoch)
+    return result
+
+
 def test_few_shot(cfg):
     du.init_distributed_training(cfg)
     np.random.seed(cfg.RANDOM_SEED)

@@ -192,6 +192,27 @@ int cfsar_prototypes(const float* Xs, const float* support_labels, float* protos
 int cfsar_cos_otam_logits(const float* Xq, const float* protos, float* logits, float* dists_out, int B, int Q,
                           int way, int T, int E, float lambda, int single_direct, cfsar_stream_t stream);
 
+/* ---- A3 + A5/A6 fused: LayerNorm folded into the GEMM that consumes it (few_shot.py:605-611 with :626-628 / :636-640).
+ * out[m,n] = act(sum_k LN(x)[m,k] W[n,k] + bias[n]) computed on the RAW fp16 residual stream, without materialising LN(x):
+ *     LN(x) W^T + bias = (x Wg^T - mean_m c_n) / std_m + d_n,   Wg = W diag(gamma),  c_n = sum_k Wg[n,k],
+ *     d_n = sum_k beta_k W[n,k] + bias_n      (Wg, c, d are prepared once by the caller; c must be the sum of the ROUNDED Wg).
+ * x [M, lda] fp16, Wg [N, ldw] fp16, out [M, ldo] bf16, cvec / dvec [N] fp32, rowstats [M, 4] fp32 = (mean, std, 1/std, -) of each
+ * row of x (cfsar_row_stats / cfsar_ln_stats_finalize).  K % 64 == 0, K >= 128, N % 64 == 0; act = NONE | QUICKGELU. */
+int cfsar_gemm_lnfold(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec, const float* rowstats,
+                      int M, int N, int K, int lda, int ldw, int ldo, int act, cfsar_stream_t stream);
+
+/* ---- A5/A6 residual update + the statistics of the next LayerNorm (few_shot.py:633-635 / :639-640 followed by :636 / :626).
+ * x[m,n] = x[m,n] + sum_k A[m,k] W[n,k] + bias[n] in place on the fp16 residual stream (A, W bf16).  If stats_partial != NULL it
+ * receives, per row m and 64-column slot s = n / 64, (sum, sum of squares) of the NEW (rounded) x[m, 64 s .. 64 s + 63]:
+ * [M, N / 64, 2] fp32.  Deterministic (no atomics).  K % 64 == 0, K >= 128, N % 64 == 0. */
+int cfsar_gemm_residual_stats(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M, int N,
+                              int K, int lda, int ldw, int ldx, cfsar_stream_t stream);
+
+/* rowstats[m] = (mean, std, 1/std, 0) with std = sqrt(biased variance + eps) from the partials above (D = row length). */
+int cfsar_ln_stats_finalize(const float* partial, float* rowstats, int M, int slots, int D, float eps, cfsar_stream_t stream);
+/* The same statistics directly from fp16 rows x [M, ld] (first LN-folded GEMM of a tower: its input comes from ln_pre). */
+int cfsar_row_stats(const void* x, float* rowstats, int M, int D, int ld, float eps, cfsar_stream_t stream);
+
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop
 #endif

@@ -19,6 +19,10 @@ extern "C" {
  * (0, 0) restores the product policy.  Variants: see the dispatch comment in csrc/gemm.hip and csrc/gemm_vit.hip. */
 void cfsar_debug_set_gemm_variant(int variant, int dbg);
 
+/* Operand path (0 register-staged, 1 LDS-DMA) and store policy (0 default, 1 nt, 2 sc1) of cfsar_gemm_lnfold /
+ * cfsar_gemm_residual_stats; -1 = the product policy. */
+void cfsar_debug_set_vit_paths(int opath, int store);
+
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop
 #endif

@@ -7,6 +7,8 @@ Tolerances (written here, per the north star "within 1e-3 fp32"):
 """
 import math
 
+import os
+
 import pytest
 import torch
 
@@ -312,38 +314,56 @@ def test_avgpool_and_attnpool_tokens(hip, dtype):
     assert maxdiff(tok.float().cpu(), ref_tok) < (2e-6 if dtype == "f32" else 3e-2)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 6, 7, 10, 11, 12, 13])
-def test_gemm_every_kernel_variant(hip, variant):
-    """Each bf16 GEMM kernel kept in gemm.hip (v1 / p3 / p6 / p6-persistent / p10 / p10-persistent / p12; the auto policy
-    picks p12, p3 and v1) against the fp32 product of the bf16-rounded operands, on ragged M and N edges, through the
-    fused epilogues the ViT and RN50 towers use.  Variants are forced with the dev hook cfsar_debug_set_gemm_variant."""
-    import ctypes
+def _gemm_epilogue_checks(hip, M, N, K, tag):
+    """bf16 GEMM through the fused epilogues the ViT and RN50 towers use, against the fp32 product of the bf16-rounded operands
+    (torch fp32 matmul on the device: a checker, not the thing under test)."""
+    A = _rand(M, K, seed=11).to(torch.bfloat16).cuda()
+    W = _rand(N, K, seed=12, scale=K ** -0.5).to(torch.bfloat16).cuda()
+    bias = _rand(N, seed=13).cuda()
+    ref0 = A.float() @ W.float().t() + bias
+    scale = max(1.0, float(ref0.abs().max()))
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    hip.gemm(A, W, out, bias=bias)                                                       # QKV-like
+    assert maxdiff(out.float(), ref0) < 2e-2 * scale, ("plain", tag, M, N, K)
+    out.fill_(float("nan"))
+    hip.gemm(A, W, out, bias=bias, act=hip.ACT_QUICKGELU)                                # c_fc-like
+    assert maxdiff(out.float(), orc.quick_gelu(ref0)) < 4e-2 * scale, ("gelu", tag, M, N, K)
+    x = _rand(M, N, seed=14).cuda()
+    xr = x.clone()
+    hip.gemm(A, W, x, bias=bias, residual=x)                                             # fp32 residual stream, in place
+    assert maxdiff(x, ref0 + xr) < 2e-2 * scale, ("residual f32", tag, M, N, K)
+    xh = _rand(M, N, seed=16).to(torch.float16).cuda()
+    xh0 = xh.clone()
+    hip.gemm(A, W, xh, bias=bias, residual=xh)                                           # fp16 residual stream (bf16 mode), in place
+    assert maxdiff(xh.float(), ref0 + xh0.float()) < 2e-2 * scale, ("residual f16", tag, M, N, K)
+    rb = _rand(M, N, seed=15).to(torch.bfloat16).cuda()
+    hip.gemm(A, W, out, bias=bias, residual=rb, relu=True)                               # RN50 bottleneck tail
+    assert maxdiff(out.float(), torch.relu(ref0 + rb.float())) < 2e-2 * scale, ("relu", tag, M, N, K)
+
+
+# one shape per branch of the kernel policy in cfsar_gemm_ex (csrc/gemm.hip), every one with ragged M (and N where the kernel
+# supports it): v1 128x128 | p3 256x128 (M >= 1024, few 256x256 tiles) | p12 one workgroup per tile (240 <= tiles < 512) |
+# the persistent ViT kernel of gemm_vit.hip (>= 512 tiles; N % 64 == 0) incl. a long-K case, an N that is not a multiple of 256,
+# and a grid with fewer tiles per workgroup than stages
+@pytest.mark.parametrize("M,N,K", [(515, 260, 192), (777, 516, 768), (1300, 768, 3072), (20500, 768, 768),
+                                   (44000, 768, 768), (33000, 1024, 128), (22100, 1600, 256), (16500, 2304, 3072)])
+def test_gemm_policy_reaches_every_kernel(hip, M, N, K):
+    _gemm_epilogue_checks(hip, M, N, K, "auto")
+
+
+@pytest.mark.skipif(os.environ.get("CFSAR_DEV_LIB", "0") != "1", reason="developer library only (CFSAR_DEV_LIB=1)")
+@pytest.mark.parametrize("variant", [1, 2, 10, 11, 12, 13, 20, 21, 22, 24, 25, 26])
+def test_gemm_forced_variants_dev(hip, variant):
+    """Developer build: every kernel / operand path / store policy forced on ragged shapes (incl. shapes the policy would not
+    give it), plus the alternative tile walks of the ViT kernel."""
     L = hip.lib()
-    L.cfsar_debug_set_gemm_variant.argtypes = [ctypes.c_int, ctypes.c_int]
-    L.cfsar_debug_set_gemm_variant.restype = None
     try:
-        L.cfsar_debug_set_gemm_variant(variant, 0)
-        for (M, N, K) in [(777, 516, 768), (1300, 768, 3072), (515, 260, 192)]:
-            A = _rand(M, K, seed=11).to(torch.bfloat16)
-            W = _rand(N, K, seed=12, scale=K ** -0.5).to(torch.bfloat16)
-            bias = _rand(N, seed=13)
-            ref0 = A.float() @ W.float().t() + bias
-            Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
-            scale = max(1.0, float(ref0.abs().max()))
-            out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-            hip.gemm(Ad, Wd, out, bias=bd)                                                   # QKV-like
-            assert maxdiff(out.float().cpu(), ref0) < 2e-2 * scale, ("plain", variant, M, N, K)
-            hip.gemm(Ad, Wd, out, bias=bd, act=hip.ACT_QUICKGELU)                            # c_fc-like
-            assert maxdiff(out.float().cpu(), orc.quick_gelu(ref0)) < 4e-2 * scale, ("gelu", variant, M, N, K)
-            x = _rand(M, N, seed=14).cuda()
-            xr = x.clone()
-            hip.gemm(Ad, Wd, x, bias=bd, residual=x)                                         # residual stream, in place
-            assert maxdiff(x.cpu(), ref0 + xr.cpu()) < 2e-2 * scale, ("residual", variant, M, N, K)
-            rb = _rand(M, N, seed=15).to(torch.bfloat16)
-            hip.gemm(Ad, Wd, out, bias=bd, residual=rb.cuda(), relu=True)                    # RN50 bottleneck tail
-            assert maxdiff(out.float().cpu(), torch.relu(ref0 + rb.float())) < 2e-2 * scale, ("relu", variant, M, N, K)
+        for dbg in ([0, 256, 512 | 256, 1024] if variant >= 20 else [0]):
+            L.cfsar_debug_set_gemm_variant(variant, dbg)
+            for (M, N, K) in [(777, 512, 768), (1300, 768, 3072), (5000, 320, 192), (9000, 768, 128)]:
+                _gemm_epilogue_checks(hip, M, N, K, (variant, dbg))
     finally:
-        L.cfsar_debug_set_gemm_variant(-1, -1)
+        L.cfsar_debug_set_gemm_variant(0, 0)
 
 
 @pytest.mark.parametrize("C,H,W_,Co,res", [(32, 12, 10, 64, False), (32, 11, 13, 32, True), (64, 9, 14, 64, False), (128, 7, 7, 128, True), (8, 5, 6, 260, True), (64, 10, 9, 256, False)])
@@ -387,31 +407,6 @@ def test_attnpool_attend_single_query(hip, T, heads, hd):
     out = torch.empty(Fn, C, device="cuda")
     hip.attnpool_attend(q.cuda(), kv.cuda(), out, Fn, T, heads, hd, hd ** -0.5)
     assert maxdiff(out.cpu(), ref) < 2e-5
-
-
-@pytest.mark.parametrize("variant", ["4"])
-def test_vit_attention_compact_variant(hip, variant):
-    """The compact-LDS / 256-thread form of the bf16 attention kernel (CFSAR_ATTN_VARIANT=4: three workgroups per CU; the
-    variable is read once per process -> run in a subprocess) == the fp32 softmax(q k^T / 8) v on bf16-rounded inputs."""
-    import subprocess, sys, os, textwrap
-    code = textwrap.dedent("""
-        import torch, sys
-        sys.path.insert(0, %r)
-        from clip_fsar_amd import hip
-        F_, N, D, H = 3, 197, 768, 12
-        g = torch.Generator().manual_seed(5)
-        qkv = torch.randn(F_ * N, 3 * D, generator=g).to(torch.bfloat16)
-        o = torch.empty(F_ * N, D, device="cuda", dtype=torch.bfloat16)
-        hip.vit_attention(qkv.cuda(), o, F_, N, D, H)
-        x = qkv.float().reshape(F_, N, 3, H, 64).permute(2, 0, 3, 1, 4)
-        ref = (torch.softmax(x[0] @ x[1].transpose(-1, -2) / 8.0, -1) @ x[2]).permute(0, 2, 1, 3).reshape(F_ * N, D)
-        d = float((o.float().cpu() - ref).abs().max())
-        assert d < 2e-2, d
-        print("ok", d)
-    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CFSAR_ATTN_VARIANT=variant)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("Co,H,W_", [(32, 24, 20), (8, 9, 11), (64, 6, 6)])
@@ -468,3 +463,68 @@ def test_fp16_residual_stream_ops(hip):
         out = torch.empty(rows, D, device="cuda", dtype=od)
         hip.layernorm(xh.cuda(), out, w.cuda(), b.cuda(), rows, D)
         assert maxdiff(out.float().cpu(), ref_ln) < tol * max(1.0, float(ref_ln.abs().max())), od
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm folded into the GEMMs
+@pytest.mark.parametrize("M,N,K,act", [(777, 384, 128, "none"), (5000, 2304, 768, "none"), (44000, 3072, 768, "gelu"),
+                                       (300, 512, 1024, "gelu"), (20500, 768, 256, "none")])
+def test_gemm_lnfold_matches_layernorm_then_gemm(hip, M, N, K, act):
+    """cfsar_row_stats + cfsar_gemm_lnfold == act(F.layer_norm(x) @ W.T + b) (few_shot.py:605-611 + :626-628 / :636-640) on the
+    raw fp16 stream: the reference of the folded form is the UNFOLDED fp32 computation, so the test covers the algebra (Wg, c, d,
+    the rank-1 mean term, the 1/std row scale) and not just the kernel.  Rows get different means / scales (column offsets,
+    a few large-magnitude channels like CLIP's outlier dimensions) so that a wrong row statistic cannot hide."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 3.0) + torch.randn(M, 1, generator=g) * 2.0
+    x[:, 5] += 25.0
+    x[:, K // 2] -= 12.0
+    x = x.to(torch.float16).cuda()
+    W = (_rand(N, K, seed=4, scale=K ** -0.5)).cuda()
+    gamma = (1.0 + 0.5 * _rand(K, seed=5)).cuda()
+    beta = (0.3 * _rand(K, seed=6)).cuda()
+    bias = _rand(N, seed=7).cuda()
+    ref = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ W.t() + bias
+    if act == "gelu":
+        ref = orc.quick_gelu(ref)
+    Wg = (W * gamma[None, :]).to(torch.float16).contiguous()
+    c = Wg.double().sum(1).float()
+    d = (W.double() @ beta.double() + bias.double()).float()
+    rstat = torch.empty(M, 4, device="cuda")
+    hip.row_stats(x, rstat, M, K)
+    mean, var = x.float().mean(1), x.float().var(1, unbiased=False)
+    assert maxdiff(rstat[:, 0], mean) < 1e-4 * max(1.0, float(mean.abs().max()))
+    assert maxdiff(rstat[:, 2], torch.rsqrt(var + 1e-5)) < 2e-4 * float(torch.rsqrt(var + 1e-5).max())
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    hip.gemm_lnfold(x, Wg, out, c, d, rstat, act=hip.ACT_QUICKGELU if act == "gelu" else hip.ACT_NONE)
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxdiff(out.float(), ref) < 2e-2 * scale, (M, N, K, act)
+    # tighter, against the same math with the operands the kernel sees (fp16 x, fp16 Wg): isolates the kernel from fp16 rounding
+    ref2 = ((x.float() @ Wg.float().t()) - mean[:, None] * c[None, :]) * torch.rsqrt(var + 1e-5)[:, None] + d
+    if act == "gelu":
+        ref2 = orc.quick_gelu(ref2)
+    assert maxdiff(out.float(), ref2) < 6e-3 * scale, (M, N, K, act)          # bf16 output rounding (2^-9) dominates
+
+
+@pytest.mark.parametrize("M,N,K", [(777, 128, 128), (5000, 768, 768), (44000, 768, 3072), (20500, 1024, 256)])
+def test_gemm_residual_stats_and_finalize(hip, M, N, K):
+    """cfsar_gemm_residual_stats: x += A W^T + b in place on the fp16 stream, and its partial statistics, finalized by
+    cfsar_ln_stats_finalize, are the LayerNorm statistics of the NEW (stored, fp16-rounded) x."""
+    A = _rand(M, K, seed=11).to(torch.bfloat16).cuda()
+    W = _rand(N, K, seed=12, scale=K ** -0.5).to(torch.bfloat16).cuda()
+    bias = _rand(N, seed=13).cuda()
+    x = (_rand(M, N, seed=14) * 2.0 + 1.5).to(torch.float16).cuda()
+    x0 = x.clone()
+    part = torch.full((M, N // 64, 2), float("nan"), device="cuda")
+    hip.gemm_residual_stats(A, W, x, bias, part)
+    ref = x0.float() + A.float() @ W.float().t() + bias
+    assert maxdiff(x.float(), ref) < 2e-2 * max(1.0, float(ref.abs().max()))
+    xs = x.float()
+    assert maxdiff(part[:, :, 0], xs.reshape(M, N // 64, 64).sum(2)) < 1e-3 * 64
+    assert maxdiff(part[:, :, 1], (xs * xs).reshape(M, N // 64, 64).sum(2)) < 1e-3 * 64 * float(xs.abs().max()) ** 2
+    rstat = torch.empty(M, 4, device="cuda")
+    hip.ln_stats_finalize(part, rstat, M, N // 64, N)
+    assert maxdiff(rstat[:, 0], xs.mean(1)) < 1e-4 * max(1.0, float(xs.mean(1).abs().max()))
+    assert maxdiff(rstat[:, 1], torch.sqrt(xs.var(1, unbiased=False) + 1e-5)) < 1e-3
+    x2 = x0.clone()
+    hip.gemm_residual_stats(A, W, x2, bias, None)                    # statistics are optional
+    assert torch.equal(x2, x)

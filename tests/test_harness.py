@@ -1,0 +1,225 @@
+"""The mirrored harness (runs/test_net_few_shot.py: test_few_shot / test_epoch / eval_epoch) with the REAL head.
+
+GPU (`-m gpu`): `test_few_shot(cfg)` end to end -- registry -> build_model -> load_test_checkpoint -> build_loader -> test_epoch ->
+ValMeter -- on the HIP model, at EPISODES_PER_STEP 1 and 4; the accuracy / loss it reports must be the ones the CPU oracle's logits
+give on the same synthetic episodes.  The checkpoint path is covered with a reference-format `.pyth`
+({'epoch', 'model_state': {'head.backbone...', 'head.context2...', 'head.scale'}}) through every rung of the reference's
+priority chain (reference utils/checkpoint.py:452-530).
+
+CPU: the priority chain, the filename filter and the loud failures of the loader (no GPU needed: constructing the head does not
+touch the device).
+"""
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import clip_fsar_amd.synth as synth
+
+ARCH = "ViT-test/16"
+N_TRAIN, N_TEST, T = 64, 24, 4
+
+
+def _cfg(n_tasks, eps_per_step=1, seed=18, precision="fp32", num_gpus=1, **extra):
+    a = synth.ARCHS[ARCH]
+    cfg = NS(VIDEO=NS(HEAD=NS(NAME="CNN_OTAM_CLIPFSAR", BACKBONE_NAME=ARCH, PRECISION=precision), BACKBONE=NS(META_ARCH="Identity")),
+             TRAIN=NS(CLASS_NAME=["c%d" % i for i in range(N_TRAIN)], WAY=5, SHOT=1, QUERY_PER_CLASS=1, NUM_TEST_TASKS=n_tasks,
+                      BATCH_SIZE=1, CHECKPOINT_FILE_PATH=""),
+             TEST=NS(CLASS_NAME=["t%d" % i for i in range(N_TEST)], DATASET="Synthetic_few_shot", EPISODES_PER_STEP=eps_per_step,
+                     CHECKPOINT_FILE_PATH=""),
+             DATA=NS(NUM_INPUT_FRAMES=T, TEST_CROP_SIZE=a["res"]), MODEL=NS(NAME="BaseVideoModel", EMA=NS(ENABLE=False)),
+             BN=NS(FREEZE=False), NUM_GPUS=num_gpus, NUM_SHARDS=1, RANDOM_SEED=seed, LOG_PERIOD=100, OUTPUT_DIR="")
+    for k, v in extra.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _oracle_stats(n_tasks, weight_seed, table_seed=18, episode_seed=18):
+    """(top1_acc %, mean loss) of the CPU oracle on episodes 0..n-1 with head weights of `weight_seed`."""
+    import clipfsar_oracle as orc
+    a = synth.ARCHS[ARCH]
+    sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(ARCH, weight_seed).items()}
+    tt = torch.from_numpy(synth.text_features(N_TRAIN, a["embed"], "train", table_seed))
+    te = torch.from_numpy(synth.text_features(N_TEST, a["embed"], "test", table_seed))
+    accs, losses = [], []
+    with torch.no_grad():
+        for e in range(n_tasks):
+            ep = {k: torch.from_numpy(v) for k, v in synth.make_episode(5, 1, 1, T, a["res"], N_TEST, e, episode_seed).items()}
+            lg = orc.head_forward(ep, sd, tt, te, a, frames=T)["logits"]
+            lab = ep["target_labels"].long()
+            accs.append(float((lg.argmax(1) == lab).float().mean()) * 100.0)
+            losses.append(float(F.cross_entropy(lg, lab)))
+    return float(np.mean(accs)), float(np.mean(losses))
+
+
+def _write_pyth(path, weight_seed, prefix="head.", epoch=7, drop=None):
+    sd = {prefix + k: torch.from_numpy(v) for k, v in synth.head_state_dict(ARCH, weight_seed).items()}
+    if drop:
+        sd = {k: v for k, v in sd.items() if drop not in k}
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({"epoch": epoch, "model_state": sd, "optimizer_state": {}, "cfg": "dump"}, path)
+    return path
+
+
+# ------------------------------------------------------------------------------------------------ GPU: the real thing
+gpu = pytest.mark.gpu
+needs_gpu = pytest.mark.skipif(not torch.cuda.is_available(), reason="no GPU")
+
+
+@gpu
+@needs_gpu
+@pytest.mark.parametrize("eps_per_step", [1, 4])
+def test_test_few_shot_real_head_matches_oracle(eps_per_step):
+    from clip_fsar_amd.runs.test_net_few_shot import test_few_shot
+    n = 8
+    res = test_few_shot(_cfg(n, eps_per_step))
+    acc, loss = _oracle_stats(n, 18)
+    assert res["episodes"] == n
+    assert abs(res["top1_acc"] - acc) < 1e-4, (res["top1_acc"], acc)
+    assert abs(res["loss"] - loss) < 2e-3, (res["loss"], loss)
+
+
+@gpu
+@needs_gpu
+def test_eval_epoch_and_ragged_last_step():
+    """7 episodes in steps of 4: the loader's last batch holds 3; eval_epoch == test_epoch statistics."""
+    from clip_fsar_amd.datasets.base.builder import build_loader
+    from clip_fsar_amd.models.base.builder import build_model
+    from clip_fsar_amd.runs.test_net_few_shot import eval_epoch
+    from clip_fsar_amd.utils.meters import ValMeter
+    cfg = _cfg(7, 4)
+    model, _ = build_model(cfg)
+    loader = build_loader(cfg, "test")
+    res = eval_epoch(loader, model, ValMeter(len(loader), cfg), 0, cfg)
+    acc, loss = _oracle_stats(7, 18)
+    assert res["episodes"] == 7 and abs(res["top1_acc"] - acc) < 1e-4 and abs(res["loss"] - loss) < 2e-3
+
+
+@gpu
+@needs_gpu
+@pytest.mark.parametrize("rung", ["test_path", "output_dir", "train_path"])
+def test_checkpoint_round_trip_through_priority_chain(tmp_path, rung):
+    """A reference-format .pyth holding DIFFERENT weights (seed 99) than the model's init (seed 18): after load_test_checkpoint
+    the run must reproduce the oracle's numbers for the seed-99 weights."""
+    from clip_fsar_amd.runs.test_net_few_shot import test_few_shot
+    n = 6
+    cfg = _cfg(n, 2)
+    if rung == "test_path":
+        cfg.TEST.CHECKPOINT_FILE_PATH = _write_pyth(str(tmp_path / "a" / "w.pyth"), 99)
+        cfg.TRAIN.CHECKPOINT_FILE_PATH = _write_pyth(str(tmp_path / "b" / "w.pyth"), 5)      # lower priority: must be ignored
+    elif rung == "output_dir":
+        cfg.OUTPUT_DIR = str(tmp_path)
+        _write_pyth(str(tmp_path / "checkpoints" / "checkpoint_epoch_00002.pyth"), 5)
+        _write_pyth(str(tmp_path / "checkpoints" / "checkpoint_epoch_00010.pyth"), 99)         # the newest one wins
+        cfg.TRAIN.CHECKPOINT_FILE_PATH = _write_pyth(str(tmp_path / "b" / "w.pyth"), 5)
+    else:
+        cfg.TRAIN.CHECKPOINT_FILE_PATH = _write_pyth(str(tmp_path / "b" / "w.pyth"), 99)
+    res = test_few_shot(cfg)
+    acc99, loss99 = _oracle_stats(n, 99)
+    acc18, loss18 = _oracle_stats(n, 18)
+    assert abs(loss99 - loss18) > 1e-3                      # the two weight sets are distinguishable on these episodes
+    assert abs(res["top1_acc"] - acc99) < 1e-4 and abs(res["loss"] - loss99) < 2e-3, (res, acc99, loss99)
+
+
+@gpu
+@needs_gpu
+def test_label_validation_raises_like_the_reference():
+    from clip_fsar_amd.models.base.builder import build_model
+    cfg = _cfg(1)
+    model, _ = build_model(cfg)
+    model.eval()
+    a = synth.ARCHS[ARCH]
+    ep = {k: torch.from_numpy(v).cuda() for k, v in synth.make_episode(5, 1, 1, T, a["res"], N_TEST, 0, 18).items()}
+    bad = dict(ep)
+    bad["real_support_labels"] = ep["real_support_labels"].clone()
+    bad["real_support_labels"][0] = float(N_TEST)            # one past the text table: IndexError in the reference (:2946)
+    with pytest.raises(IndexError):
+        model(bad)
+    dup = dict(ep)
+    dup["support_labels"] = torch.zeros_like(ep["support_labels"])   # one class only: not a 5-way episode
+    with pytest.raises(ValueError):
+        model(dup)
+    with torch.no_grad():
+        out = model(ep)
+    assert torch.isfinite(out["logits"]).all()
+    # the kernels themselves never repair a bad class id silently: with validation off the logits come back NaN
+    cfg2 = _cfg(1)
+    cfg2.VIDEO.HEAD.VALIDATE_LABELS = False
+    model2, _ = build_model(cfg2)
+    model2.eval()
+    with torch.no_grad():
+        out2 = model2(bad)
+    assert torch.isnan(out2["logits"]).any()
+
+
+# ------------------------------------------------------------------------------------------------ CPU: loader logic
+def _cpu_model(seed=18):
+    import clip_fsar_amd.models.base  # noqa: F401
+    from clip_fsar_amd.models.base.models import BaseVideoModel
+    return BaseVideoModel(_cfg(1, seed=seed, num_gpus=0))
+
+
+def _head_equals_seed(model, seed):
+    want = synth.head_state_dict(ARCH, seed)
+    got = model.head.state_dict()
+    return all(np.array_equal(got[k].numpy(), np.asarray(want[k], dtype=got[k].numpy().dtype)) for k in want)
+
+
+def test_load_test_checkpoint_priority_chain_cpu(tmp_path):
+    from clip_fsar_amd.utils import checkpoint as cu
+    cfg = _cfg(1, num_gpus=0)
+    m = _cpu_model()
+    assert _head_equals_seed(m, 18)
+    assert cu.load_test_checkpoint(cfg, m) is None and _head_equals_seed(m, 18)          # nothing given: random init stays
+    cfg.TRAIN.CHECKPOINT_FILE_PATH = _write_pyth(str(tmp_path / "t" / "w.pyth"), 31, epoch=3)
+    assert cu.load_test_checkpoint(cfg, m) == 3 and _head_equals_seed(m, 31)
+    cfg.OUTPUT_DIR = str(tmp_path)
+    _write_pyth(str(tmp_path / "checkpoints" / "checkpoint_epoch_00004.pyth"), 32, epoch=4)
+    _write_pyth(str(tmp_path / "checkpoints" / "my_checkpoint_zz.pyth"), 33, epoch=9)      # "checkpoint" anywhere in the name (:71)
+    open(str(tmp_path / "checkpoints" / "notes.txt"), "w").write("ignored")
+    assert cu.get_last_checkpoint(str(tmp_path)).endswith("my_checkpoint_zz.pyth")
+    assert cu.load_test_checkpoint(cfg, m) == 9 and _head_equals_seed(m, 33)
+    cfg.TEST.CHECKPOINT_FILE_PATH = _write_pyth(str(tmp_path / "x" / "w.pyth"), 34, epoch=1)
+    assert cu.load_test_checkpoint(cfg, m) == 1 and _head_equals_seed(m, 34)
+
+
+def test_checkpoint_loader_fails_loudly(tmp_path):
+    from clip_fsar_amd.utils import checkpoint as cu
+    cfg = _cfg(1, num_gpus=0)
+    m = _cpu_model()
+    cfg.TEST.CHECKPOINT_FILE_PATH = _write_pyth(str(tmp_path / "p" / "w.pyth"), 40, prefix="module.head.")   # wrong prefix
+    with pytest.raises(RuntimeError, match="none of its"):
+        cu.load_test_checkpoint(cfg, m)
+    cfg.TEST.CHECKPOINT_FILE_PATH = _write_pyth(str(tmp_path / "q" / "w.pyth"), 40, drop="resblocks.1.mlp")  # partial backbone
+    with pytest.raises(RuntimeError, match="lacks"):
+        cu.load_test_checkpoint(cfg, m)
+    torch.save({"state_dict": {}}, str(tmp_path / "r.pyth"))
+    cfg.TEST.CHECKPOINT_FILE_PATH = str(tmp_path / "r.pyth")
+    with pytest.raises(KeyError):
+        cu.load_test_checkpoint(cfg, m)
+    cfg.TEST.CHECKPOINT_FILE_PATH = "oss://bucket/ckpt.pyth"
+    with pytest.raises(NotImplementedError):
+        cu.load_test_checkpoint(cfg, m)
+
+
+def test_save_checkpoint_round_trip_cpu(tmp_path):
+    from clip_fsar_amd.utils import checkpoint as cu
+    m = _cpu_model(seed=50)
+    path = cu.save_checkpoint(str(tmp_path), m, epoch=4)
+    assert path.endswith(os.path.join("checkpoints", "checkpoint_epoch_00005.pyth"))
+    ck = torch.load(path, map_location="cpu")
+    assert ck["epoch"] == 4 and any(k.startswith("head.backbone.") for k in ck["model_state"])
+    m2 = _cpu_model(seed=18)
+    cfg = _cfg(1, num_gpus=0, OUTPUT_DIR=str(tmp_path))
+    assert cu.load_test_checkpoint(cfg, m2) == 4 and _head_equals_seed(m2, 50)
+
+
+def test_build_loader_refuses_real_datasets_without_data(tmp_path):
+    from clip_fsar_amd.datasets.base.builder import build_loader
+    cfg = _cfg(2, num_gpus=0)
+    cfg.TEST.DATASET = "Ssv2_few_shot"
+    with pytest.raises((FileNotFoundError, ValueError, KeyError)):
+        build_loader(cfg, "test")

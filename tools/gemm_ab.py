@@ -3,14 +3,13 @@ thermal drift hits all of them equally; reports the median and min over rounds.
 usage: python tools/gemm_ab.py B "variant:dbg" "variant:dbg" ...      (B = episodes -> M = 80*197*B)"""
 import ctypes, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["CFSAR_DEV_LIB"] = "1"      # the -DCFSAR_DEV library (clip-fsar_amd/build.py --dev) carries the variant hook
 import torch
 from clip_fsar_amd import hip
 
 B = int(sys.argv[1])
 cfgs = [tuple(int(x) for x in c.split(":")) for c in sys.argv[2:]]
 L = hip.lib()
-L.cfsar_debug_set_gemm_variant.argtypes = [ctypes.c_int, ctypes.c_int]
-L.cfsar_debug_set_gemm_variant.restype = None
 D = int(os.environ.get("AB_D", "768"))                      # 1024 + AB_TOK=257 AB_FPE=160: ViT-L/14, 16 frames
 M = int(os.environ.get("AB_FPE", "80")) * int(os.environ.get("AB_TOK", "197")) * B
 dev = "cuda"

@@ -1,13 +1,12 @@
 """Dev tool (GPU box): A/B of the GEMM variants on the RN50 tower's 1x1-conv / im2col GEMM shapes (8 episodes = 640 frames)."""
 import ctypes, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["CFSAR_DEV_LIB"] = "1"      # the -DCFSAR_DEV library (clip-fsar_amd/build.py --dev) carries the variant hook
 import torch
 from clip_fsar_amd import hip
 
 variants = [tuple(int(x) for x in (v.split(':') + ['0'])[:2]) for v in sys.argv[1:]] or [(1, 0), (2, 0), (6, 0), (10, 0)]
 L = hip.lib()
-L.cfsar_debug_set_gemm_variant.argtypes = [ctypes.c_int, ctypes.c_int]
-L.cfsar_debug_set_gemm_variant.restype = None
 F = 640
 # (tag, M, N, K, residual)
 shapes = [("stem1 im2col", F * 112 * 112, 32, 64, False), ("stem2 im2col", F * 112 * 112, 32, 320, False),
@@ -40,4 +39,4 @@ for tag, M, N, K, res in shapes:
         line += "| v%-2d:%-3d %7.1f us %5.0f TF %4.1f TB/s " % (v[0], v[1], med, 2.0 * M * N * K / med / 1e6, byts / med / 1e6)
     print(line, flush=True)
     del A, out, r
-L.cfsar_debug_set_gemm_variant(-1, -1)
+L.cfsar_debug_set_gemm_variant(0, 0)
