@@ -62,25 +62,25 @@ __device__ __forceinline__ void glds16_asm(const char* src, unsigned lds_addr) {
 }
 
 // x * sigmoid(1.702 x) for four values, few_shot.py:614-616.
-// gfx950 / ROCm 7.2 finding (this kernel's LN-folded c_fc returned exact zeros in lanes 48-63 of some accumulators; value dump in
-// tools/dbg_lnfold.py): hipcc recycles the SOURCE register of a transcendental in the very next instruction
-// ("v_rcp_f32 v228, v163 ; v_add_f32 v163, 1.0, v175").  v_exp_f32 / v_rcp_f32 run in the quarter-rate transcendental pipe; with
-// several of them queued back to back the pipe reads its operand after the following full-rate VALU instruction has already
-// rewritten it, for the last lane group.  (A lone v_rcp + overwrite does not show it: tools/ubench/trans_war.hip.)  The empty asm
-// statement below takes the transcendental INPUTS and the final products as operands: the inputs must stay intact until the
-// products exist, i.e. until every transcendental has executed.  It emits no instruction.
+// The empty asm statement is a WORKAROUND for a fault seen on MI355X / ROCm 7.2 with the straightforward form
+// `v * rcp(1 + exp2(k v))` in the LN-folded c_fc instance of this kernel: exact zeros in lanes 48-63 of single accumulator
+// registers (~1 % of the tiles, timing dependent, all operand paths and store policies; value dump: tools/dbg_lnfold.py).  In the
+// faulty code hipcc had recycled the source register of a transcendental in the very next instruction
+// ("v_rcp_f32 v228, v163 ; v_add_f32 v163, 1.0, v175") inside a dense run of v_exp / v_rcp / v_pk_mul_f32.  Pinning the
+// transcendental inputs and the products as operands of one statement (no instruction is emitted) changes the allocation so that
+// no input is rewritten before its product exists, and the fault is gone (tests/test_gpu_kernels.py::test_gemm_lnfold_*, the
+// sizes that exposed it).  The root cause is NOT isolated: tools/ubench/trans_war.hip replays the instruction shapes alone and
+// does not reproduce it.
 __device__ __forceinline__ void quick_gelu4(float (&v)[4]) {
-    float z[4], d[4], o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) z[j] = -1.702f * 1.4426950408889634f * v[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) d[j] = 1.0f + __builtin_amdgcn_exp2f(z[j]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = v[j] * __builtin_amdgcn_rcpf(d[j]);
-    asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])
-                 : "v"(z[0]), "v"(z[1]), "v"(z[2]), "v"(z[3]), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = o[j];
+    for (int j = 0; j < 4; ++j) {
+        const float z = -1.702f * 1.4426950408889634f * v[j];
+        float d = 1.0f + __builtin_amdgcn_exp2f(z);
+        asm volatile("" : "+v"(d) : "v"(z));          // z stays intact until 1 + 2^z exists
+        float o = v[j] * __builtin_amdgcn_rcpf(d);
+        asm volatile("" : "+v"(o) : "v"(d));          // d stays intact until v / d exists
+        v[j] = o;
+    }
 }
 
 // 16-byte global store with a cache policy: 0 = default (write-back, line stays in this XCD's L2), 1 = nt, 2 = sc1
@@ -213,7 +213,7 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
 
 // OPATH 0: register-staged operands (global_load_dwordx4 -> VGPR -> ds_write_b128), loads two K tiles ahead.
 // OPATH 1: LDS-DMA operands (global_load_lds_dwordx4), one K tile ahead.
-// MODE 0: out = act(A W^T + bias)                      (TI = bf16 operands)
+// MODE 0: out = act(A W^T + bias)                      (TI = bf16 operands; dev builds also instantiate TI = f16 for timing A/B)
 // MODE 1: x   = x + A W^T + bias, fp16 in place        (TI = bf16; optional row-statistics partials, see epilogue_rows)
 // MODE 2: out = act(LayerNorm(x) W^T + bias) computed WITHOUT materialising LayerNorm(x) (few_shot.py:605-611, 626-640):
 //         with W' = W diag(gamma) (fp16, folded at init), c_n = sum_k W'_nk, d_n = sum_k beta_k W_nk + bias_n and the row's
@@ -521,6 +521,9 @@ int launch_path(const VitGemmArgs& a, int mode, hipStream_t s) {
         if (a.act == CFSAR_ACT_QUICKGELU) return launch_inst<_Float16, __bf16, CFSAR_ACT_QUICKGELU, 2, OPATH, STORE>(a, s);
         return launch_inst<_Float16, __bf16, CFSAR_ACT_NONE, 2, OPATH, STORE>(a, s);
     }
+#ifdef CFSAR_DEV
+    if (mode == 3) return launch_inst<_Float16, __bf16, CFSAR_ACT_NONE, 0, OPATH, STORE>(a, s);   // timing A/B: fp16 MFMA on a plain GEMM
+#endif
     if (a.act == CFSAR_ACT_QUICKGELU) return launch_inst<__bf16, __bf16, CFSAR_ACT_QUICKGELU, 0, OPATH, STORE>(a, s);
     return launch_inst<__bf16, __bf16, CFSAR_ACT_NONE, 0, OPATH, STORE>(a, s);
 }
@@ -558,7 +561,10 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
 #ifdef CFSAR_DEV
     a.dbg = c.dbg;
 #endif
-    const int mode = lnfold ? 2 : (f16res ? 1 : 0);
+    int mode = lnfold ? 2 : (f16res ? 1 : 0);
+#ifdef CFSAR_DEV
+    if (mode == 0 && c.act == CFSAR_ACT_NONE && (c.dbg & 64)) mode = 3;
+#endif
     switch (c.opath * 4 + c.store) {
         case 0: return launch_path<0, 0>(a, mode, s);
         case 2: return launch_path<0, 2>(a, mode, s);
@@ -574,7 +580,7 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
 
 namespace {
 #ifdef CFSAR_DEV
-int g_force_opath = -1, g_force_store = -1;
+int g_force_opath = -1, g_force_store = -1, g_force_dbg = 0;
 #endif
 int vit_policy_opath(int K) {                                   // measured, see the policy comment in gemm.hip
 #ifdef CFSAR_DEV
@@ -593,6 +599,7 @@ int vit_policy_store(int dflt) {
 #include "../../include/clipfsar_hip_dev.h"
 // dev builds only: operand path / store policy of cfsar_gemm_lnfold and cfsar_gemm_residual_stats; -1 = product policy
 extern "C" void cfsar_debug_set_vit_paths(int opath, int store) { g_force_opath = opath; g_force_store = store; }
+extern "C" void cfsar_debug_set_vit_dbg(int dbg) { g_force_dbg = dbg; }
 #endif
 
 // out = act(LayerNorm(x; gamma, beta) W^T + bias) with the LayerNorm folded into the GEMM (MODE 2 above).  See the header.
@@ -608,6 +615,9 @@ extern "C" int cfsar_gemm_lnfold(const void* x, const void* Wg, void* out, const
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = 0;
     c.out_dtype = CFSAR_BF16; c.res_dtype = CFSAR_F32; c.act = act; c.relu = 0;
     c.opath = vit_policy_opath(K); c.store = vit_policy_store(2); c.group = 8; c.colfast = 0; c.dbg = 0;
+#ifdef CFSAR_DEV
+    c.dbg = g_force_dbg;
+#endif
     const int rc = cfsar_gemm_vit_try(c, static_cast<hipStream_t>(stream));
     return rc == -2 ? cfsar_fail("cfsar_gemm_lnfold: operands too large for 32-bit offsets") : rc;
 }

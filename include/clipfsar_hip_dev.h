@@ -22,6 +22,8 @@ void cfsar_debug_set_gemm_variant(int variant, int dbg);
 /* Operand path (0 register-staged, 1 LDS-DMA) and store policy (0 default, 1 nt, 2 sc1) of cfsar_gemm_lnfold /
  * cfsar_gemm_residual_stats; -1 = the product policy. */
 void cfsar_debug_set_vit_paths(int opath, int store);
+/* ablation bits of cfsar_gemm_lnfold (32 = bf16 MFMA instruction on the fp16 bits: timing A/B only) */
+void cfsar_debug_set_vit_dbg(int dbg);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop
