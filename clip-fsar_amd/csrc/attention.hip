@@ -2,12 +2,13 @@
 // per (frame, head): softmax(q k^T / sqrt(64)) v, no mask, no dropout.  Sequence = 197 (B/16) or 257 (L/14) tokens,
 // head_dim = 64, so K and V of one (frame, head) fit in LDS and the softmax is single-pass.
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "common.h"
 
 namespace {
 
-__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 typedef unsigned att_u32x4 __attribute__((ext_vector_type(4)));
 
 // O^T tile -> global, 16 bytes per lane.  A lane (q = lane&15, g = lane>>4) holds d = 16dt + 4g + r of its query row; lanes g
@@ -53,170 +54,369 @@ __device__ __forceinline__ void store_o_tile(const f32x4 (&o)[4], float inv, boo
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// bf16 MFMA kernel.  One 256-thread workgroup per (head, frame).
-//   LDS:  K tile  [NP keys][64] bf16, 128-byte rows, 16-byte chunks XOR-swizzled with (row>>1)&7
-//         V^T tile [64 d][NP keys] bf16, row stride == 16 (mod 256) bytes -> conflict-free ds_read_b64
-//   Per wave: 16 query rows at a time.  S^T = K . Q^T with v_mfma_f32_16x16x32_bf16 (K rows feed MFMA "A", Q^T feeds
-//   "B"), so lane (q = lane&15, g = lane>>4) holds, for every 16-key tile j, the scores of keys 16j+4g+{0..3} for
-//   ITS query: the softmax reduction over keys is in-lane + two shuffles (xor 16, 32), and the exponentiated
-//   scores are already in the "B" fragment layout of the PV MFMA (O^T = V^T . P^T) because the MFMA k index is
-//   only a summation index: k-slot (g, j<4) <-> key 32kb+4g+j, (g, j>=4) <-> key 32kb+16+4g+(j-4); V^T fragments are
-//   read from LDS with the same key permutation.  No P round trip through LDS, no cross-lane data movement.
+// bf16 MFMA kernel (round 2).  One workgroup of NW waves per (head, frame).
+//   Staging: the K rows and the V rows of the (frame, head) go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: 8 rows x 128 B per
+//         wave-instruction, no VGPR round trip, no transposition pass); both tiles keep the global row-major [key][64] bf16 layout
+//         with 128-byte rows and XOR-swizzled 16-byte chunks (the swizzle is applied to the per-lane SOURCE address):
+//           K: chunk ^= (row >> 1) & 7         -> the 16 rows x one chunk of a ds_read_b128 K fragment hit 16 different slots
+//           V: chunk ^= ((row >> 1) & 3) << 1  -> the 8 rows x 32 B of a ds_read_b64_tr_b16 half hit 8 different 32-byte slots
+//         (round 1 loaded K / V into registers, transposed V with 4-byte LDS writes -- 8.2-11.5 K of a workgroup's 28.8 K cycles --
+//         and read V^T with 2-way conflicted ds_read2_b64: 37 % of the LDS cycles were conflicts.)
+//   Per wave: 16 query rows at a time.  S^T = K . Q^T with v_mfma_f32_16x16x32_bf16 (K rows feed MFMA "A", Q^T feeds "B"), so
+//         lane (q = lane & 15, g = lane >> 4) holds, for every 16-key tile j, the scores of keys 16 j + 4 g + {0..3} for ITS query:
+//         the softmax reduction over keys is in-lane + two shuffles (xor 16, 32), and the exponentiated scores are already the
+//         "B" fragment of the PV MFMA (O^T = V^T . P^T): k-slot (g, i < 4) <-> key 32 kb + 4 g + i, (g, i >= 4) <-> key
+//         32 kb + 16 + 4 g + (i - 4).  The matching V^T "A" fragment (d = 16 dt + (lane & 15); the same 8 keys) is TWO
+//         ds_read_b64_tr_b16: the hardware transposes a [4 keys][16 d] block of the row-major V tile per 16-lane group
+//         (semantics probed in tools/ubench/tr_read_probe.hip).  No P round trip through LDS, no cross-lane data movement.
+//   The exponentials of key block kb + 1 are issued before the PV MFMAs of block kb, so the transcendental / VALU work of the
+//         softmax runs in the shadow of the matrix pipe instead of in a phase of its own.
 // ------------------------------------------------------------------------------------------------------------
-// NKB = number of 32-key blocks (7 -> up to 224 keys, 9 -> up to 288 keys); NTV = number of 16-key tiles that hold at
-// least one real key when known at compile time (13 for 197 tokens, 17 for 257), 0 = generic (all tiles, all masked).
-// ATT_THREADS = 512: 8 waves share one staged (frame, head); 2 workgroups per CU (LDS 61 KB each) = 4 waves/SIMD.
-// COMPACT (needs NTV > 0): K holds only the NTV*16 rows that are read and V^T rows are 16*NTV + 8 keys long -> 54 336 B for
-// 197 tokens, THREE workgroups per CU; used with 256-thread workgroups (4 waves, 3-4 query tiles each).
-template <int NTV>
-constexpr int att_vt_stride(int NP, bool compact) { return compact ? (NTV * 16 + 8) * 2 : ((NP * 2 + 255) / 256) * 256 + 16; }
-template <int NKB, int NTV, int ATT_THREADS = 512, bool COMPACT = false>
-__global__ __launch_bounds__(ATT_THREADS, ATT_THREADS == 512 ? 4 : 3) void vit_attn_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
-                                                            int ntok, int D, float scale_log2e) {
-    constexpr int NP = NKB * 32;
+// NKB = number of 32-key blocks (7 -> up to 224 keys, 9 -> up to 288 keys); NTV = number of 16-key tiles that hold at least one
+// real key when known at compile time (13 for 197 tokens, 17 for 257), 0 = generic (all 2 NKB tiles, masked by ntok).
+// NW = waves per workgroup; WPS = waves per SIMD the register budget must allow (workgroups per CU x NW / 4).
+__device__ __forceinline__ void att_glds16(const char* src, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_addr)
+        : "memory");
+}
+typedef short att_s16x4 __attribute__((ext_vector_type(4)));
+template <typename F, int... Is>
+__device__ __forceinline__ void att_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void att_static_for(F&& f) {
+    att_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// Per-lane LDS read offsets of the tile computation.  K fragment of tile j: row 16 j + q16, chunk (4 ks + g) ^ ((row >> 1) & 7)
+// -- the swizzle term does not depend on j (16 j is a multiple of 16).  V^T fragment of (dt, kb): rows 32 kb (+16) + 4 g +
+// (q16 >> 2), bytes ((dt ^ s) << 5) + ((q16 & 3) << 3),  s = (2 g + (q16 >> 3)) & 3.
+struct AttLane {
+    int q16, g, krow, koff[2], vrow, voff[4];
+    __device__ __forceinline__ explicit AttLane(int lane) {
+        q16 = lane & 15;
+        g = lane >> 4;
+        krow = q16 * 128;
+        const int kswz = (q16 >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) koff[ks] = ((ks * 4 + g) ^ kswz) << 4;
+        vrow = (4 * g + (q16 >> 2)) * 128 + ((q16 & 3) << 3);
+        const int vs = (2 * g + (q16 >> 3)) & 3;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) voff[dt] = (dt ^ vs) << 5;
+    }
+};
+
+// One 16-query tile against the K / V tiles in LDS: o[dt][r] = (unnormalised) O^T[16 dt + 4 g + r][q16], inv = 1 / row sum.
+// The LDS fragment reads run TWO steps ahead of the MFMAs that consume them (S^T: two 16-key tiles; PV: one 32-key block = 8
+// transpose reads): left to itself hipcc emits read -> wait -> MFMA pairs, and a wave then spends an LDS round trip per MFMA pair
+// (13 + 28 round trips per tile; measured 12.7 K cycles per (frame, head) against 2.8 K of matrix-pipe work).
+template <int NKB, int NTV>
+__device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const AttLane& L, const bf16x8 (&qf)[2], int ntok,
+                                          float scale_log2e, f32x4 (&o)[4], float& inv) {
+    constexpr int NT = NKB * 2;
+    constexpr int nt_valid = NTV > 0 ? NTV : NT;
+    const char* kbase = sK + L.krow;
+    const char* vbase = sV + L.vrow;
+    const int g = L.g;
+    f32x4 s[NT];
+    bf16x8 kf[nt_valid][2];
+    auto kload = [&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[j][ks] = *reinterpret_cast<const bf16x8*>(kbase + j * 2048 + L.koff[ks]);
+    };
+    constexpr int KPF = NKB >= 9 ? 1 : 2;                          // read-ahead in tiles (the 288-key instance has 72 score registers)
+    kload(std::integral_constant<int, 0>{});
+    if constexpr (nt_valid > 1 && KPF > 1) kload(std::integral_constant<int, 1>{});
+    att_static_for<NT>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (j < nt_valid) {
+            if constexpr (j + KPF < nt_valid) kload(std::integral_constant<int, j + KPF>{});
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j][ks], qf[ks], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        s[j] = acc;
+    });
+    // mask the padded keys of the last (partial) tile, row max over keys (in-lane, then across the 4 lane groups)
+    float mx = -1e30f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        if (NTV == 0 || j == nt_valid - 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (j * 16 + g * 4 + r >= ntok) s[j][r] = -1e30f;
+        }
+        if (j < nt_valid) mx = fmaxf(fmaxf(mx, fmaxf(s[j][0], s[j][1])), fmaxf(s[j][2], s[j][3]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxs = mx * scale_log2e;
+    float sum = 0.f;
+    // P fragment of key block kb: exp2 of tiles 2 kb, 2 kb + 1 (raw v_exp_f32), summed in fp32, rounded to bf16
+    auto pblock = [&](int kb) __attribute__((always_inline)) {
+        bf16x8 pf;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = 2 * kb + t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pv = 0.f;
+                if (j < nt_valid) {
+                    const float z = fmaf(s[j][r], scale_log2e, -mxs);
+                    pv = __builtin_amdgcn_exp2f(z);
+                    asm volatile("" : "+v"(pv) : "v"(z));       // z stays intact until 2^z exists (see csrc/gemm_vit.hip quick_gelu4)
+                    sum += pv;
+                }
+                pf[4 * t + r] = (__bf16)pv;
+            }
+        }
+        return pf;
+    };
+    // V^T fragments of block kb: second half (keys 32 kb + 16 ...): when that tile is not staged (odd nt_valid) its probabilities
+    // are 0 and the fragment re-reads the first half (finite values)
+    constexpr int NBLK = (nt_valid + 1) / 2;
+    uint4 vf[2][4];
+    auto vload = [&](int kb, uint4 (&dst)[4]) __attribute__((always_inline)) {
+        const int hoff = (2 * kb + 1 < nt_valid) ? 2048 : 0;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const char* vp = vbase + kb * 4096 + L.voff[dt];
+            const att_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)(vp));
+            const att_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)(vp + hoff));
+            const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+            dst[dt] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+    };
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    vload(0, vf[0]);
+    bf16x8 pcur = pblock(0);
+    att_static_for<NBLK>([&](auto KB) {
+        constexpr int kb = decltype(KB)::value;
+        bf16x8 pnext = pcur;
+        if constexpr (kb + 1 < NBLK) {
+            vload(kb + 1, vf[(kb + 1) & 1]);                      // next block's transpose reads ...
+            pnext = pblock(kb + 1);                                // ... and its exponentials, under the MFMAs below
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf[kb & 1][dt]), pcur, o[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        pcur = pnext;
+    });
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    inv = __builtin_amdgcn_rcpf(sum);
+}
+
+template <int NKB, int NTV, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
+                                                                     int ntok, int D, float scale_log2e, int dbg) {
     constexpr int NT = NKB * 2;                                    // 16-key tiles
-    constexpr int VT_STRIDE = att_vt_stride<NTV>(NP, COMPACT);     // bytes
-    constexpr int KROWS = COMPACT ? NTV * 16 : NP;                 // K rows kept in LDS
-    constexpr int VKEYS = COMPACT ? VT_STRIDE / 2 : NP;            // keys per V^T row that are written (pairs: VKEYS / 2)
-    static_assert(!COMPACT || NTV > 0, "the compact LDS image needs the number of valid key tiles at compile time");
+    constexpr int nt_valid = NTV > 0 ? NTV : NT;                   // tiles that are computed
+    constexpr int KROWS = nt_valid * 16;                           // rows of K and of V kept in LDS
+    constexpr int NPIECE = KROWS / 8;                              // 1 KiB DMA pieces per operand
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
-    char* sVt = smem + KROWS * 128;
+    char* sV = smem + KROWS * 128;
 
     const int h = blockIdx.x, f = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t ld = (size_t)3 * D;
     const __bf16* base = qkv + (size_t)f * ntok * ld + h * 64;
+    const char* baseb = reinterpret_cast<const char*>(base);
 
-    // ---- stage K (swizzled rows, NP*8 16-byte chunks) and V^T: ALL global loads of a thread are issued before the first LDS
-    // write (cycle stamps: the load -> write -> load -> write form spent 11.5 K of a workgroup's 28.8 K cycles here, three to
-    // four dependent memory round trips)
-    constexpr int KIT = (KROWS * 8 + ATT_THREADS - 1) / ATT_THREADS;
-    constexpr int VIT = ((VKEYS / 2) * 8 + ATT_THREADS - 1) / ATT_THREADS;
-    att_u32x4 kreg[KIT], vreg0[VIT], vreg1[VIT];     // native vectors: plain SSA values (a HIP uint4 copy is a memcpy -> scratch)
+    // ---- stage K and V: piece p = rows 8p .. 8p+7; lane (r = lane >> 3, c = lane & 7) fills LDS chunk c of its row with the
+    // global chunk c ^ swizzle(row).  Rows >= ntok (padding of the last tile) re-read row ntok-1: finite values whose
+    // probabilities are exactly 0.
+    {
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+        const int r = lane >> 3, c = lane & 7;
 #pragma unroll
-    for (int it = 0; it < KIT; ++it) {
-        const int idx = tid + it * ATT_THREADS;
-        const int r = idx >> 3, c = (idx & 7) ^ swz(r);
-        kreg[it] = att_u32x4{0, 0, 0, 0};
-        if (idx < KROWS * 8 && r < ntok) kreg[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)r * ld + D + c * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < VIT; ++it) {
-        const int idx = tid + it * ATT_THREADS;
-        const int kp = idx % (VKEYS / 2), dc = idx / (VKEYS / 2);
-        vreg0[it] = vreg1[it] = att_u32x4{0, 0, 0, 0};
-        if (idx < (VKEYS / 2) * 8) {
-            if (2 * kp < ntok) vreg0[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)(2 * kp) * ld + 2 * D + dc * 8);
-            if (2 * kp + 1 < ntok) vreg1[it] = *reinterpret_cast<const att_u32x4*>(base + (size_t)(2 * kp + 1) * ld + 2 * D + dc * 8);
+        for (int it = 0; it < (NPIECE + NW - 1) / NW; ++it) {
+            const int pc = wave + it * NW;                          // wave-uniform
+            if (pc < NPIECE) {
+                int row = pc * 8 + r;
+                const int srow = row < ntok ? row : ntok - 1;
+                const char* rowp = baseb + (size_t)srow * ld * 2;
+                const int ck = c ^ ((row >> 1) & 7);
+                att_glds16(rowp + (size_t)D * 2 + ck * 16, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)pc * 1024u));
+            }
         }
-    }
 #pragma unroll
-    for (int it = 0; it < KIT; ++it) {
-        const int idx = tid + it * ATT_THREADS;
-        if (idx < KROWS * 8) *reinterpret_cast<att_u32x4*>(sK + (idx >> 3) * 128 + (idx & 7) * 16) = kreg[it];
-    }
-#pragma unroll
-    for (int it = 0; it < VIT; ++it) {
-        const int idx = tid + it * ATT_THREADS;
-        if (idx < (VKEYS / 2) * 8) {
-            const int kp = idx % (VKEYS / 2), dc = idx / (VKEYS / 2);
-            const unsigned a[4] = {vreg0[it][0], vreg0[it][1], vreg0[it][2], vreg0[it][3]};
-            const unsigned b[4] = {vreg1[it][0], vreg1[it][1], vreg1[it][2], vreg1[it][3]};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<unsigned*>(sVt + (dc * 8 + 2 * j) * VT_STRIDE + kp * 4) = (a[j] & 0xFFFFu) | (b[j] << 16);          // d = dc*8 + 2j
-                *reinterpret_cast<unsigned*>(sVt + (dc * 8 + 2 * j + 1) * VT_STRIDE + kp * 4) = (a[j] >> 16) | (b[j] & 0xFFFF0000u);  // d + 1
+        for (int it = 0; it < (NPIECE + NW - 1) / NW; ++it) {       // V after K: the S phase starts as soon as K has landed
+            const int pc = wave + it * NW;
+            if (pc < NPIECE) {
+                int row = pc * 8 + r;
+                const int srow = row < ntok ? row : ntok - 1;
+                const char* rowp = baseb + (size_t)srow * ld * 2;
+                const int cv = c ^ (((row >> 1) & 3) << 1);
+                att_glds16(rowp + (size_t)D * 4 + cv * 16, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(KROWS * 128) + (unsigned)pc * 1024u));
             }
         }
     }
-    if constexpr (COMPACT) {                 // the last V^T row is over-read by 16 bytes (keys 216-223 of d = 63): keep them finite
-        if (tid < 4) *reinterpret_cast<att_u32x4*>(sVt + 64 * VT_STRIDE + tid * 16) = att_u32x4{0, 0, 0, 0};
-    }
-    __syncthreads();
-
     const int q16 = lane & 15, g = lane >> 4;
     const int nqt = (ntok + 15) >> 4;
-    constexpr int nt_valid = NTV > 0 ? NTV : NKB * 2;   // 16-key tiles that are computed
-    for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
+    // Q fragment ("B" operand) of this wave's first tile, in flight while the DMA lands: Q[qrow][32 ks + 8 g .. +8].
+    // (Tried: Q by LDS-DMA into a wave-private 2 KiB buffer that then stages the O tile for whole-line stores -- 404 vs 410 us at
+    // 1 280 frames, inside the noise, for 14-18 KiB of LDS; removed.)
+    bf16x8 qf[2];
+    {
+        int qrow = wave * 16 + q16;
+        qrow = qrow < ntok ? qrow : ntok - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + ks * 32 + g * 8);
+    }
+    // One wait for everything.  (Tried: K first / V under the S phase with counted vmcnt -- LDS-DMA and VGPR loads share the
+    // counter but do not retire in one order, so a counted wait across the two kinds is not a guarantee (wrong results), and
+    // with vmcnt(0) everywhere the split bought nothing: 406 vs 411 us at 1 280 frames, other workgroups already fill the wait.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const AttLane L(lane);
+    for (int qt = wave; qt < nqt; qt += NW) {
         int qrow = qt * 16 + q16;
         const bool qvalid = qrow < ntok;
         if (!qvalid) qrow = ntok - 1;
-        // Q fragment ("B" operand): Q[qrow][32ks + 8g .. +8]
-        bf16x8 qf[2];
+        bf16x8 qn[2];                                               // the next tile's Q rows: in flight during this tile's computation
+        {
+            int qr2 = (qt + NW) * 16 + q16;
+            qr2 = qr2 < ntok ? qr2 : ntok - 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + ks * 32 + g * 8);
-
-        // S^T tiles (tiles that hold only padded keys are skipped; their probabilities are 0)
-        f32x4 s[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (j < nt_valid) {
-                const int kr = j * 16 + q16;   // key row this lane reads for the "A" operand
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kr * 128 + (((ks * 4 + g) ^ swz(kr)) << 4));
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
-                }
-            }
-            s[j] = acc;
-            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the K-fragment live ranges (no spills)
+            for (int ks = 0; ks < 2; ++ks) qn[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qr2 * ld + ks * 32 + g * 8);
         }
-        // mask the padded keys of the last (partial) tile, row max over keys (in-lane, then across the 4 lane groups)
-        float mx = -1e30f;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            if (NTV == 0 || j == nt_valid - 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (j * 16 + g * 4 + r >= ntok) s[j][r] = -1e30f;
-            }
-            if (j < nt_valid) mx = fmaxf(fmaxf(mx, fmaxf(s[j][0], s[j][1])), fmaxf(s[j][2], s[j][3]));
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mxs = mx * scale_log2e;
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            if (j < nt_valid) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[j][r], scale_log2e, -mxs));   // raw v_exp_f32
-                    s[j][r] = pv;
-                    sum += pv;
-                }
-            }
-        }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = __builtin_amdgcn_rcpf(sum);
-        // O^T = V^T . P^T
         f32x4 o[4];
+        float inv;
+#ifdef CFSAR_DEV
+        if (dbg & 1) {                                               // ablation: no tile computation (memory pipeline only)
+            inv = 1.f;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            bf16x8 pf;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pf[r] = (__bf16)s[2 * kb][r];
-                pf[4 + r] = (__bf16)s[2 * kb + 1][r];
-            }
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const char* vr = sVt + (dt * 16 + q16) * VT_STRIDE + (kb * 32 + g * 4) * 2;
-                const uint2 lo = *reinterpret_cast<const uint2*>(vr);
-                const uint2 hi = *reinterpret_cast<const uint2*>(vr + 32);
-                const uint4 packed = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, packed), pf, o[dt], 0, 0, 0);
-            }
-            if (kb & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        // O^T[d][q]: lane owns query q16, d = 16dt + 4g + r
+            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{(float)qf[0][0], 0.f, 0.f, (float)qf[1][1]};
+        } else
+#endif
+        attn_tile<NKB, NTV>(sK, sV, L, qf, ntok, scale_log2e, o, inv);
+        // O^T[d][q]: lane owns query q16, d = 16 dt + 4 g + r
         store_o_tile(o, inv, qvalid, out + ((size_t)f * ntok + qrow) * D + h * 64, g);
+        qf[0] = qn[0];
+        qf[1] = qn[1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Persistent ring form of the kernel above for ntok <= 16 NTV (ViT-B/16: 197 tokens, NTV = 13): ONE workgroup per CU walks
+// (frame, head) items; K / V of item i + 2 are in flight while item i is computed.
+//
+// Why: the one-item-per-workgroup kernel ran at 3.8-3.9 TB/s whatever the workgroup shape (2 x 7, 2 x 8, 3 x 5 waves per CU: 394-408 us
+// at 1 280 frames, 1.55 GB of traffic): with one buffer per workgroup about ONE item (53 KB) per CU is in flight at a time, and
+// 256 x 53 KB / ~3.5 us of loaded HBM latency is that rate (Little's law).  The memory floor is ~260 us.
+//   * LDS = a ring of THREE K+V buffers (3 x 53 248 B of the CU's 163 840): two items (106 KB) in flight per CU all the time;
+//   * wave NTV is a LOADER: it issues every LDS-DMA piece (52 per item) and nothing else, so its vmcnt queue holds one kind of
+//     operation, retires in order, and `s_waitcnt vmcnt(52)` means "item i has landed, item i + 1 may still fly".  (Q loads, O
+//     stores and DMA share the counter but retire out of order with each other: consumers cannot count across kinds.)
+//   * waves 0 .. NTV-1 are CONSUMERS, one 16-query tile each (same S / softmax / PV code as above);
+//   * ONE barrier per item: the loader arrives when item i has landed, the consumers when they are done with item i - 1; past it
+//     the loader refills the buffer of item i - 1 with item i + 2.
+// ------------------------------------------------------------------------------------------------------------
+template <int NKB, int NTV>
+__global__ __launch_bounds__((NTV + 1) * 64, 4) void vit_attn_ring_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
+                                                                          int ntok, int D, int heads, int nitems, float scale_log2e) {
+    constexpr int nt_valid = NTV;
+    constexpr int KROWS = nt_valid * 16;
+    constexpr int NPIECE = KROWS / 8;
+    constexpr int BUF = 2 * KROWS * 128;
+    static_assert(2 * NPIECE <= 63, "the loader's counted wait must fit vmcnt");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t ld = (size_t)3 * D;
+    const int first = blockIdx.x, stride = gridDim.x;
+    const int nmine = first < nitems ? (nitems - first + stride - 1) / stride : 0;       // same for every wave of the workgroup
+
+    if (wave == NTV) {
+        // ------------------------------------------------------------------ loader
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+        const int r = lane >> 3, c = lane & 7;
+        auto issue = [&](int k) __attribute__((always_inline)) {       // item first + k * stride -> ring slot k % 3
+            const int item = first + k * stride;
+            const int f = item / heads, h = item - f * heads;
+            const char* baseb = reinterpret_cast<const char*>(qkv + (size_t)f * ntok * ld + h * 64);
+            const unsigned slot = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(k % 3) * (unsigned)BUF);
+#pragma unroll 2
+            for (int pc = 0; pc < NPIECE; ++pc) {                    // (rolled: the loader's addresses must not cost the consumers registers)
+                const int row = pc * 8 + r;
+                const int srow = row < ntok ? row : ntok - 1;
+                att_glds16(baseb + (size_t)srow * ld * 2 + (size_t)D * 2 + ((c ^ ((row >> 1) & 7)) << 4),
+                           __builtin_amdgcn_readfirstlane(slot + (unsigned)pc * 1024u));
+            }
+#pragma unroll 2
+            for (int pc = 0; pc < NPIECE; ++pc) {
+                const int row = pc * 8 + r;
+                const int srow = row < ntok ? row : ntok - 1;
+                att_glds16(baseb + (size_t)srow * ld * 2 + (size_t)D * 4 + ((c ^ (((row >> 1) & 3) << 1)) << 4),
+                           __builtin_amdgcn_readfirstlane(slot + (unsigned)(KROWS * 128) + (unsigned)pc * 1024u));
+            }
+        };
+        if (nmine > 0) issue(0);
+        if (nmine > 1) issue(1);
+        for (int k = 0; k < nmine; ++k) {
+            if (k + 1 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPIECE) : "memory");     // item k landed; k + 1 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                                                       // item k ready / item k - 1 consumed
+            if (k + 2 < nmine) issue(k + 2);
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- consumers: wave w owns query tile w
+    const int q16 = lane & 15, g = lane >> 4;
+    const int qt = wave;
+    int qrow = qt * 16 + q16;
+    const bool qvalid = qrow < ntok;
+    if (!qvalid) qrow = ntok - 1;
+    const bool has_tile = qt * 16 < ntok;                            // wave-uniform
+    const AttLane L(lane);
+    auto qptr = [&](int k) __attribute__((always_inline)) {
+        const int item = first + k * stride;
+        const int f = item / heads, h = item - f * heads;
+        return qkv + ((size_t)f * ntok + qrow) * ld + h * 64;
+    };
+    bf16x8 qf[2];
+    if (nmine > 0 && has_tile) {
+        const __bf16* qp = qptr(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32 + g * 8);
+    }
+    for (int k = 0; k < nmine; ++k) {
+        __syncthreads();                                             // item k has landed in ring slot k % 3
+        if (!has_tile) continue;
+        const char* sK = smem + (k % 3) * BUF;
+        bf16x8 qn[2] = {qf[0], qf[1]};
+        if (k + 1 < nmine) {                                         // next item's Q rows: in flight during this item's computation
+            const __bf16* qp = qptr(k + 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qn[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32 + g * 8);
+        }
+        f32x4 o[4];
+        float inv;
+        attn_tile<NKB, NTV>(sK, sK + KROWS * 128, L, qf, ntok, scale_log2e, o, inv);
+        {
+            const int item = first + k * stride;
+            const int f = item / heads, h = item - f * heads;
+            store_o_tile(o, inv, qvalid, out + ((size_t)f * ntok + qrow) * D + h * 64, g);
+        }
+        qf[0] = qn[0];
+        qf[1] = qn[1];
     }
 }
 
@@ -271,19 +471,47 @@ __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float* __restri
     }
 }
 
-template <int NKB, int NTV, int NTHR = 512, bool COMPACT = false>
+#ifdef CFSAR_DEV
+int g_attn_dbg = 0;
+#endif
+static inline int attn_dbg() {
+#ifdef CFSAR_DEV
+    return g_attn_dbg;
+#else
+    return 0;
+#endif
+}
+
+template <int NKB, int NTV, int NW, int WPS>
 int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
-    constexpr int NP = NKB * 32;
-    constexpr int VT_STRIDE = att_vt_stride<NTV>(NP, COMPACT);
-    constexpr int LDS = (COMPACT ? NTV * 16 : NP) * 128 + 64 * VT_STRIDE + (COMPACT ? 64 : 0);   // + tail pad: the last V^T row is over-read
-    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<NKB, NTV, NTHR, COMPACT>), LDS, "cfsar_vit_attention")) return rc;
+    constexpr int KROWS = (NTV > 0 ? NTV : NKB * 2) * 16;
+    constexpr int LDS = 2 * KROWS * 128;
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<NKB, NTV, NW, WPS>), LDS, "cfsar_vit_attention")) return rc;
     const float scale_log2e = 0.125f * 1.4426950408889634f;
-    hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB, NTV, NTHR, COMPACT>), dim3(heads, F), dim3(NTHR), LDS, s,
-                       static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e);
+    hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB, NTV, NW, WPS>), dim3(heads, F), dim3(NW * 64), LDS, s,
+                       static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e, attn_dbg());
     return cfsar_check_launch("cfsar_vit_attention(bf16)");
 }
 
+template <int NKB, int NTV>
+int launch_ring(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
+    constexpr int LDS = 3 * 2 * NTV * 16 * 128;
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_ring_kernel<NKB, NTV>), LDS, "cfsar_vit_attention")) return rc;
+    const int nitems = F * heads;
+    const int cus = cfsar_num_cus();
+    const int grid = nitems < cus ? nitems : cus;
+    hipLaunchKernelGGL((vit_attn_ring_kernel<NKB, NTV>), dim3(grid), dim3((NTV + 1) * 64), LDS, s, static_cast<const __bf16*>(qkv),
+                       static_cast<__bf16*>(out), ntok, D, heads, nitems, 0.125f * 1.4426950408889634f);
+    return cfsar_check_launch("cfsar_vit_attention(bf16 ring)");
+}
+
 }  // namespace
+
+#ifdef CFSAR_DEV
+#include "../../include/clipfsar_hip_dev.h"
+static int g_attn_variant = 0;
+extern "C" void cfsar_debug_set_attn_variant(int v) { g_attn_variant = v & 255; g_attn_dbg = v >> 8; }
+#endif
 
 extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads,
                                    cfsar_stream_t stream) {
@@ -296,10 +524,23 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
         CFSAR_REQUIRE(ntok <= 288, "cfsar_vit_attention: ntok=%d > 288", ntok);
         // (A compact-LDS three-workgroups-per-CU form and a pipelined multi-head form were measured slower / equal in round 1 and
         // removed; numbers and per-phase cycle stamps: profiles/r01_attention_ablation.md.)
-        if (ntok == 197) return launch_bf16<7, 13>(qkv, out, F, ntok, D, heads, s);
-        if (ntok == 257) return launch_bf16<9, 17>(qkv, out, F, ntok, D, heads, s);     // ViT-L/14 @224
-        if (ntok <= 224) return launch_bf16<7, 0>(qkv, out, F, ntok, D, heads, s);
-        return launch_bf16<9, 0>(qkv, out, F, ntok, D, heads, s);
+        // 197 tokens: 13 query tiles over 8 waves, 52 KiB of LDS, 128 registers -> 2 workgroups per CU (measured at 1 280 frames with
+        // the pipelined tile routine: 2 x 8 waves 371-378 us, 2 x 7 383, 3 x 5 403, persistent ring 409; memory pipeline alone 294);
+        // 257 tokens (ViT-L/14 @224): 17 tiles, 68 KiB
+#ifdef CFSAR_DEV
+        if (ntok == 197 && g_attn_variant == 7) return launch_ring<7, 13>(qkv, out, F, ntok, D, heads, s);           // persistent ring
+        if (ntok == 257 && g_attn_variant == 8) return launch_bf16<9, 17, 9, 4>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257 && g_attn_variant == 9) return launch_bf16<9, 17, 6, 4>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197 && g_attn_variant == 5) return launch_bf16<7, 13, 8, 4>(qkv, out, F, ntok, D, heads, s);   // one item per workgroup
+        if (ntok == 197 && g_attn_variant == 6) return launch_bf16<7, 13, 7, 4>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197 && g_attn_variant == 2) return launch_bf16<7, 13, 5, 4>(qkv, out, F, ntok, D, heads, s);   // 3 workgroups x 5 waves
+        if (ntok == 197 && g_attn_variant == 3) return launch_bf16<7, 13, 8, 4>(qkv, out, F, ntok, D, heads, s);   // 2 x 8 waves
+        if (ntok == 197 && g_attn_variant == 4) return launch_bf16<7, 13, 13, 4>(qkv, out, F, ntok, D, heads, s);  // one tile per wave
+#endif
+        if (ntok == 197) return launch_bf16<7, 13, 8, 4>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257) return launch_bf16<9, 17, 8, 4>(qkv, out, F, ntok, D, heads, s);
+        if (ntok <= 224) return launch_bf16<7, 0, 7, 4>(qkv, out, F, ntok, D, heads, s);
+        return launch_bf16<9, 0, 9, 4>(qkv, out, F, ntok, D, heads, s);
     }
     if (dtype == CFSAR_F32) {
         const int lds = ntok * 64 * 4 * 2;

@@ -24,6 +24,8 @@ void cfsar_debug_set_gemm_variant(int variant, int dbg);
 void cfsar_debug_set_vit_paths(int opath, int store);
 /* ablation bits of cfsar_gemm_lnfold (32 = bf16 MFMA instruction on the fp16 bits: timing A/B only) */
 void cfsar_debug_set_vit_dbg(int dbg);
+/* workgroup shape of the bf16 attention kernel at 197 tokens (csrc/attention.hip); 0 = product */
+void cfsar_debug_set_attn_variant(int v);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

