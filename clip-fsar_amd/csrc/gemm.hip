@@ -1276,38 +1276,75 @@ static int launch_p12_f16(const GemmArgs& a0, hipStream_t s) {
 }
 
 // ============================================================================================================
-// Skinny fp32 GEMM (M <= 256 rows): the temporal head of ONE episode is (S+Q)*T = 80 rows against 512...2048-wide weights; the
-// 128x128 MFMA kernel gives that 4-16 workgroups with a long serial K loop (66 us per launch, 8 % of a single-episode forward).
-// Here a workgroup owns 8 output columns for all rows: 256 threads = 8 columns x 32 row groups, thread (c, g) accumulates rows
-// g, g+32, ... in registers with plain fp32 FMAs (A rows broadcast through L1, W rows read once per workgroup), so N/8
-// workgroups (256 for N = 2048) spread over the chip.  Same epilogue as cfsar_gemm: bias, QuickGELU / GELU(erf), fp32 residual.
+// Skinny fp32 GEMM (M <= 256 rows): the temporal head of ONE episode is (S+Q)*T + S = 85 rows against 512...2048-wide weights,
+// and the final ViT projection of one episode's support / query set is 40 rows.  An MFMA tiling gives such a problem 4-16
+// workgroups with a long serial K loop (66 us per launch); a thread-per-column FMA loop straight from global memory is bound
+// by the latency of its K / 4 dependent loads (60 us).  Here a workgroup owns 8 output columns for all rows and streams K in
+// chunks of KC through a 3-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4, two chunks in flight, one barrier per
+// chunk): 256 threads = 8 columns x 32 row groups, thread (c, g) accumulates rows g, g + 32, ... with plain fp32 FMAs from
+// conflict-free ds_read_b128s (the 16-byte chunks of LDS row r sit at position q ^ (r & (CH - 1)); the swizzle is applied on
+// the DMA source side).  N / 8 workgroups (64 ... 256) spread over the chip.  Same epilogue as cfsar_gemm: bias, QuickGELU /
+// GELU(erf), fp32 residual, ReLU, output-row remap.
 // ============================================================================================================
-template <int RPT>
+template <int RPT, int KC>
 __global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(GemmArgs p) {
-    const int c = threadIdx.x & 7, g = threadIdx.x >> 3;
-    const int n = blockIdx.x * 8 + c;
-    const int nc = n < p.N ? n : p.N - 1;
-    const float* A = reinterpret_cast<const float*>(p.A);
-    const float* wr = reinterpret_cast<const float*>(p.W) + (size_t)nc * p.ldw;
+    constexpr int CH = KC / 4;                     // 16-byte chunks per LDS row
+    constexpr int RB = KC * 4;                     // bytes per LDS row
+    constexpr int RPI = 1024 / RB;                 // LDS rows filled by one DMA instruction
+    constexpr int AR = 32 * RPT;                   // A rows of a stage; then 8 W rows; padded so that 4 waves share evenly
+    constexpr int R = AR + 4 * RPI;
+    constexpr int NI = R / RPI / 4;                // DMA instructions per wave per chunk
+    constexpr int STG = R * RB;
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int c = t & 7, g = t >> 3;
+    const int n0 = blockIdx.x * 8;
+    const char* src[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = (i * 4 + wave) * RPI + lane / CH;
+        const int q = (lane % CH) ^ (row & (CH - 1));
+        const char* base;
+        if (row < AR) base = p.A + (size_t)(row < p.M ? row : p.M - 1) * p.lda * 4;
+        else if (row < AR + 8) base = p.W + (size_t)(n0 + row - AR < p.N ? n0 + row - AR : p.N - 1) * p.ldw * 4;
+        else base = p.A;                           // padding rows: any valid address, never read back
+        src[i] = base + q * 16;
+    }
+    auto issue = [&](int chunk, int stage) __attribute__((always_inline)) {
+        char* dst = sk_smem + stage * STG + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) glds16(src[i] + (size_t)chunk * RB, dst + i * 4096);
+    };
+    const int nch = p.K / KC;
+    issue(0, 0);
+    if (nch > 1) issue(1, 1);
     float acc[RPT];
-    const float* ar[RPT];
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        acc[i] = 0.f;
-        const int r = g + 32 * i;
-        ar[i] = A + (size_t)(r < p.M ? r : p.M - 1) * p.lda;
-    }
-    for (int k = 0; k < p.K; k += 4) {
-        const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
+    for (int i = 0; i < RPT; ++i) acc[i] = 0.f;
+    const int gsw = g & (CH - 1);
+    int stage = 0;
+    for (int j = 0; j < nch; ++j) {
+        if (j + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");     // chunk j landed, chunk j + 1 in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // ... for every wave; and every wave is done with chunk j - 1
+        if (j + 2 < nch) issue(j + 2, stage >= 1 ? stage - 1 : 2);                      // into the stage of chunk j - 1
+        const char* sa = sk_smem + stage * STG;
+        const char* sw = sa + (AR + c) * RB;
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const float4 a4 = *reinterpret_cast<const float4*>(ar[i] + k);
-            acc[i] = fmaf(a4.x, w4.x, acc[i]);
-            acc[i] = fmaf(a4.y, w4.y, acc[i]);
-            acc[i] = fmaf(a4.z, w4.z, acc[i]);
-            acc[i] = fmaf(a4.w, w4.w, acc[i]);
+        for (int s4 = 0; s4 < CH; ++s4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(sw + ((s4 ^ c) << 4));
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const float4 a4 = *reinterpret_cast<const float4*>(sa + (g + 32 * i) * RB + ((s4 ^ gsw) << 4));
+                acc[i] = fmaf(a4.x, w4.x, acc[i]);
+                acc[i] = fmaf(a4.y, w4.y, acc[i]);
+                acc[i] = fmaf(a4.z, w4.z, acc[i]);
+                acc[i] = fmaf(a4.w, w4.w, acc[i]);
+            }
         }
+        stage = stage == 2 ? 0 : stage + 1;
     }
+    const int n = n0 + c;
     if (n >= p.N) return;
     const float bv = p.bias ? p.bias[n] : 0.f;
     float* outp = reinterpret_cast<float*>(p.out);
@@ -1315,25 +1352,41 @@ __global__ __launch_bounds__(256) void skinny_gemm_f32_kernel(GemmArgs p) {
     for (int i = 0; i < RPT; ++i) {
         const int r = g + 32 * i;
         if (r >= p.M) continue;
+        int orow = r + p.row_off;
+        if (p.row_group > 0) orow += (r / p.row_group) * p.row_gap;
         float v = apply_act(acc[i] + bv, p.act);
-        if (p.res) v += static_cast<const float*>(p.res)[(size_t)(r + p.row_off) * p.ldr + n];
+        if (p.res) v += static_cast<const float*>(p.res)[(size_t)orow * p.ldr + n];
         if (p.relu) v = fmaxf(v, 0.f);
-        outp[(size_t)(r + p.row_off) * p.ldo + n] = v;
+        outp[(size_t)orow * p.ldo + n] = v;
     }
 }
 
-static int launch_skinny_f32(const GemmArgs& a, hipStream_t s) {
-    const dim3 grid((unsigned)((a.N + 7) / 8));
-    const int rpt = (a.M + 31) / 32;
-    switch (rpt) {
-        case 1: hipLaunchKernelGGL(skinny_gemm_f32_kernel<1>, grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(skinny_gemm_f32_kernel<2>, grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(skinny_gemm_f32_kernel<3>, grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(skinny_gemm_f32_kernel<4>, grid, dim3(256), 0, s, a); break;
-        case 5: case 6: hipLaunchKernelGGL(skinny_gemm_f32_kernel<6>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(skinny_gemm_f32_kernel<8>, grid, dim3(256), 0, s, a); break;
-    }
+template <int RPT, int KC>
+static int launch_skinny_inst(const GemmArgs& a, hipStream_t s) {
+    constexpr int lds = 3 * (32 * RPT + 4 * (1024 / (KC * 4))) * KC * 4;
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&skinny_gemm_f32_kernel<RPT, KC>), lds, "cfsar_gemm(skinny f32)")) return rc;
+    hipLaunchKernelGGL((skinny_gemm_f32_kernel<RPT, KC>), dim3((unsigned)((a.N + 7) / 8)), dim3(256), lds, s, a);
     return cfsar_check_launch("cfsar_gemm(skinny f32)");
+}
+
+// M <= 256, K % 32 == 0 (checked by the caller).  64-float chunks while three stages fit the LDS (M <= 128), else 32.
+static int launch_skinny_f32(const GemmArgs& a, hipStream_t s) {
+    const int rpt = (a.M + 31) / 32;
+    if (a.K % 64 == 0) {
+        switch (rpt) {
+            case 1: return launch_skinny_inst<1, 64>(a, s);
+            case 2: return launch_skinny_inst<2, 64>(a, s);
+            case 3: return launch_skinny_inst<3, 64>(a, s);
+            case 4: return launch_skinny_inst<4, 64>(a, s);
+            default: break;
+        }
+    }
+    switch (rpt) {
+        case 1: case 2: return launch_skinny_inst<2, 32>(a, s);
+        case 3: case 4: return launch_skinny_inst<4, 32>(a, s);
+        case 5: case 6: return launch_skinny_inst<6, 32>(a, s);
+        default: return launch_skinny_inst<8, 32>(a, s);
+    }
 }
 
 }  // namespace
@@ -1391,8 +1444,8 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     constexpr int forced = 0;
 #endif
     const long tiles4 = (long)((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
-    // fp32, at most 256 rows, no row remap: the skinny kernel (the temporal head of one or two episodes)
-    if (in_dtype == CFSAR_F32 && out_dtype == CFSAR_F32 && res_dtype == CFSAR_F32 && row_group == 0 && res_mod == 0 && K % 4 == 0 &&
+    // fp32, at most 192 rows: the skinny kernel (the temporal head and the final ViT projection of one or two episodes)
+    if (in_dtype == CFSAR_F32 && out_dtype == CFSAR_F32 && res_dtype == CFSAR_F32 && res_mod == 0 && K % 32 == 0 &&
         lda % 4 == 0 && ldw % 4 == 0 && M <= 256 && (forced == 14 || (forced == 0 && M <= 192)))
         return launch_skinny_f32(a, s);
     // The ViT-block GEMMs at batch scale (bias [+ QuickGELU] -> bf16, or bias + fp16 residual -> fp16; >= two 256x256 tiles per

@@ -34,6 +34,8 @@ __global__ __launch_bounds__(256) void class_text_logits_kernel(const float* __r
                                                                 const float* __restrict__ text,
                                                                 const float* __restrict__ scale,
                                                                 float* __restrict__ out, int T, int E, int n_cls) {
+    // grid (video, group of 16 classes): every workgroup rebuilds the video's frame mean (T x E floats, L2-resident), then each
+    // wave takes 4 classes at once so that their row loads overlap (a one-class-at-a-time loop is a chain of global latencies).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* mean = reinterpret_cast<float*>(smem);       // [E]
     __shared__ float red[4];
@@ -52,17 +54,22 @@ __global__ __launch_bounds__(256) void class_text_logits_kernel(const float* __r
     __syncthreads();
     const float xnorm = sqrtf(red[0] + red[1] + red[2] + red[3]);
     const float sc = scale[0];
-    for (int c = wave; c < n_cls; c += 4) {
-        const float* tr = text + (size_t)c * E;
-        float dot = 0.f, yy = 0.f;
-        for (int e = lane; e < E; e += 64) {
-            const float y = tr[e];
-            dot = fmaf(mean[e], y, dot);
-            yy = fmaf(y, y, yy);
+    const int c0 = blockIdx.y * 16 + wave * 4;
+    float dot[4] = {0.f, 0.f, 0.f, 0.f}, yy[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int e = lane; e < E; e += 64) {
+        const float m = mean[e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j < n_cls ? c0 + j : n_cls - 1;
+            const float y = text[(size_t)c * E + e];
+            dot[j] = fmaf(m, y, dot[j]);
+            yy[j] = fmaf(y, y, yy[j]);
         }
-        dot = wave_sum(dot);
-        yy = wave_sum(yy);
-        if (lane == 0) out[(size_t)v * n_cls + c] = dot / (xnorm * sqrtf(yy) + 0.01f) * sc;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float d = wave_sum(dot[j]), y2 = wave_sum(yy[j]);
+        if (lane == 0 && c0 + j < n_cls) out[(size_t)v * n_cls + c0 + j] = d / (xnorm * sqrtf(y2) + 0.01f) * sc;
     }
 }
 
@@ -315,44 +322,63 @@ __global__ __launch_bounds__(128) void prototypes_kernel(const float* __restrict
 //   LDS: query rows [T][E], sim [way][T][T].  Each wave computes dot products (wave-shuffle reduction over E),
 //   then 2*way threads run the sequential soft-min DP (few_shot.py:2657-2687), un-stabilised like the reference.
 constexpr int MAX_T = 32;
-__device__ float otam_dp(const float* d /*[T][T] row-major, row stride rs, col stride cs*/, int rs, int cs, int T,
-                         float lbda) {
+// TT > 0: T is the compile-time constant TT, every loop unrolls and the two DP rows live in registers.  TT == 0: run-time T, the
+// rows live in the caller's LDS scratch `rows` (2 x (MAX_T + 2) floats per thread) -- never in scratch memory: the recurrence is
+// one dependent chain of T*T cells, and a scratch round trip per cell made this kernel 140 us for an 8x8 problem.
+template <int TT>
+__device__ __forceinline__ float otam_dp(const float* d /*[T][T] row-major, row stride rs, col stride cs*/, int rs, int cs, int Trt,
+                                         float lbda, float* rows) {
+    const int T = TT > 0 ? TT : Trt;
     // padded width M = T+2; columns 0 and T+1 are zero padding (few_shot.py:2663)
-    float prev[MAX_T + 2], cur[MAX_T + 2];
+    float regs[TT > 0 ? 2 * (TT + 2) : 1];
+    float* prev = TT > 0 ? regs : rows;
+    float* cur = TT > 0 ? regs + (TT + 2) : rows + (MAX_T + 2);
     const float il = 1.0f / lbda;
     prev[0] = 0.f;
+#pragma unroll
     for (int m = 1; m <= T + 1; ++m) {                      // first row: running sum (:2668-2671)
         const float dv = (m <= T) ? d[0 * rs + (m - 1) * cs] : 0.f;
         prev[m] = dv + prev[m - 1];
     }
+#pragma unroll
     for (int l = 1; l < T; ++l) {
         cur[0] = 0.f;
         {   // first non-zero column (:2675)
             const float dv = d[l * rs + 0 * cs];
             cur[1] = dv - lbda * logf(expf(-prev[0] * il) + expf(-prev[1] * il) + expf(-cur[0] * il));
         }
+#pragma unroll
         for (int m = 2; m <= T; ++m) {                      // middle columns (:2678-2679)
             const float dv = d[l * rs + (m - 1) * cs];
             cur[m] = dv - lbda * logf(expf(-prev[m - 1] * il) + expf(-cur[m - 1] * il));
         }
         // last (padding) column (:2683)
         cur[T + 1] = 0.f - lbda * logf(expf(-prev[T] * il) + expf(-prev[T + 1] * il) + expf(-cur[T] * il));
+#pragma unroll
         for (int m = 0; m <= T + 1; ++m) prev[m] = cur[m];
     }
     return prev[T + 1];
 }
 
+// One workgroup per (query video, class): LDS holds the query's T frames [T][E], their norms and the T x T distance block.
+// Phase 1: each wave takes support frames j = wave, wave + 4, ...: the frame's E values sit in registers (float4 per lane per
+// 256 columns, E <= 2048), its T dot products accumulate side by side from ds_read_b128s of the query rows and are reduced at
+// the end -- no dependent global load inside the loops.  Phase 2: two threads run the two sequential soft-min DPs.
+template <int TT>
 __global__ __launch_bounds__(256) void cos_otam_kernel(const float* __restrict__ Xq, const float* __restrict__ protos,
                                                        float* __restrict__ logits, float* __restrict__ dists_out, int Q,
-                                                       int way, int T, int E, float lbda, int single_direct) {
+                                                       int way, int Trt, int E, float lbda, int single_direct) {
+    constexpr int TMAXI = TT > 0 ? TT : MAX_T;
+    const int T = TT > 0 ? TT : Trt;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sq = reinterpret_cast<float*>(smem);            // [T][E]
     float* qn = sq + (size_t)T * E;                          // [T] query norms
-    float* sd = qn + T;                                      // [way][T][T] distances (1 - sim)
-    const int bq = blockIdx.x, b = bq / Q;
+    float* sd = qn + MAX_T;                                  // [T][T] distances (1 - sim) of this class
+    float* dprows = sd + T * T;                              // TT == 0 only: [2][2][MAX_T + 2]
+    const int bq = blockIdx.x, c = blockIdx.y, b = bq / Q;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* xq = Xq + (size_t)bq * T * E;
-    for (int i = tid; i < T * E; i += 256) sq[i] = xq[i];
+    const float4* xq4 = reinterpret_cast<const float4*>(Xq + (size_t)bq * T * E);
+    for (int i = tid; i < T * E / 4; i += 256) reinterpret_cast<float4*>(sq)[i] = xq4[i];
     __syncthreads();
     for (int t = wave; t < T; t += 4) {
         float ss = 0.f;
@@ -361,35 +387,56 @@ __global__ __launch_bounds__(256) void cos_otam_kernel(const float* __restrict__
         if (lane == 0) qn[t] = sqrtf(ss);
     }
     __syncthreads();
-    // one wave per support frame (c, j): its norm once, then dot with every query frame
-    const float* pb = protos + (size_t)b * way * T * E;
-    for (int cj = wave; cj < way * T; cj += 4) {
-        const float* pr = pb + (size_t)cj * E;
+    const float* pb = protos + ((size_t)b * way + c) * T * E;
+    for (int j = wave; j < T; j += 4) {
+        const float* pr = pb + (size_t)j * E;
+        float4 pv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = 4 * lane + 256 * k;
+            pv[k] = e < E ? *reinterpret_cast<const float4*>(pr + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         float yy = 0.f;
-        for (int e = lane; e < E; e += 64) yy = fmaf(pr[e], pr[e], yy);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) yy += pv[k].x * pv[k].x + pv[k].y * pv[k].y + pv[k].z * pv[k].z + pv[k].w * pv[k].w;
         const float yn = sqrtf(wave_sum(yy));
-        const int c = cj / T, j = cj - c * T;
-        for (int i = 0; i < T; ++i) {
-            float dot = 0.f;
-            for (int e = lane; e < E; e += 64) dot = fmaf(sq[i * E + e], pr[e], dot);
-            dot = wave_sum(dot);
-            if (lane == 0) sd[(c * T + i) * T + j] = 1.0f - dot / (qn[i] * yn + 0.01f);
+        float part[TMAXI];
+#pragma unroll
+        for (int i = 0; i < TMAXI; ++i) part[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = 4 * lane + 256 * k;
+            if (256 * k < E) {                                  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < TMAXI; ++i) {
+                    if (i < T && e < E) {
+                        const float4 q4 = *reinterpret_cast<const float4*>(sq + (size_t)i * E + e);
+                        part[i] += q4.x * pv[k].x + q4.y * pv[k].y + q4.z * pv[k].z + q4.w * pv[k].w;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TMAXI; ++i) {
+            if (i < T) {
+                const float dot = wave_sum(part[i]);
+                if (lane == 0) sd[i * T + j] = 1.0f - dot / (qn[i] * yn + 0.01f);
+            }
         }
     }
     __syncthreads();
     if (dists_out)
-        for (int i = tid; i < way * T * T; i += 256) dists_out[(size_t)bq * way * T * T + i] = sd[i];
-    // DP: thread (c, dir)
-    __shared__ float res[2 * 64];
-    if (tid < 2 * way) {
-        const int c = tid >> 1, dir = tid & 1;
+        for (int i = tid; i < T * T; i += 256) dists_out[((size_t)bq * way + c) * T * T + i] = sd[i];
+    __shared__ float res[2];
+    if (tid < 2) {
         float v = 0.f;
-        if (dir == 0) v = otam_dp(sd + c * T * T, T, 1, T, lbda);
-        else if (!single_direct) v = otam_dp(sd + c * T * T, 1, T, T, lbda);     // transposed distances (:2982)
+        float* rows = dprows + (TT > 0 ? 0 : tid * 2 * (MAX_T + 2));
+        if (tid == 0) v = otam_dp<TT>(sd, T, 1, T, lbda, rows);
+        else if (!single_direct) v = otam_dp<TT>(sd, 1, T, T, lbda, rows);        // transposed distances (:2982)
         res[tid] = v;
     }
     __syncthreads();
-    if (tid < way) logits[(size_t)bq * way + tid] = -(res[2 * tid] + res[2 * tid + 1]);
+    if (tid == 0) logits[(size_t)bq * way + c] = -(res[0] + res[1]);
 }
 
 }  // namespace
@@ -398,7 +445,7 @@ extern "C" int cfsar_class_text_logits(const float* feats, const float* text, co
                                        int n_videos, int T, int E, int n_cls, cfsar_stream_t stream) {
     CFSAR_REQUIRE(feats && text && scale && out, "cfsar_class_text_logits: null pointer");
     CFSAR_REQUIRE(n_videos > 0 && T > 0 && E > 0 && n_cls > 0 && E * 4 <= 60000, "cfsar_class_text_logits: bad shape");
-    hipLaunchKernelGGL(class_text_logits_kernel, dim3(n_videos), dim3(256), E * sizeof(float),
+    hipLaunchKernelGGL(class_text_logits_kernel, dim3(n_videos, (n_cls + 15) / 16), dim3(256), E * sizeof(float),
                        static_cast<hipStream_t>(stream), feats, text, scale, out, T, E, n_cls);
     return cfsar_check_launch("cfsar_class_text_logits");
 }
@@ -483,11 +530,18 @@ extern "C" int cfsar_prototypes(const float* Xs, const float* support_labels, fl
 extern "C" int cfsar_cos_otam_logits(const float* Xq, const float* protos, float* logits, float* dists_out, int B, int Q,
                                      int way, int T, int E, float lambda, int single_direct, cfsar_stream_t stream) {
     CFSAR_REQUIRE(Xq && protos && logits, "cfsar_cos_otam_logits: null pointer");
-    CFSAR_REQUIRE(B > 0 && Q > 0 && way > 0 && way <= 64 && T > 0 && T <= MAX_T && E > 0, "cfsar_cos_otam_logits: bad shape");
-    const int lds = (T * E + T + way * T * T) * (int)sizeof(float);
+    CFSAR_REQUIRE(B > 0 && Q > 0 && way > 0 && way <= 65535 && T > 0 && T <= MAX_T && E > 0 && E % 4 == 0 && E <= 2048,
+                  "cfsar_cos_otam_logits: bad shape (T <= 32, E %% 4 == 0, E <= 2048)");
+    const bool fixed_t = T == 8 || T == 16;                  // DP rows in registers; otherwise 2 rows per DP thread in LDS
+    const int lds = (T * E + MAX_T + T * T + (fixed_t ? 0 : 2 * 2 * (MAX_T + 2))) * (int)sizeof(float);
     CFSAR_REQUIRE(lds <= 150 * 1024, "cfsar_cos_otam_logits: T*E too large for LDS");
-    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&cos_otam_kernel), lds, "cfsar_cos_otam_logits")) return rc;
-    hipLaunchKernelGGL(cos_otam_kernel, dim3((unsigned)(B * Q)), dim3(256), lds, static_cast<hipStream_t>(stream), Xq,
-                       protos, logits, dists_out, Q, way, T, E, lambda, single_direct);
-    return cfsar_check_launch("cfsar_cos_otam_logits");
+    auto launch = [&](auto kern) -> int {
+        if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(kern), lds, "cfsar_cos_otam_logits")) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B * Q), (unsigned)way), dim3(256), lds, static_cast<hipStream_t>(stream), Xq, protos, logits,
+                           dists_out, Q, way, T, E, lambda, single_direct);
+        return cfsar_check_launch("cfsar_cos_otam_logits");
+    };
+    if (T == 8) return launch(&cos_otam_kernel<8>);          // DATA.NUM_INPUT_FRAMES of the shipped configs
+    if (T == 16) return launch(&cos_otam_kernel<16>);
+    return launch(&cos_otam_kernel<0>);
 }

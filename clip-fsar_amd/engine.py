@@ -99,14 +99,16 @@ class HipViT:
                     blk["wg_" + tag] = Wg
                     blk["c_" + tag] = Wg.double().sum(1).float().contiguous()          # of the ROUNDED folded weights
                     blk["d_" + tag] = (W.double() @ beta.double() + g(b + bname).double()).float().contiguous()
-        self._cap = 0
-        self._ws = None
+        self._slots = {}
 
     # ------------------------------------------------------------------ workspace (caller-owned device buffers)
-    def _workspace(self, F_):
-        if F_ > self._cap:
+    def _workspace(self, F_, slot=0):
+        """Activation buffers for up to F_ frames.  `slot` names an independent set: two forwards that run concurrently on two
+        streams (ClipFsarEngine's small-batch path) must not share one."""
+        cap, ws = self._slots.get(slot, (0, None))
+        if F_ > cap:
             M, D, cd, dev = F_ * self.ntok, self.D, self.cd, self.dev
-            self._ws = dict(
+            ws = dict(
                 patches=torch.empty(F_ * (self.ntok - 1), self.kpad, device=dev, dtype=cd),
                 x=torch.empty(M, D, device=dev, dtype=self.xd),
                 h=torch.empty(M, D, device=dev, dtype=cd),
@@ -115,12 +117,12 @@ class HipViT:
                 u=torch.empty(M, 4 * D, device=dev, dtype=cd),
                 c=torch.empty(F_, D, device=dev, dtype=torch.float32))
             if self.fold:
-                self._ws["part"] = torch.empty(M, D // 64, 2, device=dev, dtype=torch.float32)    # partial row statistics
-                self._ws["rstat"] = torch.empty(M, 4, device=dev, dtype=torch.float32)            # (mean, std, 1/std, -)
-            self._cap = F_
-        return self._ws
+                ws["part"] = torch.empty(M, D // 64, 2, device=dev, dtype=torch.float32)    # partial row statistics
+                ws["rstat"] = torch.empty(M, 4, device=dev, dtype=torch.float32)            # (mean, std, 1/std, -)
+            self._slots[slot] = (F_, ws)
+        return ws
 
-    def forward(self, frame_sets, feats_out=None, row_maps=None, taps=None):
+    def forward(self, frame_sets, feats_out=None, row_maps=None, taps=None, slot=0):
         """frame_sets: tensor [F,3,H,W] or list of such tensors (processed as one concatenated batch).
         feats_out: optional fp32 [*, E] buffer; row_maps: per set (row_group, row_gap, row_off) mapping the set's
         frame index m to the output feature row  m + (m // row_group) * row_gap + row_off.
@@ -136,7 +138,7 @@ class HipViT:
                 off += c
         if feats_out is None:
             feats_out = torch.empty(F_, self.E, device=self.dev, dtype=torch.float32)
-        ws = self._workspace(F_)
+        ws = self._workspace(F_, slot)
         N, D, npatch = self.ntok, self.D, self.ntok - 1
         M = F_ * N
         x, h, qkv, o, u = ws["x"], ws["h"], ws["qkv"], ws["o"], ws["u"]
@@ -439,6 +441,11 @@ class ClipFsarEngine:
         self.text_train, self.text_test = f32(text_train), f32(text_test)
         self.scale = f32(head_sd["scale"])
         self.max_frames = max_frames
+        # Small batches (one or two episodes): the support and the query frames go through the tower as two concurrent forwards
+        # on two HIP streams.  A single 80-frame GEMM is 2.2 rounds of 256x256 tiles on 256 CUs (a third round that is 18 %
+        # full); with two independent kernel chains the tail of one chain's kernel is filled by the other chain's next kernel.
+        self.dual_frames = 160 if os.environ.get("CFSAR_DUAL_STREAM", "1") != "0" else 0
+        self._side = None
 
     def forward(self, support_set, target_set, support_labels, real_support_labels, way, T, merge_before=False,
                 single_direct=False, taps=None, mode="otam", text_coff=0.9):
@@ -454,7 +461,21 @@ class ClipFsarEngine:
         feats = torch.empty(B, S + Q, T, E, device=self.dev, dtype=torch.float32)
         chunk = max(1, self.max_frames // per_ep)
         feats2d = feats.reshape(B * per_ep, E)
-        for b0 in range(0, B, chunk):
+        dual = (taps is None and B * per_ep <= self.dual_frames and B <= chunk and self.dev.type == "cuda" and
+                not isinstance(self.vit, HipResNet))
+        if dual:
+            if self._side is None:
+                self._side = (torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev))
+            cur = torch.cuda.current_stream(self.dev)
+            sets = (support_set.reshape(-1, *support_set.shape[2:]), target_set.reshape(-1, *target_set.shape[2:]))
+            maps = ((S * T, Q * T, 0), (Q * T, S * T, S * T))
+            for slot, (st, fr, rm) in enumerate(zip(self._side, sets, maps)):
+                st.wait_stream(cur)                                          # the frames were produced on the caller's stream
+                with torch.cuda.stream(st):
+                    self.vit.forward([fr], feats2d, row_maps=[rm], slot=1 + slot)
+            for st in self._side:
+                cur.wait_stream(st)                                          # the head below reads feats on the caller's stream
+        for b0 in range(0, B if not dual else 0, chunk):
             b1 = min(B, b0 + chunk)
             sup = support_set[b0:b1].reshape(-1, *support_set.shape[2:])
             tgt = target_set[b0:b1].reshape(-1, *target_set.shape[2:])

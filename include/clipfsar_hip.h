@@ -188,7 +188,7 @@ int cfsar_prototypes(const float* Xs, const float* support_labels, float* protos
 /* ---- A13/A14/A15 cos_sim (eps = 0.01 added to the product of norms) -> 1 - sim -> OTAM soft-DTW (lambda 0.5,
  * zero-padded columns, both directions unless single_direct) -> logits = -cum_dists
  * (few_shot.py:1115-1124, 2657-2687, 2970-2990).  Xq [B, Q, T, E], protos [B, way, T, E] f32;
- * logits [B, Q, way]; dists_out (optional, may be NULL) [B, Q, way, T, T].  T <= 32. */
+ * logits [B, Q, way]; dists_out (optional, may be NULL) [B, Q, way, T, T].  T <= 32, E % 4 == 0, E <= 2048. */
 int cfsar_cos_otam_logits(const float* Xq, const float* protos, float* logits, float* dists_out, int B, int Q,
                           int way, int T, int E, float lambda, int single_direct, cfsar_stream_t stream);
 

@@ -64,6 +64,39 @@ def test_gemm_plain_and_epilogues(hip, M, N, K, dtype):
     assert maxdiff(x.cpu(), ref0 + bias + res) < tol * max(1.0, float(ref0.abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 8, 64), (40, 512, 768), (85, 1536, 512), (85, 512, 2048), (96, 2048, 512), (97, 100, 96),
+                                   (128, 516, 64), (170, 1536, 512), (192, 36, 160), (33, 24, 32)])
+def test_gemm_skinny_f32(hip, M, N, K):
+    """The LDS-ring skinny fp32 kernel (M <= 192: temporal head / final projection of one or two episodes): every rows-per-
+    thread instance and both chunk widths (K % 64 == 0 with M <= 128, else 32-float chunks), N not a multiple of 8, one-chunk and
+    two-chunk K, all epilogues, and the output-row remap of the final projection (rows of a set scattered into [B, S+Q, T])."""
+    A = _rand(M, K, seed=31)
+    W = _rand(N, K, seed=32, scale=K ** -0.5)
+    bias, res = _rand(N, seed=33), _rand(M, N, seed=34)
+    ref0 = A.double() @ W.double().t()
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    tol = 2e-5 * max(1.0, float(ref0.abs().max()))
+    out = torch.full((M, N), 7.0, device="cuda")
+    hip.gemm(Ad, Wd, out)
+    assert maxdiff(out.cpu().double(), ref0) < tol
+    hip.gemm(Ad, Wd, out, bias=bd, act=hip.ACT_GELU_ERF)
+    assert maxdiff(out.cpu(), orc.gelu_erf((ref0 + bias).float())) < 2 * tol
+    x = res.cuda().clone()
+    hip.gemm(Ad, Wd, x, bias=bd, residual=x)
+    assert maxdiff(x.cpu().double(), ref0 + bias + res) < tol
+    # row remap: row m -> m + (m // group) * gap + off inside a larger buffer; the other rows stay untouched
+    group, gap, off = 8, 5, 3
+    rows_out = M + ((M - 1) // group) * gap + off + 2
+    y = torch.full((rows_out, N), -3.0, device="cuda")
+    hip.gemm(Ad, Wd, y, bias=bd, M=M, N=N, K=K, ldo=N, row_group=group, row_gap=gap, row_off=off)
+    idx = torch.tensor([m + (m // group) * gap + off for m in range(M)])
+    yc = y.cpu()
+    assert maxdiff(yc[idx].double(), ref0 + bias) < tol
+    mask = torch.ones(rows_out, dtype=torch.bool)
+    mask[idx] = False
+    assert torch.all(yc[mask] == -3.0)
+
+
 def test_gemm_row_remap(hip):
     """patch-embed epilogue: rows scattered behind the class token + positional rows added."""
     F_, npatch, D, K = 3, 16, 128, 64
