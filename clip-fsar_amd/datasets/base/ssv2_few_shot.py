@@ -11,8 +11,9 @@ real reference class with a stubbed decoder: oracle/make_golden_n2.py).
 
 Where this differs from the reference, by design:
   * Decoding is a pluggable ``decoder(path) -> reader`` (``len(reader)``, ``reader.get_avg_fps()``, ``reader.get_batch(indices)
-    -> uint8 [T, H, W, 3]``).  The default is decord's ``VideoReader`` like the reference; when decord is not importable the
-    dataset refuses to construct (it never substitutes synthetic frames).
+    -> uint8 [T, H, W, 3]``), given as ``decoder=`` or ``DATA.DECODER`` (callable or "module:attr").  The default is decord's
+    ``VideoReader`` like the reference; when decord is not importable the dataset refuses to construct (it never substitutes
+    synthetic frames).
   * The test transform (ToTensorVideo -> KineticsResizedCropFewshot -> NormalizeVideo -> permute) runs as ONE HIP kernel on the
     device when ``AUGMENTATION.USE_GPU`` is set (clip_fsar_amd.preprocess.preprocess_video, csrc/preprocess.hip: resize + crop
     + normalise + layout in a single pass over the uint8 frames); otherwise on the host with the reference's own torch ops
@@ -165,12 +166,21 @@ class Ssv2_few_shot(torch.utils.data.Dataset):
         self.cfg = cfg
         self.split = split
         self.split_dataset = split
-        self.data_root_dir = cfg.DATA.DATA_ROOT_DIR
-        self.anno_dir = cfg.DATA.ANNO_DIR
+        self.data_root_dir = getattr(cfg.DATA, "DATA_ROOT_DIR", None)
+        self.anno_dir = getattr(cfg.DATA, "ANNO_DIR", None)
+        if not self.data_root_dir or not self.anno_dir:
+            raise FileNotFoundError("Ssv2_few_shot needs DATA.DATA_ROOT_DIR (videos) and DATA.ANNO_DIR ({train,test}_few_shot.txt); "
+                                    "for synthetic episodes set TEST.DATASET: Synthetic_few_shot")
         self.dataset_name = getattr(cfg.TRAIN, "DATASET_FEW", cfg.TEST.DATASET if split == "test" else cfg.TRAIN.DATASET)
         self._num_frames = int(cfg.DATA.NUM_INPUT_FRAMES)
         self._sampling_rate = cfg.DATA.SAMPLING_RATE
         self.gpu_transform = bool(getattr(getattr(cfg, "AUGMENTATION", None), "USE_GPU", False))
+        if decoder is None:
+            decoder = getattr(cfg.DATA, "DECODER", None)          # optional: a callable or "package.module:attribute"
+            if isinstance(decoder, str):
+                import importlib
+                mod, _, attr = decoder.partition(":")
+                decoder = getattr(importlib.import_module(mod), attr)
         self.decoder = decoder if decoder is not None else _decord_decoder()
         self.rng = random                               # the process-global stream, like the reference
         self._episode_seed = getattr(cfg.TEST, "EPISODE_SEED", None)
