@@ -27,6 +27,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -109,7 +110,7 @@ def measured_traffic(episodes_per_step):
     try:
         path = next(p for p in (os.path.join(ROOT, "profiles", n) for n in ("r02_gemm_traffic.json", "r01_gemm_traffic.json")) if os.path.exists(p))
         d = json.load(open(path))["_all_bf16_gemm"]
-        if "--episodes-per-step %d" % episodes_per_step in d["note"]:
+        if re.search(r"--episodes-per-step %d\b" % episodes_per_step, d["note"]):
             return round(d["hbm_bytes_per_launch"])
     except Exception:
         pass

@@ -108,6 +108,41 @@ def test_cfg2_full_size_fp32_and_bf16():
     assert maxdiff(lb[0], g["logits"]) < 0.05
 
 
+def test_timed_configuration_b16_equals_b1_and_golden():
+    """The configuration bench.py times (cfg2, 16 episodes per step, bf16): every episode of the batch gives the logits the same
+    episode gives alone (the single-episode call takes the two-stream small-batch path, the batch the one-stream path: row results
+    do not depend on the tile a row lands in), episode 0 is within the bf16 bound of the reference's logits, and the fp32 mode
+    at 16 episodes per step meets the 1e-3 tolerance against the reference golden."""
+    g = load_golden("cfg2_B16_5w1s_T8")
+    m = g["meta"]
+    a, sd, tt, te, ep0 = case_inputs(m)
+    eps = [ep0] + [case_inputs(m, episode=m["episode"] + e)[4] for e in range(1, 16)]
+    lb16, cb16 = run_engine(m, a, sd, tt, te, eps, "bf16")
+    assert maxdiff(lb16[0], g["logits"]) < 0.05
+    for i in (0, 5, 15):
+        l1, c1 = run_engine(m, a, sd, tt, te, [eps[i]], "bf16")
+        assert maxdiff(lb16[i], l1[0]) <= 1e-6, i
+        assert maxdiff(cb16[i], c1[0]) <= 1e-6, i
+    lf16, cf16 = run_engine(m, a, sd, tt, te, eps, "fp32")
+    assert maxdiff(lf16[0], g["logits"]) < 1e-3
+    assert maxdiff(cf16[0], g["class_logits"]) < 1e-3
+
+
+def test_cfg3_four_episodes_per_step():
+    """BASELINE config 3 (5-way 5-shot, MERGE_BEFORE) batched 4 episodes per step: episode 0 against the reference golden."""
+    g = load_golden("cfg3_B16_5w5s_T8_mb")
+    m = g["meta"]
+    a, sd, tt, te, ep0 = case_inputs(m)
+    eps = [ep0] + [case_inputs(m, episode=m["episode"] + e)[4] for e in range(1, 4)]
+    lf, cf = run_engine(m, a, sd, tt, te, eps, "fp32")
+    assert maxdiff(lf[0], g["logits"]) < 1e-3
+    assert maxdiff(cf[0], g["class_logits"]) < 1e-3
+    lb, _ = run_engine(m, a, sd, tt, te, eps, "bf16")
+    assert maxdiff(lb[0], g["logits"]) < 0.05
+    l1, _ = run_engine(m, a, sd, tt, te, [eps[2]], "bf16")
+    assert maxdiff(lb[2], l1[0]) <= 1e-6
+
+
 @pytest.mark.parametrize("name,tol_feat", [("cfg3_B16_5w5s_T8_mb", 2e-3), ("cfg4_L14_5w1s_T16", 4e-3),
                                            ("rn50_5w1s_T2", 2e-3)])
 def test_cfg3_cfg4_full_size(name, tol_feat):
