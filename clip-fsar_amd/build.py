@@ -63,7 +63,8 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
     os.makedirs(bdir, exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + (["-DCFSAR_DEV"] if dev else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        extra = os.environ.get("CFSAR_BUILD_DEFS", "").split() if dev else []      # developer A/B builds only
+        cmd = [HIPCC] + FLAGS + (["-DCFSAR_DEV"] if dev else []) + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

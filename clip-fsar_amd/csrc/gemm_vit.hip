@@ -221,6 +221,12 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
 //         The MFMAs run on the raw fp16 residual stream (TI = f16: same rate as bf16, 3 more mantissa bits); the accumulators
 //         start at d_n * std_m, one extra MFMA per 32x32 tile adds the rank-1 term -mean_m c_n (operands split into fp16
 //         hi + lo parts: ~22 bits), and the epilogue multiplies the row by 1 / std_m.
+#ifdef CFSAR_EARLY_STATS          // A/B only (build.py --dev with CFSAR_BUILD_DEFS=-DCFSAR_EARLY_STATS): prefetch the statistics before the epilogue
+constexpr bool kLateStats = false;
+#else
+constexpr bool kLateStats = true;
+#endif
+
 template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE>
 __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     constexpr bool HAS_RES = MODE == 1;
@@ -291,7 +297,12 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bnext[ni][g] = *reinterpret_cast<const float4*>(p.bias + nb_ + ni * 32 + 8 * g + 4 * hi);
+    };
+    // LNFOLD: row statistics and c of the tile.  Loaded AFTER the epilogue (kLateStats): 18 fewer registers live across it.
+    auto load_stats = [&](int m0_, int n0_) __attribute__((always_inline)) {
         if constexpr (LNFOLD) {
+            int nb_ = n0_ + wn * 64;
+            nb_ = nb_ + 64 <= p.N ? nb_ : p.N - 64;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 int m = m0_ + wm * 128 + mi * 32 + lr;
@@ -408,6 +419,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     unsigned offX[4], offW[4];
     offsets(m0, n0, offX, offW);
     load_bias(m0, n0);
+    load_stats(m0, n0);
     // ---- pipeline fill for the first output tile of this workgroup
     if constexpr (OPATH == 0) {
         static_for<4>([&](auto J) { gloadX(offX, 0, J); });
@@ -481,6 +493,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, F_{});           // K tile 0 of the next tile
         }
         load_bias(m0n, n0n);                                             // lands during the epilogue
+        if constexpr (!kLateStats) load_stats(m0n, n0n);
 #ifdef CFSAR_DEV
         if (p.dbg & 4) {                                                // ablation: no epilogue (keep the accumulators live)
             if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[3][1][2] + acc[2][0][1];
@@ -496,6 +509,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         b = bn;
         m0 = m0n;
         n0 = n0n;
+        if constexpr (kLateStats) load_stats(m0, n0);
     }
 }
 

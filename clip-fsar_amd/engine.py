@@ -100,6 +100,7 @@ class HipViT:
                     blk["c_" + tag] = Wg.double().sum(1).float().contiguous()          # of the ROUNDED folded weights
                     blk["d_" + tag] = (W.double() @ beta.double() + g(b + bname).double()).float().contiguous()
         self._slots = {}
+        self.max_frames_32bit = (2 ** 32 - 1) // (self.ntok * 4 * self.D * 2) - 1
 
     # ------------------------------------------------------------------ workspace (caller-owned device buffers)
     def _workspace(self, F_, slot=0):
@@ -440,7 +441,10 @@ class ClipFsarEngine:
             device=self.dev, dtype=torch.float32).contiguous()
         self.text_train, self.text_test = f32(text_train), f32(text_test)
         self.scale = f32(head_sd["scale"])
-        self.max_frames = max_frames
+        # frames per tower launch: the kernels address an activation matrix with 32-bit byte offsets, the widest one is the MLP
+        # hidden [F * tokens, 4 D] in 2 bytes (ViT-B/16: 3 548 frames); larger episode batches run the tower in chunks
+        limit = getattr(self.vit, "max_frames_32bit", None)
+        self.max_frames = min(max_frames, limit) if limit else max_frames
         # Small batches (one or two episodes): the support and the query frames go through the tower as two concurrent forwards
         # on two HIP streams.  A single 80-frame GEMM is 2.2 rounds of 256x256 tiles on 256 CUs (a third round that is 18 %
         # full); with two independent kernel chains the tail of one chain's kernel is filled by the other chain's next kernel.

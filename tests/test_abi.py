@@ -104,10 +104,12 @@ def test_hot_kernels_use_no_scratch():
     assert len(usage) > 40, len(usage)
     hot = {  # substring of the mangled name -> max scratch bytes per lane
         "vit_attn_bf16_kernelILi7ELi13E": 0, "vit_attn_bf16_kernelILi9ELi17E": 96, "layernorm_kernel": 0,
-        # the persistent ViT GEMM (gemm_vit.hip): LDS-DMA instances of QKV / out_proj keep everything in registers; the QuickGELU and
-        # LN-folded epilogues and the register-staged long-K instance spill a few epilogue / tile-boundary values (never in the K loop)
+        # the persistent ViT GEMM (gemm_vit.hip): the LDS-DMA instances keep (nearly) everything in registers -- an LN-folded build
+        # with 12 spilled registers returned stale lanes under a concurrent second stream (tests/test_gpu_kernels.py::
+        # test_vit_gemms_are_bit_stable_under_a_second_stream), so these limits are tight on purpose; the register-staged long-K
+        # instance (c_proj) spills tile-boundary values (never in the K loop)
         "vit_gemm_kernelIDF16bDF16bLi0ELi0ELi1E": 0, "vit_gemm_kernelIDF16bDF16_Li0ELi1ELi1E": 16,
-        "vit_gemm_kernelIDF16_DF16bLi0ELi2ELi1E": 96, "vit_gemm_kernelIDF16_DF16bLi1ELi2ELi1E": 96,
+        "vit_gemm_kernelIDF16_DF16bLi0ELi2ELi1E": 24, "vit_gemm_kernelIDF16_DF16bLi1ELi2ELi1E": 0,
         "vit_gemm_kernelIDF16bDF16_Li0ELi1ELi0E": 256,
         # p12 (QKV, c_fc, out_proj / c_proj): a few loop-invariant epilogue scalars are spilled at kernel entry and reloaded
         # after the K loop (checked in the ISA: nothing inside the main loop); a main-loop spill would be hundreds of bytes

@@ -121,8 +121,10 @@ def test_timed_configuration_b16_equals_b1_and_golden():
     assert maxdiff(lb16[0], g["logits"]) < 0.05
     for i in (0, 5, 15):
         l1, c1 = run_engine(m, a, sd, tt, te, [eps[i]], "bf16")
-        assert maxdiff(lb16[i], l1[0]) <= 1e-6, i
-        assert maxdiff(cb16[i], c1[0]) <= 1e-6, i
+        # the ViT tower is bit-identical at any batch size; the fp32 tail picks its GEMM kernel by row count (skinny FMA kernel for
+        # one episode, MFMA kernel for 16): a different fp32 summation order = a few ulps of a logit of magnitude ~10
+        assert maxdiff(lb16[i], l1[0]) <= 4e-6, i
+        assert maxdiff(cb16[i], c1[0]) <= 4e-6, i
     lf16, cf16 = run_engine(m, a, sd, tt, te, eps, "fp32")
     assert maxdiff(lf16[0], g["logits"]) < 1e-3
     assert maxdiff(cf16[0], g["class_logits"]) < 1e-3
@@ -140,7 +142,7 @@ def test_cfg3_four_episodes_per_step():
     lb, _ = run_engine(m, a, sd, tt, te, eps, "bf16")
     assert maxdiff(lb[0], g["logits"]) < 0.05
     l1, _ = run_engine(m, a, sd, tt, te, [eps[2]], "bf16")
-    assert maxdiff(lb[2], l1[0]) <= 1e-6
+    assert maxdiff(lb[2], l1[0]) <= 4e-6
 
 
 @pytest.mark.parametrize("name,tol_feat", [("cfg3_B16_5w5s_T8_mb", 2e-3), ("cfg4_L14_5w1s_T16", 4e-3),

@@ -561,3 +561,59 @@ def test_gemm_residual_stats_and_finalize(hip, M, N, K):
     x2 = x0.clone()
     hip.gemm_residual_stats(A, W, x2, bias, None)                    # statistics are optional
     assert torch.equal(x2, x)
+
+
+# ------------------------------------------------------------------------------------------------ two concurrent streams
+def test_vit_gemms_are_bit_stable_under_a_second_stream(hip):
+    """The single-episode path runs the support and the query frames as two concurrent forwards on two HIP streams
+    (engine.py: ClipFsarEngine.dual_frames).  Every ViT-block GEMM must give bit-identical results whether or not a second
+    instance shares the chip.  Regression test for a fault seen in round 2: an LN-folded QKV kernel build with 12 spilled
+    registers returned stale values in lanes 48-63 of single accumulator registers about once per 100 concurrent launches
+    (never alone); the build without those spills does not (tools/stream_stress.py is the long version of this test)."""
+    F_, N, D = 40, 197, 768
+    M = F_ * N
+
+    def make(seed):
+        x16 = (_rand(M, D, seed=seed) * 1.5 + 0.3).to(torch.float16).cuda()
+        rstat = torch.empty(M, 4, device="cuda")
+        hip.row_stats(x16, rstat, M, D)
+        Wq = _rand(3 * D, D, seed=seed + 1, scale=D ** -0.5).to(torch.float16).cuda()
+        Wf = _rand(4 * D, D, seed=seed + 2, scale=D ** -0.5).to(torch.float16).cuda()
+        cq, dq, cf, df = (_rand(n, seed=seed + 3 + i).cuda() for i, n in enumerate((3 * D, 3 * D, 4 * D, 4 * D)))
+        qkv = torch.empty(M, 3 * D, device="cuda", dtype=torch.bfloat16)
+        u = torch.empty(M, 4 * D, device="cuda", dtype=torch.bfloat16)
+        o = _rand(M, D, seed=seed + 8).to(torch.bfloat16).cuda()
+        Wo = _rand(D, D, seed=seed + 9, scale=D ** -0.5).to(torch.bfloat16).cuda()
+        Wp = _rand(D, 4 * D, seed=seed + 10, scale=(4 * D) ** -0.5).to(torch.bfloat16).cuda()
+        uin = _rand(M, 4 * D, seed=seed + 11).to(torch.bfloat16).cuda()
+        bo = _rand(D, seed=seed + 12).cuda()
+        x0 = _rand(M, D, seed=seed + 13).to(torch.float16).cuda()
+        xa, xb = x0.clone(), x0.clone()
+        pa, pb = torch.empty(M, D // 64, 2, device="cuda"), torch.empty(M, D // 64, 2, device="cuda")
+
+        def run():
+            hip.gemm_lnfold(x16, Wq, qkv, cq, dq, rstat, M=M)
+            hip.gemm_lnfold(x16, Wf, u, cf, df, rstat, act=hip.ACT_QUICKGELU, M=M)
+            xa.copy_(x0)
+            hip.gemm_residual_stats(o, Wo, xa, bo, pa, M=M)
+            xb.copy_(x0)
+            hip.gemm_residual_stats(uin, Wp, xb, bo, pb, M=M)
+        return run, lambda: [qkv, u, xa, pa, xb, pb]
+
+    runs = [make(100), make(200)]
+    refs = []
+    for run, outs in runs:
+        run()
+        torch.cuda.synchronize()
+        refs.append([t.clone() for t in outs()])
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for it in range(12):
+        torch.cuda.synchronize()
+        for st, (run, _) in zip(streams, runs):
+            with torch.cuda.stream(st):
+                run()
+                run()
+        torch.cuda.synchronize()
+        for (run, outs), ref in zip(runs, refs):
+            for name, t, r in zip(("qkv", "c_fc", "x_out", "part_out", "x_proj", "part_proj"), outs(), ref):
+                assert torch.equal(t, r), (it, name, float((t.float() - r.float()).abs().max()))
