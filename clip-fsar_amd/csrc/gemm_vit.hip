@@ -227,10 +227,23 @@ constexpr bool kLateStats = false;
 constexpr bool kLateStats = true;
 #endif
 
+// The same for the bias vector.  Same-box A/B at 16 episodes per step (tools/r02_ab_builds.sh, episodes/s): both prefetched before the
+// epilogue 296 (r02 start) | statistics late 299.9 | + bias late for the register-staged c_proj instance (44 -> 26 spills) 304.9 |
+// bias late everywhere 305.7.  The loads are L2 hits issued right after the epilogue's stores; what they cost in exposed latency
+// is less than what the spills of the prefetched copies cost.
+#if defined(CFSAR_LATE_BIAS_NONE)         // A/B builds only (build.py --dev, CFSAR_BUILD_DEFS)
+#define CFSAR_LATE_BIAS(MODE, OPATH) false
+#elif defined(CFSAR_LATE_BIAS_CPROJ)
+#define CFSAR_LATE_BIAS(MODE, OPATH) ((MODE) == 1 && (OPATH) == 0)
+#else
+#define CFSAR_LATE_BIAS(MODE, OPATH) true
+#endif
+
 template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE>
 __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     constexpr bool HAS_RES = MODE == 1;
     constexpr bool LNFOLD = MODE == 2;
+    constexpr bool kLateBias = CFSAR_LATE_BIAS(MODE, OPATH);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -453,6 +466,11 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                     acc[i][j][4 * g + 2] = bnext[j][g].z * sc;
                     acc[i][j][4 * g + 3] = bnext[j][g].w * sc;
                 }
+#if defined(CFSAR_X1)
+        __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_nop(7); __builtin_amdgcn_s_nop(7); __builtin_amdgcn_sched_barrier(0);
+#elif defined(CFSAR_X3)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if constexpr (LNFOLD) {
             // rank-1 term  acc[n][m] -= c_n mean_m  as ONE MFMA per 32x32 tile: k slots 0..2 of the lanes with hi == 0 carry
             // (c_hi, c_hi, c_lo) x (-mean_hi, -mean_lo, -mean_hi); every other k slot is zero
@@ -474,8 +492,17 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
+#ifndef CFSAR_X4
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cw[ni], mx[mi], acc[mi][ni], 0, 0, 0);
+#else
+                    acc[mi][ni][0] += (float)cw[ni][0] * (float)mx[mi][0];
+#endif
         }
+#if defined(CFSAR_X2)
+        __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_nop(7); __builtin_amdgcn_s_nop(7); __builtin_amdgcn_sched_barrier(0);
+#elif defined(CFSAR_X3)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         static_for<6>([&](auto J) { load_one(sb, 0, J, xfA, wfA); });
         int kt = 0;
         // The tail steps ALWAYS prefetch (one straight-line MFMA stream: a fork on has_next would merge two 128-register
@@ -492,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             offsets(m0n, n0n, offX, offW);
             step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, F_{});           // K tile 0 of the next tile
         }
-        load_bias(m0n, n0n);                                             // lands during the epilogue
+        if constexpr (!kLateBias) load_bias(m0n, n0n);                   // lands during the epilogue
         if constexpr (!kLateStats) load_stats(m0n, n0n);
 #ifdef CFSAR_DEV
         if (p.dbg & 4) {                                                // ablation: no epilogue (keep the accumulators live)
@@ -509,6 +536,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         b = bn;
         m0 = m0n;
         n0 = n0n;
+        if constexpr (kLateBias) load_bias(m0, n0);
         if constexpr (kLateStats) load_stats(m0, n0);
     }
 }
