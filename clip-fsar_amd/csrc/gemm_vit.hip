@@ -61,25 +61,24 @@ __device__ __forceinline__ void glds16_asm(const char* src, unsigned lds_addr) {
         : "memory");
 }
 
-// x * sigmoid(1.702 x) for four values, few_shot.py:614-616.
-// The empty asm statement is a WORKAROUND for a fault seen on MI355X / ROCm 7.2 with the straightforward form
-// `v * rcp(1 + exp2(k v))` in the LN-folded c_fc instance of this kernel: exact zeros in lanes 48-63 of single accumulator
-// registers (~1 % of the tiles, timing dependent, all operand paths and store policies; value dump: tools/dbg_lnfold.py).  In the
-// faulty code hipcc had recycled the source register of a transcendental in the very next instruction
-// ("v_rcp_f32 v228, v163 ; v_add_f32 v163, 1.0, v175") inside a dense run of v_exp / v_rcp / v_pk_mul_f32.  Pinning the
-// transcendental inputs and the products as operands of one statement (no instruction is emitted) changes the allocation so that
-// no input is rewritten before its product exists, and the fault is gone (tests/test_gpu_kernels.py::test_gemm_lnfold_*, the
-// sizes that exposed it).  The root cause is NOT isolated: tools/ubench/trans_war.hip replays the instruction shapes alone and
-// does not reproduce it.
+// x * sigmoid(1.702 x) for four values, few_shot.py:614-616: v_exp_f32 + v_rcp_f32 (1 ulp each).
+//
+// History of a fault (round 2), kept here because this function was its first victim.  Builds of the LN-folded instances of this
+// kernel that contained packed-fp32 VALU instructions -- v_pk_mul_f32 for the 1 / std row scale in front of this function and for the
+// accumulator initialisation d x std -- occasionally produced wrong values in lanes 48-63 of the HIGH register of ONE packed pair: here
+// as exact zeros of the c_fc output (a stale, huge scaled input -> 2^z = inf -> rcp = 0), in the QKV instance as a missing d x std.
+// Rate: up to 13 % of the tiles in one build, once per ~100 launches in another and only with a second kernel on the chip; barriers or
+// nops next to the affected code made it MORE frequent, other schedules hid it.  The stand-alone replays in tools/ubench/ (trans_war,
+// valu_vmem_hazard, pk_mfma_hazard, pk_under_mfma) do not reproduce it and no spill is involved (it also hit a build with no scratch
+// memory), so the root cause is NOT isolated.  What removes it in every build tried: compiling this file without packed-fp32
+// instructions (clip-fsar_amd/build.py SOURCE_FLAGS; 0 of 1 500 stress launches against 44 of 150, same speed).  An earlier workaround
+// (pinning the transcendental operands with empty asm statements) is no longer needed and was removed.  Guards:
+// tests/test_gpu_kernels.py::test_gemm_lnfold_* and ::test_vit_gemms_are_bit_stable_under_a_second_stream, tools/stream_stress.py.
 __device__ __forceinline__ void quick_gelu4(float (&v)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float z = -1.702f * 1.4426950408889634f * v[j];
-        float d = 1.0f + __builtin_amdgcn_exp2f(z);
-        asm volatile("" : "+v"(d) : "v"(z));          // z stays intact until 1 + 2^z exists
-        float o = v[j] * __builtin_amdgcn_rcpf(d);
-        asm volatile("" : "+v"(o) : "v"(d));          // d stays intact until v / d exists
-        v[j] = o;
+        v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
     }
 }
 
@@ -466,11 +465,6 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                     acc[i][j][4 * g + 2] = bnext[j][g].z * sc;
                     acc[i][j][4 * g + 3] = bnext[j][g].w * sc;
                 }
-#if defined(CFSAR_X1)
-        __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_nop(7); __builtin_amdgcn_s_nop(7); __builtin_amdgcn_sched_barrier(0);
-#elif defined(CFSAR_X3)
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         if constexpr (LNFOLD) {
             // rank-1 term  acc[n][m] -= c_n mean_m  as ONE MFMA per 32x32 tile: k slots 0..2 of the lanes with hi == 0 carry
             // (c_hi, c_hi, c_lo) x (-mean_hi, -mean_lo, -mean_hi); every other k slot is zero
@@ -492,17 +486,8 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-#ifndef CFSAR_X4
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cw[ni], mx[mi], acc[mi][ni], 0, 0, 0);
-#else
-                    acc[mi][ni][0] += (float)cw[ni][0] * (float)mx[mi][0];
-#endif
         }
-#if defined(CFSAR_X2)
-        __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_nop(7); __builtin_amdgcn_s_nop(7); __builtin_amdgcn_sched_barrier(0);
-#elif defined(CFSAR_X3)
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         static_for<6>([&](auto J) { load_one(sb, 0, J, xfA, wfA); });
         int kt = 0;
         // The tail steps ALWAYS prefetch (one straight-line MFMA stream: a fork on has_next would merge two 128-register

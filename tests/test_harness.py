@@ -223,3 +223,64 @@ def test_build_loader_refuses_real_datasets_without_data(tmp_path):
     cfg.TEST.DATASET = "Ssv2_few_shot"
     with pytest.raises((FileNotFoundError, ValueError, KeyError)):
         build_loader(cfg, "test")
+
+
+@gpu
+@needs_gpu
+@pytest.mark.parametrize("eps_per_step", [1, 3])
+def test_real_data_pipeline_through_the_harness(tmp_path, eps_per_step):
+    """N2 end to end: split list -> Ssv2_few_shot (stub decoder, HIP frame transform) -> build_loader -> test_few_shot with the real
+    head.  The CPU oracle runs on the SAME episodes (TEST.EPISODE_SEED makes episode i a function of i; host transform)."""
+    import json
+    import clipfsar_oracle as orc
+    import make_golden_n2 as g2
+    from clip_fsar_amd.datasets.base import ssv2_few_shot as n2
+    from clip_fsar_amd.runs.test_net_few_shot import test_few_shot
+
+    class Reader:
+        def __init__(self, path):
+            self.path = path
+            self.length, self.fps, _, _ = g2.video_meta(path)
+
+        def __len__(self):
+            return self.length
+
+        def get_avg_fps(self):
+            return self.fps
+
+        def get_batch(self, idx):
+            return torch.from_numpy(g2.video_frames(self.path, idx))
+
+    a = synth.ARCHS[ARCH]
+    lines = g2.synth_split_list("path", N_TEST, 4, seed=5)            # class ids 0 .. N_TEST-1 index TEST.CLASS_NAME
+    (tmp_path / "test_few_shot.txt").write_text("\n".join(lines) + "\n")
+    n = 6
+
+    def cfg_for(use_gpu):
+        cfg = _cfg(n, eps_per_step)
+        cfg.TEST.DATASET = "Ssv2_few_shot"
+        cfg.TEST.EPISODE_SEED = 77
+        cfg.TEST.NUM_ENSEMBLE_VIEWS, cfg.TEST.NUM_SPATIAL_CROPS = 1, 1
+        cfg.TRAIN.DATASET_FEW, cfg.TRAIN.META_BATCH, cfg.TRAIN.QUERY_PER_CLASS_TEST = "Kinetics_few_shot", True, 1
+        cfg.DATA = NS(NUM_INPUT_FRAMES=T, TEST_CROP_SIZE=a["res"], TEST_SCALE=a["res"] + 8, DATA_ROOT_DIR="/data/root", ANNO_DIR=str(tmp_path),
+                      SAMPLING_RATE=50, TARGET_FPS=12, SAMPLING_MODE="interval_based", MEAN=list(synth.CLIP_MEAN), STD=list(synth.CLIP_STD),
+                      DECODER=Reader)
+        cfg.AUGMENTATION = NS(USE_GPU=use_gpu)
+        return cfg
+
+    res = test_few_shot(cfg_for(True))
+    assert res["episodes"] == n
+    ds = n2.Ssv2_few_shot(cfg_for(False), "test")
+    sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(ARCH, 18).items()}
+    tt = torch.from_numpy(synth.text_features(N_TRAIN, a["embed"], "train", 18))
+    te = torch.from_numpy(synth.text_features(N_TEST, a["embed"], "test", 18))
+    accs, losses = [], []
+    with torch.no_grad():
+        for e in range(n):
+            ep = ds[e]
+            lg = orc.head_forward(ep, sd, tt, te, a, frames=T)["logits"]
+            lab = ep["target_labels"].long()
+            accs.append(float((lg.argmax(1) == lab).float().mean()) * 100.0)
+            losses.append(float(F.cross_entropy(lg, lab)))
+    assert abs(res["top1_acc"] - float(np.mean(accs))) < 1e-4, (res["top1_acc"], float(np.mean(accs)))
+    assert abs(res["loss"] - float(np.mean(losses))) < 2e-3, (res["loss"], float(np.mean(losses)))

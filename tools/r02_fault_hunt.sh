@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: rebuild the developer library with one experiment macro at a time and run the two-stream stress on the LN-folded QKV GEMM
+# GPU box: rebuild the developer library with one extra compile flag / define at a time (e.g. "-DCFSAR_PACKED_FP32" = with packed-fp32 ops) and run the two-stream stress on the LN-folded QKV GEMM
 for defs in "$@"; do
   d="$defs"; [ "$d" = "-" ] && d=""
   CFSAR_BUILD_DEFS="$d" python clip-fsar_amd/build.py --dev --force > /dev/null 2>&1
