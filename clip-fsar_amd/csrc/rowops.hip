@@ -39,6 +39,31 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ f
     }
 }
 
+// P = 16 (ViT-B/16), bf16 rows: one thread moves one image-row segment of a patch, 16 floats (four 16-byte loads = one 64-byte
+// sector) -> 16 bf16 (two 16-byte stores).  Lane = dy + 16 * (patch within a group of 4): 16 consecutive lanes write 512 contiguous
+// bytes of one output row, a wave instruction writes 4 x 512 B and reads 64 whole 64-byte sectors.  No division in the inner path
+// (grid.y = frame x channel, grid.x walks patches).  2.85 -> ~5 TB/s on 1 280 frames.
+__global__ __launch_bounds__(256) void im2col_p16_bf16_kernel(const float* __restrict__ frames, __bf16* __restrict__ out, int H, int W,
+                                                              int k_pad) {
+    const int gw = W >> 4, gh = H >> 4, npatch = gw * gh;
+    const int fc = blockIdx.y;                       // frame * 3 + channel
+    const int f = fc / 3, c = fc - 3 * f;
+    const int dy = threadIdx.x & 15;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= npatch) return;
+    const int py = p / gw, px = p - py * gw;
+    const float4* src = reinterpret_cast<const float4*>(frames + ((size_t)fc * H + (py * 16 + dy)) * W + px * 16);
+    const float4 a = src[0], b = src[1], c4 = src[2], d = src[3];
+    bf16x8 lo, hi8;
+    lo[0] = (__bf16)a.x; lo[1] = (__bf16)a.y; lo[2] = (__bf16)a.z; lo[3] = (__bf16)a.w;
+    lo[4] = (__bf16)b.x; lo[5] = (__bf16)b.y; lo[6] = (__bf16)b.z; lo[7] = (__bf16)b.w;
+    hi8[0] = (__bf16)c4.x; hi8[1] = (__bf16)c4.y; hi8[2] = (__bf16)c4.z; hi8[3] = (__bf16)c4.w;
+    hi8[4] = (__bf16)d.x; hi8[5] = (__bf16)d.y; hi8[6] = (__bf16)d.z; hi8[7] = (__bf16)d.w;
+    __bf16* dst = out + ((size_t)f * npatch + p) * k_pad + c * 256 + dy * 16;
+    *reinterpret_cast<bf16x8*>(dst) = lo;
+    *reinterpret_cast<bf16x8*>(dst + 8) = hi8;
+}
+
 template <typename TX>
 __global__ __launch_bounds__(256) void cls_rows_kernel(TX* __restrict__ x, const float* __restrict__ cls,
                                                        const float* __restrict__ pos, int F, int ntok, int D) {
@@ -379,6 +404,12 @@ extern "C" int cfsar_im2col_patches(const float* frames, void* out, int out_dtyp
     long long blocks = (pairs + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dtype == CFSAR_BF16 && P == 16 && k_pad == 768 && W % 16 == 0 && (long long)F * 3 <= 65535) {
+        const int npatch = (H / 16) * (W / 16);
+        hipLaunchKernelGGL(im2col_p16_bf16_kernel, dim3((unsigned)((npatch + 15) / 16), (unsigned)(F * 3)), dim3(256), 0, s, frames,
+                           static_cast<__bf16*>(out), H, W, k_pad);
+        return cfsar_check_launch("cfsar_im2col_patches");
+    }
     if (out_dtype == CFSAR_BF16)
         hipLaunchKernelGGL((im2col_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, s, frames,
                            static_cast<__bf16*>(out), F, H, W, P, k_pad, pairs);
