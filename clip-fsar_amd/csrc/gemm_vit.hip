@@ -82,6 +82,18 @@ __device__ __forceinline__ void quick_gelu4(float (&v)[4]) {
     }
 }
 
+// sum over each aligned group of 8 consecutive lanes, result in all 8: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_sum8(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    return v;
+}
+
 // 16-byte global store with a cache policy: 0 = default (write-back, line stays in this XCD's L2), 1 = nt, 2 = sc1
 // (write-through: the line is not kept, MI355X_MICROARCH.md "stores of each flavour")
 template <int POLICY>
@@ -195,11 +207,10 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
                         ps += f;
                         pq = fmaf(f, f, pq);
                     }
-#pragma unroll
-                    for (int o = 1; o < 8; o <<= 1) {        // the 8 lanes Q = 0..7 of a row are consecutive
-                        ps += __shfl_xor(ps, o, 64);
-                        pq += __shfl_xor(pq, o, 64);
-                    }
+                    // the 8 lanes Q = 0..7 of a row are consecutive: quad butterflies + half-row mirror as DPP VALU ops (a
+                    // __shfl_xor is a ds_bpermute round trip through the LDS pipe: 96 dependent ones per tile before this)
+                    ps = dpp_sum8(ps);
+                    pq = dpp_sum8(pq);
                     if (Q == 0 && (FULL || (rowok[it] && colok)))
                         *reinterpret_cast<float2*>(p.stats_out + ((size_t)(mb + rr + (mi * 4 + it) * 8) * p.stats_slots + (nb >> 6)) * 2) =
                             make_float2(ps, pq);
