@@ -229,8 +229,8 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
 //         with W' = W diag(gamma) (fp16, folded at init), c_n = sum_k W'_nk, d_n = sum_k beta_k W_nk + bias_n and the row's
 //         (mean, std):   LN(x) W^T + bias = (x W'^T - mean c) / std + d.
 //         The MFMAs run on the raw fp16 residual stream (TI = f16: same rate as bf16, 3 more mantissa bits); the accumulators
-//         start at d_n * std_m, one extra MFMA per 32x32 tile adds the rank-1 term -mean_m c_n (operands split into fp16
-//         hi + lo parts: ~22 bits), and the epilogue multiplies the row by 1 / std_m.
+//         start at d_n * std_m - mean_m c_n, produced by ONE extra MFMA per 32x32 tile (a rank-2 outer product, operands split
+//         into fp16 hi + lo parts: ~22 bits), and the epilogue multiplies the row by 1 / std_m.
 #ifdef CFSAR_EARLY_STATS          // A/B only (build.py --dev with CFSAR_BUILD_DEFS=-DCFSAR_EARLY_STATS): prefetch the statistics before the epilogue
 constexpr bool kLateStats = false;
 #else
@@ -314,6 +314,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     float cn[LNFOLD ? 2 : 1];            // LNFOLD: c of columns 32 ni + lr
     float rscale[4] = {1.f, 1.f, 1.f, 1.f};
     auto load_bias = [&](int m0_, int n0_) __attribute__((always_inline)) {
+        if constexpr (LNFOLD) return;                     // the LN-folded instance gets d through load_stats (see the initialisation)
         int nb_ = n0_ + wn * 64;
         nb_ = nb_ + 64 <= p.N ? nb_ : p.N - 64;
 #pragma unroll
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                 rsn[mi] = *reinterpret_cast<const float4*>(p.rowstats + (size_t)m * 4);
             }
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) cn[ni] = p.cvec[nb_ + ni * 32 + lr];
+            for (int ni = 0; ni < 2; ++ni) cn[ni] = (hi ? p.bias : p.cvec)[nb_ + ni * 32 + lr];     // d for the k = 8.. lanes, c for k = 0..
         }
     };
     u32x4 GX[4], GW[4];
@@ -464,40 +465,42 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         const bool has_next = bn < nt;
         int m0n = m0, n0n = n0;
         if (has_next) origin(bn, m0n, n0n);
+        if constexpr (!LNFOLD) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float sc = LNFOLD ? rsn[LNFOLD ? i : 0].y : 1.0f;      // std of row 32 i + lr
-                    acc[i][j][4 * g] = bnext[j][g].x * sc;
-                    acc[i][j][4 * g + 1] = bnext[j][g].y * sc;
-                    acc[i][j][4 * g + 2] = bnext[j][g].z * sc;
-                    acc[i][j][4 * g + 3] = bnext[j][g].w * sc;
-                }
-        if constexpr (LNFOLD) {
-            // rank-1 term  acc[n][m] -= c_n mean_m  as ONE MFMA per 32x32 tile: k slots 0..2 of the lanes with hi == 0 carry
-            // (c_hi, c_hi, c_lo) x (-mean_hi, -mean_lo, -mean_hi); every other k slot is zero
+                    for (int g = 0; g < 4; ++g) {
+                        acc[i][j][4 * g] = bnext[j][g].x;
+                        acc[i][j][4 * g + 1] = bnext[j][g].y;
+                        acc[i][j][4 * g + 2] = bnext[j][g].z;
+                        acc[i][j][4 * g + 3] = bnext[j][g].w;
+                    }
+        } else {
+            // The accumulators start at  d_n std_m - c_n mean_m : a rank-2 outer product, i.e. ONE MFMA per 32x32 tile with C = 0.
+            // k slots 0..2 of the lanes with hi == 0 carry (c_hi, c_hi, c_lo) x (-mean_hi, -mean_lo, -mean_hi), the same slots of
+            // the lanes with hi == 1 (k = 8..10) carry (d_hi, d_hi, d_lo) x (std_hi, std_lo, std_hi): both factors split into fp16
+            // hi + lo parts (~22 bits); every other k slot is zero.  No VALU initialisation, no per-lane bias vector.
             f16x8 cw[2], mx[4];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
+            for (int ni = 0; ni < 2; ++ni) {                 // cn = c (hi == 0) or d (hi == 1) of column 32 ni + lr: load_stats
                 const _Float16 h = (_Float16)cn[ni], l = (_Float16)(cn[ni] - (float)h);
                 cw[ni] = f16x8{h, h, l, 0, 0, 0, 0, 0};
-                if (hi) cw[ni] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                const float nm = -rsn[mi].x;
+                const float nm = hi ? rsn[mi].y : -rsn[mi].x;
                 const _Float16 h = (_Float16)nm, l = (_Float16)(nm - (float)h);
                 mx[mi] = f16x8{h, l, h, 0, 0, 0, 0, 0};
                 rscale[mi] = rsn[mi].z;
             }
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cw[ni], mx[mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cw[ni], mx[mi], zero, 0, 0, 0);
         }
         static_for<6>([&](auto J) { load_one(sb, 0, J, xfA, wfA); });
         int kt = 0;

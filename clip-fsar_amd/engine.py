@@ -99,6 +99,15 @@ class HipViT:
                     blk["wg_" + tag] = Wg
                     blk["c_" + tag] = Wg.double().sum(1).float().contiguous()          # of the ROUNDED folded weights
                     blk["d_" + tag] = (W.double() @ beta.double() + g(b + bname).double()).float().contiguous()
+            # the kernel feeds c, d, mean and std to the matrix pipe as fp16 hi + lo pairs and the folded weights as fp16: a checkpoint
+            # whose folded quantities leave the fp16 range cannot use the folded block (CLIP's are O(1) ... O(10))
+            big = max(float(max(blk[k].abs().max() for k in ("c_qkv", "d_qkv", "c_fc", "d_fc"))) for blk in self.blocks)
+            wmax = max(float(max(blk[k].float().abs().max() for k in ("wg_qkv", "wg_fc"))) for blk in self.blocks)
+            if not (big < 3.0e4 and wmax < 6.0e4):
+                import warnings
+                warnings.warn("LayerNorm folding disabled: folded weights / vectors exceed the fp16 range (max |c|,|d| = %.3g, "
+                              "max |W gamma| = %.3g); using the unfolded block" % (big, wmax))
+                self.fold = False
         self._slots = {}
         self.max_frames_32bit = (2 ** 32 - 1) // (self.ntok * 4 * self.D * 2) - 1
 
