@@ -536,6 +536,9 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
         if (ntok == 197 && g_attn_variant == 2) return launch_bf16<7, 13, 5, 4>(qkv, out, F, ntok, D, heads, s);   // 3 workgroups x 5 waves
         if (ntok == 197 && g_attn_variant == 3) return launch_bf16<7, 13, 8, 4>(qkv, out, F, ntok, D, heads, s);   // 2 x 8 waves
         if (ntok == 197 && g_attn_variant == 4) return launch_bf16<7, 13, 13, 4>(qkv, out, F, ntok, D, heads, s);  // one tile per wave
+        if (ntok == 197 && g_attn_variant == 10) return launch_bf16<7, 13, 4, 3>(qkv, out, F, ntok, D, heads, s);  // 3 workgroups x 4 waves
+        if (ntok == 197 && g_attn_variant == 11) return launch_bf16<7, 13, 4, 2>(qkv, out, F, ntok, D, heads, s);  // (2-3) x 4 waves, 256 regs
+        if (ntok == 197 && g_attn_variant == 12) return launch_bf16<7, 13, 6, 4>(qkv, out, F, ntok, D, heads, s);  // 2 x 6 waves
 #endif
         if (ntok == 197) return launch_bf16<7, 13, 8, 4>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 257) return launch_bf16<9, 17, 8, 4>(qkv, out, F, ntok, D, heads, s);

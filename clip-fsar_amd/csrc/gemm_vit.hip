@@ -138,9 +138,9 @@ __device__ __forceinline__ void tile_of(int lin, int tiles_m, int tiles_n, int g
 // before the activation.  STATS (residual producer): per row, the sum and the sum of squares of the 64 STORED (rounded) values of
 // this wave are written to stats_out[row][slot = column / 64] -- the LayerNorm statistics of the next LN-folded GEMM come from
 // these partials (cfsar_ln_stats_finalize), so the residual stream is never re-read for them.
-template <typename TO, int ACT, bool HAS_RES, int STORE, bool FULL, bool ROWSCALE = false>
+template <typename TO, int ACT, bool HAS_RES, int STORE, bool FULL, bool ROWSCALE = false, bool PRE = false>
 __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemmArgs& p, int mb, int nb, int lane, char* slab,
-                                              const float (&rscale)[4]) {
+                                              const float (&rscale)[4], const u32x4 (&rv0)[4]) {
     typedef typename Vec2B<TO>::v4 TO4;
     typedef typename Vec2B<TO>::v8 TO8;
     const int lr = lane & 31, hi = lane >> 5;
@@ -155,19 +155,36 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
     char* outp = reinterpret_cast<char*>(p.out) + ((size_t)(mb + rr) * p.ldo + ncl + 8 * Q) * 2;
     const char* resp = HAS_RES ? reinterpret_cast<const char*>(p.res) + ((size_t)(mb + rr) * p.ldr + ncl + 8 * Q) * 2 : nullptr;
     const int rd0 = rr * 128 + ((Q ^ ((rr >> 1) & 7)) << 4);       // row rr + 8 it: + it * 1024, chunk ^ (4 it & 7) << 4
+    // residual rows: the loads of pass mi + 1 are issued before pass mi is processed, so no pass waits for its own loads (the stream
+    // is read exactly once: these are HBM / MALL latencies)
+    u32x4 rvn[4];
+    auto load_res = [&](int mi_) __attribute__((always_inline)) {
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int step = mi_ * 4 + it;
+                if (FULL || mb + rr + step * 8 < p.M) rvn[it] = *reinterpret_cast<const u32x4*>(resp + (size_t)step * rstep);
+                else rvn[it] = u32x4{0, 0, 0, 0};
+            }
+        }
+    };
+    // PRE: pass 0's rows come in from the caller, which issued their loads before the last K step of the tile (residual_prefetch)
+    if constexpr (PRE) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) rvn[it] = rv0[it];
+    } else {
+        load_res(0);
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         u32x4 rv[4];
         bool rowok[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int step = mi * 4 + it;
-            rowok[it] = FULL || mb + rr + step * 8 < p.M;
-            if constexpr (HAS_RES) {
-                if (FULL || rowok[it]) rv[it] = *reinterpret_cast<const u32x4*>(resp + (size_t)step * rstep);
-                else rv[it] = u32x4{0, 0, 0, 0};
-            }
+            rowok[it] = FULL || mb + rr + (mi * 4 + it) * 8 < p.M;
+            if constexpr (HAS_RES) rv[it] = rvn[it];
         }
+        if (mi < 3) load_res(mi + 1);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -520,6 +537,21 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         // The tail steps ALWAYS prefetch (one straight-line MFMA stream: a fork on has_next would merge two 128-register
         // accumulator sets through phi copies).  After the last output tile of this workgroup the "next" origin is the current
         // one, so the surplus loads re-read valid memory and the surplus LDS writes land in the free stage.
+        u32x4 rv0[4] = {};
+        // (LDS-DMA instance only: in the register-staged one 16 more live registers across the last K step cost 22-30 spills and 10 %)
+        auto residual_prefetch = [&]() __attribute__((always_inline)) {     // rows rr + 8 it of the wave's first 32-row pass
+            if constexpr (HAS_RES && OPATH == 1) {
+                const int mb_ = m0 + wm * 128, nb_ = n0 + wn * 64;
+                const int ncl_ = nb_ + 64 <= p.N ? nb_ : p.N - 64;
+                const int rr_ = lane >> 3, Q_ = lane & 7;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    int row = mb_ + rr_ + it * 8;
+                    row = row < p.M ? row : p.M - 1;                        // clamped: out-of-range rows are never stored
+                    rv0[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.res) + ((size_t)row * p.ldr + ncl_ + 8 * Q_) * 2);
+                }
+            }
+        };
         if constexpr (OPATH == 0) {
             for (; kt < nk - 2; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 2, T_{}, T_{}, T_{}, T_{});
             offsets(m0n, n0n, offX, offW);              // this tile's remaining K tiles are already in registers / LDS
@@ -529,6 +561,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         } else {
             for (; kt < nk - 1; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 1, T_{}, F_{}, T_{}, T_{});
             offsets(m0n, n0n, offX, offW);
+            residual_prefetch();
             step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, F_{});           // K tile 0 of the next tile
         }
         if constexpr (!kLateBias) load_bias(m0n, n0n);                   // lands during the epilogue
@@ -540,8 +573,8 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
 #endif
         {
             const int mb = m0 + wm * 128, nb = n0 + wn * 64;
-            if (mb + 128 <= p.M && nb + 64 <= p.N) epilogue_rows<TO, ACT, HAS_RES, STORE, true, LNFOLD>(acc, p, mb, nb, lane, slab, rscale);
-            else epilogue_rows<TO, ACT, HAS_RES, STORE, false, LNFOLD>(acc, p, mb, nb, lane, slab, rscale);
+            if (mb + 128 <= p.M && nb + 64 <= p.N) epilogue_rows<TO, ACT, HAS_RES, STORE, true, LNFOLD, HAS_RES && OPATH == 1>(acc, p, mb, nb, lane, slab, rscale, rv0);
+            else epilogue_rows<TO, ACT, HAS_RES, STORE, false, LNFOLD, HAS_RES && OPATH == 1>(acc, p, mb, nb, lane, slab, rscale, rv0);
         }
         if (!has_next) break;
         sb = (sb + nk) & 1;
