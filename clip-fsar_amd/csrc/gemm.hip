@@ -1461,6 +1461,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
         c.opath = K <= 1024 ? 1 : 0;
         c.store = residual ? 0 : 2;
         c.group = kVitGroup; c.colfast = kVitColfast; c.dbg = 0;
+        c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = 0;
 #ifdef CFSAR_DEV
         if (forced >= 20) { c.opath = (forced - 20) >> 2; c.store = (forced - 20) & 3; }
         c.dbg = g_dbg_override;

@@ -17,6 +17,11 @@ struct VitGemmArgs {          // kernel argument block
     int act;
     int tiles_n, ntiles;      // 256 x 256 output tiles
     int group, colfast;       // tile walk inside an XCD's range (see tile_of)
+    // head-blocked layouts (tokens per frame T >= 128; 0 = row-major).  hb_tokens / hb_heads: the LN-folded QKV instance writes
+    // out[((f H + h) T + t) * 192 + 64 which + c] for row m = f T + t, column n = 64 (which H + h) + c (which = q / k / v), i.e. 75 KB
+    // contiguous per (frame, head) -- what the attention kernel reads.  ha_tokens: the residual instance reads its A operand from
+    // A[((f H + h) T + t) * 64 + c] (K tile kt = head kt), the attention kernel's output in the same blocking.
+    int hb_tokens, hb_heads, ha_tokens;
 #ifdef CFSAR_DEV
     int dbg;                  // ablations: 4 = no epilogue, 8 = every workgroup reads tile (0, 0)
 #endif
@@ -36,6 +41,7 @@ struct VitGemmCall {          // host-side request
     int opath, store;         // operand path (0 register-staged, 1 LDS-DMA), store policy (0 default, 1 nt, 2 sc1; dev builds)
     int group, colfast;
     int dbg;
+    int hb_tokens, hb_heads, ha_tokens;
 };
 
 // 0 = launched, > 0 = error (cfsar_last_error), -2 = outside this kernel's contract (caller falls back)

@@ -138,7 +138,7 @@ __device__ __forceinline__ void tile_of(int lin, int tiles_m, int tiles_n, int g
 // before the activation.  STATS (residual producer): per row, the sum and the sum of squares of the 64 STORED (rounded) values of
 // this wave are written to stats_out[row][slot = column / 64] -- the LayerNorm statistics of the next LN-folded GEMM come from
 // these partials (cfsar_ln_stats_finalize), so the residual stream is never re-read for them.
-template <typename TO, int ACT, bool HAS_RES, int STORE, bool FULL, bool ROWSCALE = false, bool PRE = false>
+template <typename TO, int ACT, bool HAS_RES, int STORE, bool FULL, bool ROWSCALE = false, bool PRE = false, bool HB = false>
 __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemmArgs& p, int mb, int nb, int lane, char* slab,
                                               const float (&rscale)[4], const u32x4 (&rv0)[4]) {
     typedef typename Vec2B<TO>::v4 TO4;
@@ -155,6 +155,26 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
     char* outp = reinterpret_cast<char*>(p.out) + ((size_t)(mb + rr) * p.ldo + ncl + 8 * Q) * 2;
     const char* resp = HAS_RES ? reinterpret_cast<const char*>(p.res) + ((size_t)(mb + rr) * p.ldr + ncl + 8 * Q) * 2 : nullptr;
     const int rd0 = rr * 128 + ((Q ^ ((rr >> 1) & 7)) << 4);       // row rr + 8 it: + it * 1024, chunk ^ (4 it & 7) << 4
+    // HB: head-blocked output (see VitGemmArgs).  The wave's 64 columns are one (which, head) block; row mb + rr + 8 s is token
+    // t0 + 8 s of frame f0, wrapping into the next frame at most once (T >= 128 > 8 * 15).
+    int hb_f0 = 0, hb_t0 = 0;
+    size_t hb_col = 0;
+    if constexpr (HB) {
+        const int row0 = mb + rr;
+        hb_f0 = row0 / p.hb_tokens;
+        hb_t0 = row0 - hb_f0 * p.hb_tokens;
+        const int blk = ncl >> 6, which = blk / p.hb_heads, h = blk - which * p.hb_heads;
+        hb_col = (size_t)h * p.hb_tokens * 384 + which * 128 + Q * 16;
+    }
+    auto out_addr = [&](int step) __attribute__((always_inline)) -> char* {
+        if constexpr (HB) {
+            int t = hb_t0 + 8 * step, f = hb_f0;
+            if (t >= p.hb_tokens) { t -= p.hb_tokens; ++f; }
+            return reinterpret_cast<char*>(p.out) + (size_t)f * p.hb_heads * p.hb_tokens * 384 + (size_t)t * 384 + hb_col;
+        } else {
+            return outp + (size_t)step * ostep;
+        }
+    };
     // residual rows: the loads of pass mi + 1 are issued before pass mi is processed, so no pass waits for its own loads (the stream
     // is read exactly once: these are HBM / MALL latencies)
     u32x4 rvn[4];
@@ -246,7 +266,7 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
                 for (int j = 0; j < 8; ++j) s[j] = (TO)((float)a[j] + (float)b[j]);
                 x = __builtin_bit_cast(u32x4, s);
             }
-            if (FULL || (rowok[it] && colok)) store16<STORE>(outp + (size_t)(mi * 4 + it) * ostep, x);
+            if (FULL || (rowok[it] && colok)) store16<STORE>(out_addr(mi * 4 + it), x);
         }
     }
 }
@@ -282,7 +302,8 @@ constexpr bool kLateStats = true;
 template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE>
 __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     constexpr bool HAS_RES = MODE == 1;
-    constexpr bool LNFOLD = MODE == 2;
+    constexpr bool LNFOLD = MODE == 2 || MODE == 4;       // 4 = LN-folded with head-blocked output (the QKV GEMM)
+    constexpr bool HB = MODE == 4;
     constexpr bool kLateBias = CFSAR_LATE_BIAS(MODE, OPATH);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -315,7 +336,12 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             gm = gm < p.M ? gm : p.M - 1;
             int gn = n0 + row;
             gn = gn < p.N ? gn : p.N - 1;
-            ox[i] = (unsigned)gm * (unsigned)p.lda * 2u + chunk * 16;
+            if (p.ha_tokens > 0) {                          // head-blocked A (kernel-uniform): row gm = f T + t, K tile kt = head kt
+                const int f = gm / p.ha_tokens, t = gm - f * p.ha_tokens;
+                ox[i] = ((unsigned)f * (unsigned)(p.K >> 6) * (unsigned)p.ha_tokens + (unsigned)t) * 128u + chunk * 16;
+            } else {
+                ox[i] = (unsigned)gm * (unsigned)p.lda * 2u + chunk * 16;
+            }
             ow[i] = (unsigned)gn * (unsigned)p.ldw * 2u + chunk * 16;
         }
     };
@@ -336,6 +362,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     }
 
     const int nk = p.K / 64;
+    const unsigned akstride = p.ha_tokens > 0 ? (unsigned)p.ha_tokens * 128u : (unsigned)ROWB;     // bytes between K tiles of A
     f32x16 acc[4][2];
     // The accumulators START at the bias: lane columns 32 ni + 8 g + 4 hi + j of the wave's 64 -> no bias add in the epilogue.
     // The 8 x 16-byte loads for the NEXT output tile are issued before the current epilogue and consumed after it.
@@ -370,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     u32x4 GX[4], GW[4];
     uint4 xfA[4], wfA[2], xfB[4], wfB[2];
     auto gloadX = [&](const unsigned (&ox)[4], int kt, auto J) __attribute__((always_inline)) {
-        GX[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.A + (size_t)kt * ROWB + ox[decltype(J)::value]);
+        GX[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.A + (size_t)kt * akstride + ox[decltype(J)::value]);
     };
     auto gloadW = [&](const unsigned (&ow)[4], int kt, auto J) __attribute__((always_inline)) {
         GW[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.W + (size_t)kt * ROWB + ow[decltype(J)::value]);
@@ -382,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         *reinterpret_cast<u32x4*>(smem + stage * STAGE + TM * ROWB + wr_off + decltype(J)::value * 8192) = GW[decltype(J)::value];
     };
     auto dmaX = [&](const unsigned (&ox)[4], int kt, int stage, auto J) __attribute__((always_inline)) {
-        glds16_asm(p.A + (size_t)kt * ROWB + ox[decltype(J)::value],
+        glds16_asm(p.A + (size_t)kt * akstride + ox[decltype(J)::value],
                    ldsw + (unsigned)stage * (unsigned)STAGE + (unsigned)decltype(J)::value * 8192u);
     };
     auto dmaW = [&](const unsigned (&ow)[4], int kt, int stage, auto J) __attribute__((always_inline)) {
@@ -573,8 +600,8 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
 #endif
         {
             const int mb = m0 + wm * 128, nb = n0 + wn * 64;
-            if (mb + 128 <= p.M && nb + 64 <= p.N) epilogue_rows<TO, ACT, HAS_RES, STORE, true, LNFOLD, HAS_RES && OPATH == 1>(acc, p, mb, nb, lane, slab, rscale, rv0);
-            else epilogue_rows<TO, ACT, HAS_RES, STORE, false, LNFOLD, HAS_RES && OPATH == 1>(acc, p, mb, nb, lane, slab, rscale, rv0);
+            if (mb + 128 <= p.M && nb + 64 <= p.N) epilogue_rows<TO, ACT, HAS_RES, STORE, true, LNFOLD, HAS_RES && OPATH == 1, HB>(acc, p, mb, nb, lane, slab, rscale, rv0);
+            else epilogue_rows<TO, ACT, HAS_RES, STORE, false, LNFOLD, HAS_RES && OPATH == 1, HB>(acc, p, mb, nb, lane, slab, rscale, rv0);
         }
         if (!has_next) break;
         sb = (sb + nk) & 1;
@@ -606,6 +633,7 @@ int launch_path(const VitGemmArgs& a, int mode, hipStream_t s) {
     if (mode == 1) return launch_inst<__bf16, _Float16, CFSAR_ACT_NONE, 1, OPATH, STORE>(a, s);
     if (mode == 2) {
         if (a.act == CFSAR_ACT_QUICKGELU) return launch_inst<_Float16, __bf16, CFSAR_ACT_QUICKGELU, 2, OPATH, STORE>(a, s);
+        if (a.hb_tokens > 0) return launch_inst<_Float16, __bf16, CFSAR_ACT_NONE, 4, OPATH, STORE>(a, s);
         return launch_inst<_Float16, __bf16, CFSAR_ACT_NONE, 2, OPATH, STORE>(a, s);
     }
 #ifdef CFSAR_DEV
@@ -645,6 +673,12 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     a.ntiles = ((c.M + TM - 1) / TM) * a.tiles_n;
     a.group = c.group > 0 ? c.group : 8;
     a.colfast = c.colfast;
+    a.hb_tokens = c.hb_tokens; a.hb_heads = c.hb_heads; a.ha_tokens = c.ha_tokens;
+    if (a.hb_tokens > 0 && !(lnfold && c.act == CFSAR_ACT_NONE && a.hb_tokens >= 128 && a.hb_heads > 0 && c.N == 3 * 64 * a.hb_heads &&
+                             c.M % a.hb_tokens == 0))
+        return cfsar_fail("cfsar_gemm_lnfold: head-blocked output needs act NONE, N = 192 heads, tokens >= 128, M a multiple of tokens");
+    if (a.ha_tokens > 0 && !(f16res && a.ha_tokens >= 8 && c.M % a.ha_tokens == 0))
+        return cfsar_fail("cfsar_gemm_residual_stats: head-blocked A needs M a multiple of tokens");
 #ifdef CFSAR_DEV
     a.dbg = c.dbg;
 #endif
@@ -690,9 +724,9 @@ extern "C" void cfsar_debug_set_vit_dbg(int dbg) { g_force_dbg = dbg; }
 #endif
 
 // out = act(LayerNorm(x; gamma, beta) W^T + bias) with the LayerNorm folded into the GEMM (MODE 2 above).  See the header.
-extern "C" int cfsar_gemm_lnfold(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
-                                 const float* rowstats, int M, int N, int K, int lda, int ldw, int ldo, int act,
-                                 cfsar_stream_t stream) {
+static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
+                            const float* rowstats, int M, int N, int K, int lda, int ldw, int ldo, int act, int hb_tokens, int hb_heads,
+                            cfsar_stream_t stream) {
     CFSAR_REQUIRE(x && Wg && out && cvec && dvec && rowstats, "cfsar_gemm_lnfold: null pointer");
     CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_lnfold: bad shape M=%d N=%d K=%d (K %% 64, N %% 64, K >= 128)", M, N, K);
     CFSAR_REQUIRE(lda >= K && ldw >= K && ldo >= N && lda % 8 == 0 && ldw % 8 == 0 && ldo % 8 == 0, "cfsar_gemm_lnfold: bad leading dimension");
@@ -702,6 +736,7 @@ extern "C" int cfsar_gemm_lnfold(const void* x, const void* Wg, void* out, const
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = 0;
     c.out_dtype = CFSAR_BF16; c.res_dtype = CFSAR_F32; c.act = act; c.relu = 0;
     c.opath = vit_policy_opath(K); c.store = vit_policy_store(2); c.group = 8; c.colfast = 0; c.dbg = 0;
+    c.hb_tokens = hb_tokens; c.hb_heads = hb_heads; c.ha_tokens = 0;
 #ifdef CFSAR_DEV
     c.dbg = g_force_dbg;
 #endif
@@ -709,10 +744,26 @@ extern "C" int cfsar_gemm_lnfold(const void* x, const void* Wg, void* out, const
     return rc == -2 ? cfsar_fail("cfsar_gemm_lnfold: operands too large for 32-bit offsets") : rc;
 }
 
+extern "C" int cfsar_gemm_lnfold(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
+                                 const float* rowstats, int M, int N, int K, int lda, int ldw, int ldo, int act,
+                                 cfsar_stream_t stream) {
+    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats, M, N, K, lda, ldw, ldo, act, 0, 0, stream);
+}
+
+// The QKV form with head-blocked output: out[((f heads + h) tokens + t) * 192 + 64 which + c] (see the header).
+extern "C" int cfsar_gemm_lnfold_heads(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
+                                       const float* rowstats, int M, int N, int K, int lda, int ldw, int tokens, int heads,
+                                       cfsar_stream_t stream) {
+    CFSAR_REQUIRE(tokens >= 128 && heads > 0 && N == 192 * heads && M % tokens == 0,
+                  "cfsar_gemm_lnfold_heads: needs tokens >= 128, N = 192 heads, M a multiple of tokens (M=%d N=%d tokens=%d heads=%d)", M, N,
+                  tokens, heads);
+    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats, M, N, K, lda, ldw, N, CFSAR_ACT_NONE, tokens, heads, stream);
+}
+
 // x = x + A W^T + bias (fp16 residual stream, in place) and, if stats_partial != NULL, the per-row partial LayerNorm
 // statistics of the NEW x: stats_partial[m][n / 64] = (sum, sum of squares) over columns [64 (n/64), +64).  See the header.
-extern "C" int cfsar_gemm_residual_stats(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M,
-                                         int N, int K, int lda, int ldw, int ldx, cfsar_stream_t stream) {
+static int gemm_residual_stats_impl(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M,
+                                    int N, int K, int lda, int ldw, int ldx, int ha_tokens, cfsar_stream_t stream) {
     CFSAR_REQUIRE(A && W && x && bias, "cfsar_gemm_residual_stats: null pointer");
     CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_residual_stats: bad shape M=%d N=%d K=%d", M, N, K);
     CFSAR_REQUIRE(lda >= K && ldw >= K && ldx >= N && lda % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, "cfsar_gemm_residual_stats: bad leading dimension");
@@ -721,6 +772,19 @@ extern "C" int cfsar_gemm_residual_stats(const void* A, const void* W, void* x, 
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldx; c.ldr = ldx;
     c.out_dtype = CFSAR_F16; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
     c.opath = vit_policy_opath(K); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;
+    c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = ha_tokens;
     const int rc = cfsar_gemm_vit_try(c, static_cast<hipStream_t>(stream));
     return rc == -2 ? cfsar_fail("cfsar_gemm_residual_stats: operands too large for 32-bit offsets") : rc;
+}
+
+extern "C" int cfsar_gemm_residual_stats(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M,
+                                         int N, int K, int lda, int ldw, int ldx, cfsar_stream_t stream) {
+    return gemm_residual_stats_impl(A, W, x, bias, stats_partial, M, N, K, lda, ldw, ldx, 0, stream);
+}
+
+// The out_proj form: A is the attention output in head-blocked layout A[((f heads + h) tokens + t) * 64 + c], heads = K / 64.
+extern "C" int cfsar_gemm_residual_stats_heads(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M,
+                                               int N, int K, int ldw, int ldx, int tokens, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(tokens >= 8 && M % tokens == 0, "cfsar_gemm_residual_stats_heads: M=%d is not a multiple of tokens=%d", M, tokens);
+    return gemm_residual_stats_impl(A, W, x, bias, stats_partial, M, N, K, K, ldw, ldx, tokens, stream);
 }

@@ -108,6 +108,8 @@ class HipViT:
                 warnings.warn("LayerNorm folding disabled: folded weights / vectors exceed the fp16 range (max |c|,|d| = %.3g, "
                               "max |W gamma| = %.3g); using the unfolded block" % (big, wmax))
                 self.fold = False
+        # head-blocked qkv / attention-output layout (bf16 folded path, >= 128 tokens per frame, 64-wide heads)
+        self.head_blocked = (self.fold and self.ntok >= 128 and D == 64 * self.H and os.environ.get("CFSAR_HEAD_BLOCKED", "1") != "0")
         self._slots = {}
         self.max_frames_32bit = (2 ** 32 - 1) // (self.ntok * 4 * self.D * 2) - 1
 
@@ -169,9 +171,16 @@ class HipViT:
             part, rstat, S = ws["part"], ws["rstat"], D // 64
             hip.row_stats(x, rstat, M, D)                                             # statistics of ln_pre's output
             for i, b in enumerate(self.blocks):                                       # :679-681, LayerNorms folded away
-                hip.gemm_lnfold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], rstat, M=M)
-                hip.vit_attention(qkv, o, F_, N, D, self.H)
-                hip.gemm_residual_stats(o, b["w_out"], x, b["b_out"], part, M=M)      # x += out_proj(attn); stats of the new x
+                if self.head_blocked:
+                    # qkv and the attention output in head-blocked layout: 75 KB contiguous per (frame, head) for the attention
+                    # kernel (called as frames x heads one-head problems), K tile kt of out_proj = head kt
+                    hip.gemm_lnfold_heads(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], rstat, N, self.H, M=M)
+                    hip.vit_attention(qkv, o, F_ * self.H, N, 64, 1)
+                    hip.gemm_residual_stats_heads(o, b["w_out"], x, b["b_out"], N, part, M=M)
+                else:
+                    hip.gemm_lnfold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], rstat, M=M)
+                    hip.vit_attention(qkv, o, F_, N, D, self.H)
+                    hip.gemm_residual_stats(o, b["w_out"], x, b["b_out"], part, M=M)  # x += out_proj(attn); stats of the new x
                 hip.ln_stats_finalize(part, rstat, M, S, D)
                 hip.gemm_lnfold(x, b["wg_fc"], u, b["c_fc"], b["d_fc"], rstat, act=hip.ACT_QUICKGELU, M=M)
                 hip.gemm_residual_stats(u, b["w_pr"], x, b["b_pr"], part, M=M)        # x += c_proj(gelu(c_fc))

@@ -34,6 +34,8 @@ SIGNATURES = {
     "cfsar_gemm_ex": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 17 + [_c_p],
     "cfsar_gemm_lnfold": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
     "cfsar_gemm_residual_stats": [_c_p] * 5 + [_c_int] * 6 + [_c_p],
+    "cfsar_gemm_lnfold_heads": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
+    "cfsar_gemm_residual_stats_heads": [_c_p] * 5 + [_c_int] * 6 + [_c_p],
     "cfsar_ln_stats_finalize": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p],
     "cfsar_row_stats": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p],
     "cfsar_nchw_to_nhwc": [_c_p, _c_p] + [_c_int] * 5 + [_c_p],
@@ -206,6 +208,24 @@ def gemm_residual_stats(A, W, x, bias, stats_partial=None, M=None):
                                            _dev(bias, torch.float32, "bias"), _opt(stats_partial, torch.float32, "stats_partial"),
                                            M, W.shape[0], W.shape[1], A.shape[1], W.shape[1], x.shape[1], _stream()),
            "cfsar_gemm_residual_stats")
+
+
+def gemm_lnfold_heads(x, Wg, out, cvec, dvec, rowstats, tokens, heads, M=None):
+    """The QKV form of gemm_lnfold with head-blocked output [(f heads + h) tokens + t][q | k | v] (cfsar_gemm_lnfold_heads)."""
+    M = x.shape[0] if M is None else M
+    _check(lib().cfsar_gemm_lnfold_heads(_dev(x, torch.float16, "x"), _dev(Wg, torch.float16, "Wg"), _dev(out, torch.bfloat16, "out"),
+                                         _dev(cvec, torch.float32, "cvec"), _dev(dvec, torch.float32, "dvec"),
+                                         _dev(rowstats, torch.float32, "rowstats"), M, Wg.shape[0], Wg.shape[1], x.shape[1],
+                                         Wg.shape[1], tokens, heads, _stream()), "cfsar_gemm_lnfold_heads")
+
+
+def gemm_residual_stats_heads(A, W, x, bias, tokens, stats_partial=None, M=None):
+    """gemm_residual_stats whose A operand is the head-blocked attention output (cfsar_gemm_residual_stats_heads)."""
+    M = x.shape[0] if M is None else M
+    _check(lib().cfsar_gemm_residual_stats_heads(_dev(A, torch.bfloat16, "A"), _dev(W, torch.bfloat16, "W"), _dev(x, torch.float16, "x"),
+                                                 _dev(bias, torch.float32, "bias"), _opt(stats_partial, torch.float32, "stats_partial"),
+                                                 M, W.shape[0], W.shape[1], W.shape[1], x.shape[1], tokens, _stream()),
+           "cfsar_gemm_residual_stats_heads")
 
 
 def ln_stats_finalize(partial, rowstats, M, slots, D, eps=1e-5):

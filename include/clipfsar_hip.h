@@ -201,12 +201,26 @@ int cfsar_cos_otam_logits(const float* Xq, const float* protos, float* logits, f
 int cfsar_gemm_lnfold(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec, const float* rowstats,
                       int M, int N, int K, int lda, int ldw, int ldo, int act, cfsar_stream_t stream);
 
+/* The QKV form of cfsar_gemm_lnfold with HEAD-BLOCKED output (act = NONE, N = 192 heads: q | k | v, tokens per frame >= 128,
+ * M a multiple of tokens): row m = f tokens + t, column n = 64 (which heads + h) + c is written to
+ *     out[((f heads + h) tokens + t) * 192 + 64 which + c]
+ * -- the q, k and v rows of one (frame, head) form one contiguous 75 KB block (few_shot.py:626-628 produces the packed qkv the
+ * attention of :623 splits per head).  cfsar_vit_attention reads such a buffer when called with D = 64, heads = 1 and
+ * frames x heads "frames"; it then writes its output blocked as well ([(f heads + h) tokens + t][64]). */
+int cfsar_gemm_lnfold_heads(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec, const float* rowstats,
+                            int M, int N, int K, int lda, int ldw, int tokens, int heads, cfsar_stream_t stream);
+
 /* ---- A5/A6 residual update + the statistics of the next LayerNorm (few_shot.py:633-635 / :639-640 followed by :636 / :626).
  * x[m,n] = x[m,n] + sum_k A[m,k] W[n,k] + bias[n] in place on the fp16 residual stream (A, W bf16).  If stats_partial != NULL it
  * receives, per row m and 64-column slot s = n / 64, (sum, sum of squares) of the NEW (rounded) x[m, 64 s .. 64 s + 63]:
  * [M, N / 64, 2] fp32.  Deterministic (no atomics).  K % 64 == 0, K >= 128, N % 64 == 0. */
 int cfsar_gemm_residual_stats(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M, int N,
                               int K, int lda, int ldw, int ldx, cfsar_stream_t stream);
+
+/* The out_proj form of cfsar_gemm_residual_stats whose A operand is the head-blocked attention output
+ * A[((f heads + h) tokens + t) * 64 + c], heads = K / 64 (K tile kt of the GEMM = head kt), M a multiple of tokens. */
+int cfsar_gemm_residual_stats_heads(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M, int N,
+                                    int K, int ldw, int ldx, int tokens, cfsar_stream_t stream);
 
 /* rowstats[m] = (mean, std, 1/std, 0) with std = sqrt(biased variance + eps) from the partials above (D = row length). */
 int cfsar_ln_stats_finalize(const float* partial, float* rowstats, int M, int slots, int D, float eps, cfsar_stream_t stream);
