@@ -157,23 +157,21 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
     const int rd0 = rr * 128 + ((Q ^ ((rr >> 1) & 7)) << 4);       // row rr + 8 it: + it * 1024, chunk ^ (4 it & 7) << 4
     // HB: head-blocked output (see VitGemmArgs).  The wave's 64 columns are one (which, head) block; row mb + rr + 8 s is token
     // t0 + 8 s of frame f0, wrapping into the next frame at most once (T >= 128 > 8 * 15).
-    int hb_f0 = 0, hb_t0 = 0;
-    size_t hb_col = 0;
+    char* hb_base = nullptr;                                // address of step 0
+    size_t hb_wrap = 0;                                     // added from the first step that falls into the next frame
+    int hb_wrap_step = 16;
     if constexpr (HB) {
         const int row0 = mb + rr;
-        hb_f0 = row0 / p.hb_tokens;
-        hb_t0 = row0 - hb_f0 * p.hb_tokens;
+        const int f0 = row0 / p.hb_tokens, t0 = row0 - f0 * p.hb_tokens;
         const int blk = ncl >> 6, which = blk / p.hb_heads, h = blk - which * p.hb_heads;
-        hb_col = (size_t)h * p.hb_tokens * 384 + which * 128 + Q * 16;
+        const size_t frame_bytes = (size_t)p.hb_heads * p.hb_tokens * 384;
+        hb_base = reinterpret_cast<char*>(p.out) + (size_t)f0 * frame_bytes + ((size_t)h * p.hb_tokens + t0) * 384 + which * 128 + Q * 16;
+        hb_wrap = frame_bytes - (size_t)p.hb_tokens * 384;
+        hb_wrap_step = (p.hb_tokens - t0 + 7) >> 3;         // first step s with t0 + 8 s >= tokens
     }
     auto out_addr = [&](int step) __attribute__((always_inline)) -> char* {
-        if constexpr (HB) {
-            int t = hb_t0 + 8 * step, f = hb_f0;
-            if (t >= p.hb_tokens) { t -= p.hb_tokens; ++f; }
-            return reinterpret_cast<char*>(p.out) + (size_t)f * p.hb_heads * p.hb_tokens * 384 + (size_t)t * 384 + hb_col;
-        } else {
-            return outp + (size_t)step * ostep;
-        }
+        if constexpr (HB) return hb_base + step * 3072 + (step >= hb_wrap_step ? hb_wrap : (size_t)0);
+        else return outp + (size_t)step * ostep;
     };
     // residual rows: the loads of pass mi + 1 are issued before pass mi is processed, so no pass waits for its own loads (the stream
     // is read exactly once: these are HBM / MALL latencies)

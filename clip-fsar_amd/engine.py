@@ -108,8 +108,12 @@ class HipViT:
                 warnings.warn("LayerNorm folding disabled: folded weights / vectors exceed the fp16 range (max |c|,|d| = %.3g, "
                               "max |W gamma| = %.3g); using the unfolded block" % (big, wmax))
                 self.fold = False
-        # head-blocked qkv / attention-output layout (bf16 folded path, >= 128 tokens per frame, 64-wide heads)
-        self.head_blocked = (self.fold and self.ntok >= 128 and D == 64 * self.H and os.environ.get("CFSAR_HEAD_BLOCKED", "1") != "0")
+        # head-blocked qkv / attention-output layout (bf16 folded path, >= 128 tokens per frame, 64-wide heads): OFF by default.
+        # Measured at 16 episodes per step, same box, alternating runs: the attention kernel gains 3-14 us per layer from the 75 KB
+        # contiguous (frame, head) blocks (9 % in isolation), the QKV GEMM's scattered 128-byte line stores lose 15-18 us, out_proj
+        # 3 us: GPU busy time 311.4 vs 308.7 ms per 6 steps.  Kept (bit-identical results, tests/test_gpu_kernels.py) for a future
+        # attention kernel that can use whole contiguous items.
+        self.head_blocked = (self.fold and self.ntok >= 128 and D == 64 * self.H and os.environ.get("CFSAR_HEAD_BLOCKED", "0") == "1")
         self._slots = {}
         self.max_frames_32bit = (2 ** 32 - 1) // (self.ntok * 4 * self.D * 2) - 1
 

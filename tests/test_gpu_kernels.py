@@ -617,3 +617,42 @@ def test_vit_gemms_are_bit_stable_under_a_second_stream(hip):
         for (run, outs), ref in zip(runs, refs):
             for name, t, r in zip(("qkv", "c_fc", "x_out", "part_out", "x_proj", "part_proj"), outs(), ref):
                 assert torch.equal(t, r), (it, name, float((t.float() - r.float()).abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------ head-blocked layouts
+@pytest.mark.parametrize("F_,T,H", [(5, 197, 12), (3, 257, 16), (9, 128, 4)])
+def test_head_blocked_qkv_attention_outproj_chain(hip, F_, T, H):
+    """cfsar_gemm_lnfold_heads writes q | k | v per (frame, head) as one contiguous block, cfsar_vit_attention consumes / produces
+    that blocking when called with D = 64, heads = 1, and cfsar_gemm_residual_stats_heads reads the blocked attention output as its
+    A operand: every stage must equal its row-major counterpart bit for bit (same kernels, same arithmetic, other addresses)."""
+    D = 64 * H
+    M = F_ * T
+    x = (_rand(M, D, seed=41) * 1.5 + 0.3).to(torch.float16).cuda()
+    rstat = torch.empty(M, 4, device="cuda")
+    hip.row_stats(x, rstat, M, D)
+    Wg = _rand(3 * D, D, seed=42, scale=D ** -0.5).to(torch.float16).cuda()
+    c, d = _rand(3 * D, seed=43).cuda(), _rand(3 * D, seed=44).cuda()
+    qkv_rm = torch.empty(M, 3 * D, device="cuda", dtype=torch.bfloat16)
+    hip.gemm_lnfold(x, Wg, qkv_rm, c, d, rstat, M=M)
+    qkv_hb = torch.full((M * 3 * D,), 7.0, device="cuda", dtype=torch.bfloat16).reshape(M, 3 * D)
+    hip.gemm_lnfold_heads(x, Wg, qkv_hb, c, d, rstat, T, H, M=M)
+    # row-major [f, t, which, h, c] -> blocked [f, h, t, which, c]
+    want = qkv_rm.reshape(F_, T, 3, H, 64).permute(0, 3, 1, 2, 4).contiguous().reshape(M, 3 * D)
+    assert torch.equal(qkv_hb, want)
+    o_rm = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    hip.vit_attention(qkv_rm, o_rm, F_, T, D, H)
+    o_hb = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    hip.vit_attention(qkv_hb.reshape(F_ * H * T, 192), o_hb.reshape(F_ * H * T, 64), F_ * H, T, 64, 1)
+    want_o = o_rm.reshape(F_, T, H, 64).permute(0, 2, 1, 3).contiguous().reshape(M, D)
+    assert torch.equal(o_hb, want_o)
+    Wo = _rand(D, D, seed=45, scale=D ** -0.5).to(torch.bfloat16).cuda()
+    bo = _rand(D, seed=46).cuda()
+    x0 = _rand(M, D, seed=47).to(torch.float16).cuda()
+    xa, xb = x0.clone(), x0.clone()
+    pa, pb = torch.empty(M, D // 64, 2, device="cuda"), torch.empty(M, D // 64, 2, device="cuda")
+    hip.gemm_residual_stats(o_rm, Wo, xa, bo, pa, M=M)
+    hip.gemm_residual_stats_heads(o_hb, Wo, xb, bo, T, pb, M=M)
+    assert torch.equal(xa, xb) and torch.equal(pa, pb)
+    # argument checks
+    with pytest.raises(RuntimeError, match="tokens"):
+        hip.gemm_lnfold_heads(x, Wg, qkv_hb, c, d, rstat, 64, H, M=M)
