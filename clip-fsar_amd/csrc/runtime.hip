@@ -67,5 +67,5 @@ int cfsar_num_cus() {
     return n;
 }
 
-extern "C" int cfsar_version(void) { return 200; /* 0.2.0 */ }
+extern "C" int cfsar_version(void) { return 201; /* 0.2.1 */ }
 extern "C" const char* cfsar_last_error(void) { return cfsar_err_buf; }
