@@ -42,3 +42,16 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// sum over each aligned group of 8 consecutive lanes, result in all 8: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror as
+// DPP-modified VALU adds (a __shfl_xor is a ds_bpermute round trip through the LDS pipe)
+template <int CTRL>
+__device__ __forceinline__ float cfsar_dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float cfsar_dpp_sum8(float v) {
+    v += cfsar_dpp_move<0xB1>(v);
+    v += cfsar_dpp_move<0x4E>(v);
+    v += cfsar_dpp_move<0x141>(v);
+    return v;
+}
