@@ -120,7 +120,7 @@ struct AttLane {
 // The LDS fragment reads run TWO steps ahead of the MFMAs that consume them (S^T: two 16-key tiles; PV: one 32-key block = 8
 // transpose reads): left to itself hipcc emits read -> wait -> MFMA pairs, and a wave then spends an LDS round trip per MFMA pair
 // (13 + 28 round trips per tile; measured 12.7 K cycles per (frame, head) against 2.8 K of matrix-pipe work).
-template <int NKB, int NTV>
+template <int NKB, int NTV, int KPF_ = 0>
 __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const AttLane& L, const bf16x8 (&qf)[2], int ntok,
                                           float scale_log2e, f32x4 (&o)[4], float& inv) {
     constexpr int NT = NKB * 2;
@@ -135,7 +135,8 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) kf[j][ks] = *reinterpret_cast<const bf16x8*>(kbase + j * 2048 + L.koff[ks]);
     };
-    constexpr int KPF = NKB >= 9 ? 1 : 2;                          // read-ahead in tiles (the 288-key instance has 72 score registers)
+    // read-ahead in tiles: two, except that the 288-key instance (72 score registers) affords only one inside a 128-register budget
+    constexpr int KPF = KPF_ > 0 ? KPF_ : (NKB >= 9 ? 1 : 2);
     kload(std::integral_constant<int, 0>{});
     if constexpr (nt_valid > 1 && KPF > 1) kload(std::integral_constant<int, 1>{});
     att_static_for<NT>([&](auto J) {
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const __bf1
             for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{(float)qf[0][0], 0.f, 0.f, (float)qf[1][1]};
         } else
 #endif
-        attn_tile<NKB, NTV>(sK, sV, L, qf, ntok, scale_log2e, o, inv);
+        attn_tile<NKB, NTV, (NKB >= 9 && WPS > 2) ? 1 : 2>(sK, sV, L, qf, ntok, scale_log2e, o, inv);
         // O^T[d][q]: lane owns query q16, d = 16 dt + 4 g + r
         store_o_tile(o, inv, qvalid, out + ((size_t)f * ntok + qrow) * D + h * 64, g);
         qf[0] = qn[0];
@@ -530,7 +531,15 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
 #ifdef CFSAR_DEV
         if (ntok == 197 && g_attn_variant == 7) return launch_ring<7, 13>(qkv, out, F, ntok, D, heads, s);           // persistent ring
         if (ntok == 257 && g_attn_variant == 8) return launch_bf16<9, 17, 9, 4>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257 && g_attn_variant == 20) return launch_bf16<9, 17, 8, 4>(qkv, out, F, ntok, D, heads, s);   // r02 mid-round default
         if (ntok == 257 && g_attn_variant == 9) return launch_bf16<9, 17, 6, 4>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257 && g_attn_variant == 13) return launch_bf16<9, 17, 6, 3>(qkv, out, F, ntok, D, heads, s);   // 170-register budget
+        if (ntok == 257 && g_attn_variant == 14) return launch_bf16<9, 17, 5, 3>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257 && g_attn_variant == 15) return launch_bf16<9, 17, 4, 2>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257 && g_attn_variant == 16) return launch_bf16<9, 17, 3, 2>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257 && g_attn_variant == 17) return launch_bf16<9, 17, 5, 2>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197 && g_attn_variant == 18) return launch_bf16<7, 13, 3, 2>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197 && g_attn_variant == 19) return launch_bf16<7, 13, 5, 2>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 197 && g_attn_variant == 5) return launch_bf16<7, 13, 8, 4>(qkv, out, F, ntok, D, heads, s);   // one item per workgroup
         if (ntok == 197 && g_attn_variant == 6) return launch_bf16<7, 13, 7, 4>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 197 && g_attn_variant == 2) return launch_bf16<7, 13, 5, 4>(qkv, out, F, ntok, D, heads, s);   // 3 workgroups x 5 waves
@@ -541,9 +550,11 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
         if (ntok == 197 && g_attn_variant == 12) return launch_bf16<7, 13, 6, 4>(qkv, out, F, ntok, D, heads, s);  // 2 x 6 waves
 #endif
         if (ntok == 197) return launch_bf16<7, 13, 8, 4>(qkv, out, F, ntok, D, heads, s);
-        if (ntok == 257) return launch_bf16<9, 17, 8, 4>(qkv, out, F, ntok, D, heads, s);
-        if (ntok <= 224) return launch_bf16<7, 0, 7, 4>(qkv, out, F, ntok, D, heads, s);
-        return launch_bf16<9, 0, 9, 4>(qkv, out, F, ntok, D, heads, s);
+        // 257 tokens (ViT-L/14): 4 waves per workgroup in a 256-register budget -- no spills (15 at 128 registers) and K fragments
+        // two tiles ahead: 488 -> 426 us at 640 frames (8 x 128-register waves: 488, 6 x 170: 475, 3 x 256: 460, 5 x 256: 550)
+        if (ntok == 257) return launch_bf16<9, 17, 4, 2>(qkv, out, F, ntok, D, heads, s);
+        if (ntok > 224) return launch_bf16<9, 0, 4, 2>(qkv, out, F, ntok, D, heads, s);
+        return launch_bf16<7, 0, 7, 4>(qkv, out, F, ntok, D, heads, s);
     }
     if (dtype == CFSAR_F32) {
         const int lds = ntok * 64 * 4 * 2;
