@@ -18,6 +18,11 @@
 //     1 = LDS-DMA (global_load_lds_dwordx4 issued from inline asm, one K tile ahead, no ds_write traffic, 32 fewer VGPRs).
 //   * Tile walk and store cache policy are parameters (the XCD's L2 holds 4 MiB: what matters is which tiles its 32 CUs work
 //     on at the same time and whether 128 KiB of output per tile is allowed to evict the operands).
+//   * Register pressure at the tile boundary decides more than any of the above (profiles/r02_gemm_ab.md section 5): the bias and
+//     LayerNorm-statistics vectors of a tile are loaded AFTER the previous tile's epilogue (no spills in the LDS-DMA instances),
+//     the LN-folded instances start their accumulators from one rank-2 MFMA instead of 128 multiplies, the residual instances
+//     add in packed fp16, take their row statistics with v_dot2_f32_f16 + DPP sums and fetch the residual rows one pass ahead.
+//   * Built without packed-fp32 VALU instructions (build.py SOURCE_FLAGS; the story is above quick_gelu4).
 #include <type_traits>
 #include <utility>
 
