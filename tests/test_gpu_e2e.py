@@ -192,3 +192,26 @@ def test_registry_builder_dropin_surface():
     assert maxdiff(out["class_logits"].cpu(), g["class_logits"]) < 1e-3
     loss = model.head.loss(task, out)
     assert torch.isfinite(loss)
+
+
+@pytest.mark.parametrize("episodes", [1, 4])
+def test_forward_is_bit_stable_run_to_run(episodes):
+    """Same engine, same inputs, eight forwards: identical bits.  One episode takes the two-stream small-batch path, four the
+    one-stream path.  (Round 2: a rare stale-lanes fault in one GEMM build first showed up as 1e-4 run-to-run differences here;
+    tools/determinism_probe.py covers the other towers.)"""
+    from clip_fsar_amd.engine import ClipFsarEngine
+    g = load_golden("cfg2_B16_5w1s_T8")
+    m = g["meta"]
+    a, sd, tt, te, ep0 = case_inputs(m)
+    eps = [ep0] + [case_inputs(m, episode=m["episode"] + e)[4] for e in range(1, episodes)]
+    eng = ClipFsarEngine(a, sd, tt, te, precision="bf16", device="cuda")
+    st = lambda k: torch.stack([e[k] for e in eps]).cuda()
+    args = (st("support_set"), st("target_set"), st("support_labels"), st("real_support_labels"))
+    ref = None
+    for it in range(8):
+        lo, cl = eng.forward(*args, way=m["way"], T=m["T"])
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = (lo.clone(), cl.clone())
+        else:
+            assert torch.equal(lo, ref[0]) and torch.equal(cl, ref[1]), (it, float((lo - ref[0]).abs().max()))
