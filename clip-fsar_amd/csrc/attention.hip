@@ -137,8 +137,9 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     };
     // read-ahead in tiles: two, except that the 288-key instance (72 score registers) affords only one inside a 128-register budget
     constexpr int KPF = KPF_ > 0 ? KPF_ : (NKB >= 9 ? 1 : 2);
-    kload(std::integral_constant<int, 0>{});
-    if constexpr (nt_valid > 1 && KPF > 1) kload(std::integral_constant<int, 1>{});
+    att_static_for<KPF>([&](auto J) {
+        if constexpr (decltype(J)::value < nt_valid) kload(J);
+    });
     att_static_for<NT>([&](auto J) {
         constexpr int j = decltype(J)::value;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -222,7 +223,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     inv = __builtin_amdgcn_rcpf(sum);
 }
 
-template <int NKB, int NTV, int NW, int WPS>
+template <int NKB, int NTV, int NW, int WPS, int KPFK = 0>
 __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
                                                                      int ntok, int D, float scale_log2e, int dbg) {
     constexpr int NT = NKB * 2;                                    // 16-key tiles
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const __bf1
             for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{(float)qf[0][0], 0.f, 0.f, (float)qf[1][1]};
         } else
 #endif
-        attn_tile<NKB, NTV, (NKB >= 9 && WPS > 2) ? 1 : 2>(sK, sV, L, qf, ntok, scale_log2e, o, inv);
+        attn_tile<NKB, NTV, ((KPFK > 0) ? KPFK : ((NKB >= 9 && WPS > 2) ? 1 : 2))>(sK, sV, L, qf, ntok, scale_log2e, o, inv);
         // O^T[d][q]: lane owns query q16, d = 16 dt + 4 g + r
         store_o_tile(o, inv, qvalid, out + ((size_t)f * ntok + qrow) * D + h * 64, g);
         qf[0] = qn[0];
@@ -483,13 +484,13 @@ static inline int attn_dbg() {
 #endif
 }
 
-template <int NKB, int NTV, int NW, int WPS>
+template <int NKB, int NTV, int NW, int WPS, int KPFK = 0>
 int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
     constexpr int KROWS = (NTV > 0 ? NTV : NKB * 2) * 16;
     constexpr int LDS = 2 * KROWS * 128;
-    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<NKB, NTV, NW, WPS>), LDS, "cfsar_vit_attention")) return rc;
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<NKB, NTV, NW, WPS, KPFK>), LDS, "cfsar_vit_attention")) return rc;
     const float scale_log2e = 0.125f * 1.4426950408889634f;
-    hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB, NTV, NW, WPS>), dim3(heads, F), dim3(NW * 64), LDS, s,
+    hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB, NTV, NW, WPS, KPFK>), dim3(heads, F), dim3(NW * 64), LDS, s,
                        static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e, attn_dbg());
     return cfsar_check_launch("cfsar_vit_attention(bf16)");
 }
@@ -539,6 +540,11 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
         if (ntok == 257 && g_attn_variant == 16) return launch_bf16<9, 17, 3, 2>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 257 && g_attn_variant == 17) return launch_bf16<9, 17, 5, 2>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 197 && g_attn_variant == 18) return launch_bf16<7, 13, 3, 2>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197 && g_attn_variant == 21) return launch_bf16<7, 13, 4, 2, 3>(qkv, out, F, ntok, D, heads, s);   // K fragments 3 tiles ahead
+        if (ntok == 197 && g_attn_variant == 22) return launch_bf16<7, 13, 4, 2, 5>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197 && g_attn_variant == 23) return launch_bf16<7, 13, 8, 4, 3>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257 && g_attn_variant == 24) return launch_bf16<9, 17, 4, 2, 3>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257 && g_attn_variant == 25) return launch_bf16<9, 17, 4, 2, 5>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 197 && g_attn_variant == 19) return launch_bf16<7, 13, 5, 2>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 197 && g_attn_variant == 5) return launch_bf16<7, 13, 8, 4>(qkv, out, F, ntok, D, heads, s);   // one item per workgroup
         if (ntok == 197 && g_attn_variant == 6) return launch_bf16<7, 13, 7, 4>(qkv, out, F, ntok, D, heads, s);
@@ -549,10 +555,10 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
         if (ntok == 197 && g_attn_variant == 11) return launch_bf16<7, 13, 4, 2>(qkv, out, F, ntok, D, heads, s);  // (2-3) x 4 waves, 256 regs
         if (ntok == 197 && g_attn_variant == 12) return launch_bf16<7, 13, 6, 4>(qkv, out, F, ntok, D, heads, s);  // 2 x 6 waves
 #endif
-        if (ntok == 197) return launch_bf16<7, 13, 8, 4>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197) return launch_bf16<7, 13, 8, 4, 3>(qkv, out, F, ntok, D, heads, s);      // K fragments 3 tiles ahead: 394 -> 386 us
         // 257 tokens (ViT-L/14): 4 waves per workgroup in a 256-register budget -- no spills (15 at 128 registers) and K fragments
         // two tiles ahead: 488 -> 426 us at 640 frames (8 x 128-register waves: 488, 6 x 170: 475, 3 x 256: 460, 5 x 256: 550)
-        if (ntok == 257) return launch_bf16<9, 17, 4, 2>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257) return launch_bf16<9, 17, 4, 2, 5>(qkv, out, F, ntok, D, heads, s);
         if (ntok > 224) return launch_bf16<9, 0, 4, 2>(qkv, out, F, ntok, D, heads, s);
         return launch_bf16<7, 0, 7, 4>(qkv, out, F, ntok, D, heads, s);
     }
