@@ -178,7 +178,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
                 if (j < nt_valid) {
                     const float z = fmaf(s[j][r], scale_log2e, -mxs);
                     pv = __builtin_amdgcn_exp2f(z);
-                    asm volatile("" : "+v"(pv) : "v"(z));       // z stays intact until 2^z exists (see csrc/gemm_vit.hip quick_gelu4)
+                    asm volatile("" : "+v"(pv) : "v"(z));       // operand pin kept from the round-2 fault hunt (csrc/gemm_vit.hip, above quick_gelu4): no instruction, no measured cost
                     sum += pv;
                 }
                 pf[4 * t + r] = (__bf16)pv;
