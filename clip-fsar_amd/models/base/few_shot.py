@@ -214,6 +214,11 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
                 raise ValueError("episode %d has %d distinct support labels, expected way = %d" % (b, c, way))
         return way
 
+    def validate_labels_host(self, support_labels, support_real_class):
+        """The checks of _validate_labels on CPU tensors (before they are uploaded).  Returns the way of the batch; the harness
+        hands it to forward() as inputs["_labels_validated_way"] so that the forward issues no device -> host copy."""
+        return self._validate_labels(support_labels, support_real_class, support_labels.dim() == 2)
+
     def forward(self, inputs):
         cfg = self.args
         if self.training:
@@ -227,7 +232,8 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
                                "(reference runs/test_net_few_shot.py:59-62 does the same)")
         T = int(cfg.DATA.NUM_INPUT_FRAMES)
         batched = support_images.dim() == 5
-        way = self._validate_labels(support_labels, support_real_class, batched)
+        pre = inputs.get("_labels_validated_way")                # set by the harness after validate_labels_host (no sync needed)
+        way = int(pre) if pre is not None else self._validate_labels(support_labels, support_real_class, batched)
         eng = self._get_engine(support_images.device)
         logits, class_logits = eng.forward(
             support_images.float().contiguous(), target_images.float().contiguous(), support_labels, support_real_class,

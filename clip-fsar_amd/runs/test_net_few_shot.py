@@ -35,7 +35,16 @@ def test_epoch(val_loader, model, val_meter, cur_epoch, cfg, writer=None):
         if n_local >= cfg.TRAIN.NUM_TEST_TASKS:
             break
         if misc.get_num_gpus(cfg):
+            # the head checks the label vectors on the host (class ids inside the text table, `way` distinct labels per episode): do it
+            # on the loader's CPU tensors BEFORE the upload, so that the forward itself needs no device -> host copy -- a copy there
+            # waits for the previous episode's kernels and stalls the launch queue once per step
+            head = getattr(getattr(model, "module", model), "head", None)
+            checked = None
+            if head is not None and hasattr(head, "validate_labels_host") and not task_dict["support_labels"].is_cuda:
+                checked = head.validate_labels_host(task_dict["support_labels"], task_dict["real_support_labels"])
             task_dict = {k: v.cuda(non_blocking=True) for k, v in task_dict.items()}
+            if checked is not None:
+                task_dict["_labels_validated_way"] = checked
         model_dict = model(task_dict)
         logits = model_dict["logits"]                                  # [B, Q, way]
         labels = task_dict["target_labels"]
