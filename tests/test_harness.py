@@ -284,3 +284,44 @@ def test_real_data_pipeline_through_the_harness(tmp_path, eps_per_step):
             losses.append(float(F.cross_entropy(lg, lab)))
     assert abs(res["top1_acc"] - float(np.mean(accs))) < 1e-4, (res["top1_acc"], float(np.mean(accs)))
     assert abs(res["loss"] - float(np.mean(losses))) < 2e-3, (res["loss"], float(np.mean(losses)))
+
+
+def _rccl_worker(rank, world, port, n, eps_per_step, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from clip_fsar_amd.runs.test_net_few_shot import test_few_shot
+    cfg = _cfg(n, eps_per_step, num_gpus=world)
+    if world == 1:                                   # a one-rank RCCL group: init_distributed_training only creates groups for world > 1
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    res = test_few_shot(cfg)                         # world 2: init_distributed_training binds cuda:LOCAL_RANK and creates the group
+    assert dist.is_initialized() and torch.cuda.current_device() == rank
+    q.put((rank, res["episodes"], res["top1_acc"], res["loss"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@gpu
+@needs_gpu
+def test_few_shot_under_rccl():
+    """test_few_shot(cfg) with the real head, one process per GPU over RCCL (backend "nccl"): two ranks when two GPUs are visible
+    (static episode shard, ragged: 7 episodes; every rank reports the global statistics), else a one-rank group on this GPU
+    (set_device, RCCL init, the all-gather).  ADVICE r1: each rank must bind ITS GPU before building the model."""
+    import torch.multiprocessing as mp
+    world = 2 if torch.cuda.device_count() >= 2 else 1
+    n = 7
+    port = 29650 + (os.getpid() % 1500)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, n, 2, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    acc, loss = _oracle_stats(n, 18)
+    for rank, episodes, a, l in out:
+        assert episodes == n
+        assert abs(a - acc) < 1e-4 and abs(l - loss) < 2e-3, (rank, a, acc, l, loss)
