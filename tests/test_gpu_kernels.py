@@ -502,6 +502,10 @@ def test_fp16_residual_stream_ops(hip):
 @pytest.mark.parametrize("M,N,K,act", [(777, 384, 128, "none"), (5000, 2304, 768, "none"), (44000, 3072, 768, "gelu"),
                                        (300, 512, 1024, "gelu"), (20500, 768, 256, "none")])
 def test_gemm_lnfold_matches_layernorm_then_gemm(hip, M, N, K, act):
+    _check_lnfold(hip, M, N, K, act)
+
+
+def _check_lnfold(hip, M, N, K, act):
     """cfsar_row_stats + cfsar_gemm_lnfold == act(F.layer_norm(x) @ W.T + b) (few_shot.py:605-611 + :626-628 / :636-640) on the
     raw fp16 stream: the reference of the folded form is the UNFOLDED fp32 computation, so the test covers the algebra (Wg, c, d,
     the rank-1 mean term, the 1/std row scale) and not just the kernel.  Rows get different means / scales (column offsets,
@@ -540,6 +544,26 @@ def test_gemm_lnfold_matches_layernorm_then_gemm(hip, M, N, K, act):
 
 @pytest.mark.parametrize("M,N,K", [(777, 128, 128), (5000, 768, 768), (44000, 768, 3072), (20500, 1024, 256)])
 def test_gemm_residual_stats_and_finalize(hip, M, N, K):
+    _check_residual_stats(hip, M, N, K)
+
+
+def test_vit_gemm_random_shapes(hip):
+    """The LN-folded and the residual + statistics GEMMs on 14 seeded random shapes: ragged M (last row band partial, also M < one
+    tile), N any multiple of 64 (partial column tiles), K any multiple of 64 from 128 (both operand paths: K <= 1024 LDS-DMA,
+    longer K register-staged)."""
+    import random
+    rng = random.Random(20260928)
+    for i in range(14):
+        M = rng.choice([rng.randint(1, 300), rng.randint(300, 3000), rng.randint(3000, 9000)])
+        N = 64 * rng.randint(1, 40)
+        K = 64 * rng.choice([2, 3, 5, 8, 12, 16, 17, 24, 40])
+        if i % 2 == 0:
+            _check_lnfold(hip, M, N, K, "gelu" if i % 4 == 0 else "none")
+        else:
+            _check_residual_stats(hip, M, N, K)
+
+
+def _check_residual_stats(hip, M, N, K):
     """cfsar_gemm_residual_stats: x += A W^T + b in place on the fp16 stream, and its partial statistics, finalized by
     cfsar_ln_stats_finalize, are the LayerNorm statistics of the NEW (stored, fp16-rounded) x."""
     A = _rand(M, K, seed=11).to(torch.bfloat16).cuda()
@@ -567,9 +591,10 @@ def test_gemm_residual_stats_and_finalize(hip, M, N, K):
 def test_vit_gemms_are_bit_stable_under_a_second_stream(hip):
     """The single-episode path runs the support and the query frames as two concurrent forwards on two HIP streams
     (engine.py: ClipFsarEngine.dual_frames).  Every ViT-block GEMM must give bit-identical results whether or not a second
-    instance shares the chip.  Regression test for a fault seen in round 2: an LN-folded QKV kernel build with 12 spilled
-    registers returned stale values in lanes 48-63 of single accumulator registers about once per 100 concurrent launches
-    (never alone); the build without those spills does not (tools/stream_stress.py is the long version of this test)."""
+    instance shares the chip.  Regression test for a fault seen in round 2: builds of the LN-folded QKV kernel that used packed-fp32
+    VALU instructions returned stale values in lanes 48-63 of single accumulator registers -- in one build about once per 100
+    concurrent launches and never alone (DESIGN.md "A fault worth recording"; csrc/gemm_vit.hip is now compiled without those
+    instructions; tools/stream_stress.py is the long version of this test)."""
     F_, N, D = 40, 197, 768
     M = F_ * N
 
