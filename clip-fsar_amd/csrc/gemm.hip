@@ -1452,7 +1452,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     // CU): the persistent kernel of gemm_vit.hip whose operand pipeline runs through the epilogues.  Dev builds: variant
     // 20 + 4 * opath + store forces it on any shape; dbg bit 256 = column-fastest tile walk, bits 9-11 = band group (see below).
     if (in_dtype == CFSAR_BF16 && row_group == 0 && res_mod == 0 && row_off == 0 &&
-        ((forced == 0 && kUseVitKernel && tiles4 >= 512) || (forced >= 20 && forced < 28))) {
+        ((forced == 0 && kUseVitKernel && tiles4 >= 512) || (forced >= 20 && forced < 32))) {
         VitGemmCall c;
         c.A = A; c.W = W; c.out = out; c.bias = bias; c.res = residual;
         c.rowstats = nullptr; c.cvec = nullptr; c.stats_out = nullptr;

@@ -23,7 +23,10 @@ struct VitGemmArgs {          // kernel argument block
     // A[((f H + h) T + t) * 64 + c] (K tile kt = head kt), the attention kernel's output in the same blocking.
     int hb_tokens, hb_heads, ha_tokens;
 #ifdef CFSAR_DEV
-    int dbg;                  // ablations: 4 = no epilogue, 8 = every workgroup reads tile (0, 0)
+    int dbg;                  // ablations: 4 = no epilogue, 8 = every workgroup reads tile (0, 0), 16 = epilogue without its global stores,
+                              // 128 = start-time stagger: workgroup b sleeps ((b >> 3) & 31) * stagger_unit * 64 cycles before its first tile
+    int stagger_unit;
+    long long* trace;         // NULL or [grid][64 tiles][4]: s_memrealtime (100 MHz) at tile start, K loop end, epilogue end, spare
 #endif
 };
 

@@ -43,6 +43,10 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
+#ifndef CFSAR_EPI_PIPE
+#define CFSAR_EPI_PIPE 0      // 1 = software-pipelined epilogue stores (measured neutral to negative: profiles/r03_gemm_anatomy.md)
+#endif
+
 constexpr int TM = 256, TN = 256;              // output tile
 constexpr int ROWB = 128;                      // bytes of K per row per K tile (64 bf16)
 constexpr int STAGE = (TM + TN) * ROWB;        // 64 KiB: X rows [0, 32 KiB), W rows [32 KiB, 64 KiB)
@@ -198,80 +202,117 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
     } else {
         load_res(0);
     }
+    // One 32-row pass = convert (8 groups of 4 values: [row scale] [activation] pack, ds_write_b64) -> read back (4 ds_read_b128) ->
+    // finish (4 x: [+ residual, statistics] 16-byte store).  CFSAR_EPI_PIPE = 1 (A/B builds) issues the four finish steps of pass
+    // mi - 1 BETWEEN the convert groups of pass mi; measured neutral (QKV, c_fc) to negative (residual instances): what the stores
+    // cost is not issue time inside the epilogue but memory-system interference with every workgroup's operand loads during the K
+    // loops that follow (profiles/r03_gemm_anatomy.md: workgroups that skip their stores slow down exactly like those that store).
+    auto convert_group = [&](int mi, int q) __attribute__((always_inline)) {
+        const int ni = q >> 2, g = q & 3;
+        TO4 o;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = acc[mi][ni][4 * g + j];
+            if constexpr (ROWSCALE) v[j] *= rscale[mi];
+        }
+        if constexpr (ACT == CFSAR_ACT_QUICKGELU) quick_gelu4(v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (TO)v[j];
+        const int slot = (2 * (ni * 4 + g) + hi) ^ wsw;
+        *reinterpret_cast<TO4*>(wr + slot * 8) = o;
+    };
+    auto read_back = [&](u32x4 (&d)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)                       // row r = 8 it + rr: (r >> 1) & 7 = ((rr >> 1) + 4 it) & 7
+            d[it] = *reinterpret_cast<const u32x4*>(slab + it * 1024 + (rd0 ^ ((it & 1) << 6)));
+    };
+    auto finish = [&](int mi, int it, u32x4 x, u32x4 r) __attribute__((always_inline)) {
+        const bool rowok = FULL || mb + rr + (mi * 4 + it) * 8 < p.M;
+        if (swap_halves) x = u32x4{x[2], x[3], x[0], x[1]};
+        if constexpr (HAS_RES && std::is_same<TO, _Float16>::value) {
+            // x += residual as four packed fp16 adds; the row statistics of the STORED values as v_dot2_f32_f16 (exact fp16
+            // products, fp32 accumulation): 12 VALU instructions per 8 elements instead of ~56 through fp32
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+            float ps = 0.f, pq = 0.f;
+            const TO8 s8 = __builtin_bit_cast(TO8, x) + __builtin_bit_cast(TO8, r);        // 4 x v_pk_add_f16
+            x = __builtin_bit_cast(u32x4, s8);
+            if (p.stats_out) {                           // wave-uniform
+                const h2 s01 = __builtin_shufflevector(s8, s8, 0, 1), s23 = __builtin_shufflevector(s8, s8, 2, 3);
+                const h2 s45 = __builtin_shufflevector(s8, s8, 4, 5), s67 = __builtin_shufflevector(s8, s8, 6, 7);
+                ps = __builtin_amdgcn_fdot2(s01, ones, ps, false);
+                pq = __builtin_amdgcn_fdot2(s01, s01, pq, false);
+                ps = __builtin_amdgcn_fdot2(s23, ones, ps, false);
+                pq = __builtin_amdgcn_fdot2(s23, s23, pq, false);
+                ps = __builtin_amdgcn_fdot2(s45, ones, ps, false);
+                pq = __builtin_amdgcn_fdot2(s45, s45, pq, false);
+                ps = __builtin_amdgcn_fdot2(s67, ones, ps, false);
+                pq = __builtin_amdgcn_fdot2(s67, s67, pq, false);
+                // the 8 lanes Q = 0..7 of a row are consecutive: quad butterflies + half-row mirror as DPP VALU ops (a
+                // __shfl_xor is a ds_bpermute round trip through the LDS pipe: 96 dependent ones per tile before this)
+                ps = dpp_sum8(ps);
+                pq = dpp_sum8(pq);
+                if (Q == 0 && (FULL || (rowok && colok)))
+                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)(mb + rr + (mi * 4 + it) * 8) * p.stats_slots + (nb >> 6)) * 2) =
+                        make_float2(ps, pq);
+            }
+        } else if constexpr (HAS_RES) {
+            const TO8 a = __builtin_bit_cast(TO8, x), b = __builtin_bit_cast(TO8, r);
+            TO8 sres;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sres[j] = (TO)((float)a[j] + (float)b[j]);
+            x = __builtin_bit_cast(u32x4, sres);
+        }
+#ifdef CFSAR_DEV
+        if ((p.dbg & 16) && x[0] != 0x7fc12345u) return;               // ablation: everything but the global stores
+        if ((p.dbg & 32) && ((blockIdx.x >> 3) & 1) && x[0] != 0x7fc12345u) return;   // ... on every other workgroup of each XCD only
+#endif
+        if (FULL || (rowok && colok)) store16<STORE>(out_addr(mi * 4 + it), x);
+    };
+#if CFSAR_EPI_PIPE
+    u32x4 dprev[4], rvprev[4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         u32x4 rv[4];
-        bool rowok[4];
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) rv[it] = rvn[it];
+        }
+        if (mi < 3) load_res(mi + 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            convert_group(mi, q);
+            if (mi > 0 && (q & 1)) {
+                finish(mi - 1, q >> 1, dprev[q >> 1], rvprev[q >> 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_back(dprev);
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) rvprev[it] = rv[it];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) finish(3, it, dprev[it], rvprev[it]);
+#else
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        u32x4 rv[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            rowok[it] = FULL || mb + rr + (mi * 4 + it) * 8 < p.M;
             if constexpr (HAS_RES) rv[it] = rvn[it];
         }
         if (mi < 3) load_res(mi + 1);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                TO4 o;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = acc[mi][ni][4 * g + j];
-                    if constexpr (ROWSCALE) v[j] *= rscale[mi];
-                }
-                if constexpr (ACT == CFSAR_ACT_QUICKGELU) quick_gelu4(v);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (TO)v[j];
-                const int slot = (2 * (ni * 4 + g) + hi) ^ wsw;
-                *reinterpret_cast<TO4*>(wr + slot * 8) = o;
-            }
+        for (int q = 0; q < 8; ++q) convert_group(mi, q);
         u32x4 d[4];
+        read_back(d);
 #pragma unroll
-        for (int it = 0; it < 4; ++it)                       // row r = 8 it + rr: (r >> 1) & 7 = ((rr >> 1) + 4 it) & 7
-            d[it] = *reinterpret_cast<const u32x4*>(slab + it * 1024 + (rd0 ^ ((it & 1) << 6)));
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            u32x4 x = d[it];
-            if (swap_halves) x = u32x4{x[2], x[3], x[0], x[1]};
-            if constexpr (HAS_RES && std::is_same<TO, _Float16>::value) {
-                // x += residual as four packed fp16 adds; the row statistics of the STORED values as v_dot2_f32_f16 (exact fp16
-                // products, fp32 accumulation): 12 VALU instructions per 8 elements instead of ~56 through fp32
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
-                float ps = 0.f, pq = 0.f;
-                const TO8 s8 = __builtin_bit_cast(TO8, x) + __builtin_bit_cast(TO8, rv[it]);        // 4 x v_pk_add_f16
-                x = __builtin_bit_cast(u32x4, s8);
-                if (p.stats_out) {                           // wave-uniform
-                    const h2 s01 = __builtin_shufflevector(s8, s8, 0, 1), s23 = __builtin_shufflevector(s8, s8, 2, 3);
-                    const h2 s45 = __builtin_shufflevector(s8, s8, 4, 5), s67 = __builtin_shufflevector(s8, s8, 6, 7);
-                    ps = __builtin_amdgcn_fdot2(s01, ones, ps, false);
-                    pq = __builtin_amdgcn_fdot2(s01, s01, pq, false);
-                    ps = __builtin_amdgcn_fdot2(s23, ones, ps, false);
-                    pq = __builtin_amdgcn_fdot2(s23, s23, pq, false);
-                    ps = __builtin_amdgcn_fdot2(s45, ones, ps, false);
-                    pq = __builtin_amdgcn_fdot2(s45, s45, pq, false);
-                    ps = __builtin_amdgcn_fdot2(s67, ones, ps, false);
-                    pq = __builtin_amdgcn_fdot2(s67, s67, pq, false);
-                }
-                if (p.stats_out) {
-                    // the 8 lanes Q = 0..7 of a row are consecutive: quad butterflies + half-row mirror as DPP VALU ops (a
-                    // __shfl_xor is a ds_bpermute round trip through the LDS pipe: 96 dependent ones per tile before this)
-                    ps = dpp_sum8(ps);
-                    pq = dpp_sum8(pq);
-                    if (Q == 0 && (FULL || (rowok[it] && colok)))
-                        *reinterpret_cast<float2*>(p.stats_out + ((size_t)(mb + rr + (mi * 4 + it) * 8) * p.stats_slots + (nb >> 6)) * 2) =
-                            make_float2(ps, pq);
-                }
-            } else if constexpr (HAS_RES) {
-                const TO8 a = __builtin_bit_cast(TO8, x), b = __builtin_bit_cast(TO8, rv[it]);
-                TO8 s;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] = (TO)((float)a[j] + (float)b[j]);
-                x = __builtin_bit_cast(u32x4, s);
-            }
-            if (FULL || (rowok[it] && colok)) store16<STORE>(out_addr(mi * 4 + it), x);
-        }
+        for (int it = 0; it < 4; ++it) finish(mi, it, d[it], rv[it]);
     }
+#endif
 }
 
 // OPATH 0: register-staged operands (global_load_dwordx4 -> VGPR -> ds_write_b128), loads two K tiles ahead.
@@ -455,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             if constexpr (j < 6) load_one(cur, 1, J, xfB, wfB);
             if constexpr (j >= 4) {
                 if constexpr (OPATH == 0) { if constexpr (write) swriteX(nxt, std::integral_constant<int, j - 4>{}); }
-                else { if constexpr (load) dmaX(ox, ksrc, nxt, std::integral_constant<int, j - 4>{}); }
+                else if constexpr (OPATH == 1) { if constexpr (load) dmaX(ox, ksrc, nxt, std::integral_constant<int, j - 4>{}); }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -465,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             if constexpr (j < 6) load_one(cur, 2, J, xfA, wfA);
             if constexpr (j >= 4) {
                 if constexpr (OPATH == 0) { if constexpr (load) gloadX(ox, ksrc, std::integral_constant<int, j - 4>{}); }
-                else { if constexpr (load) dmaW(ow, ksrc, nxt, std::integral_constant<int, j - 4>{}); }
+                else if constexpr (OPATH == 1) { if constexpr (load) dmaW(ow, ksrc, nxt, std::integral_constant<int, j - 4>{}); }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -485,9 +526,19 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                     gloadW(ow, ksrc, std::integral_constant<int, 2 * j + 1>{});
                 }
             } else if constexpr (frags) load_one(nxt, 0, std::integral_constant<int, j - 2>{}, xfA, wfA);
+            // OPATH 2: every wave has issued its last fragment reads of stage `cur` before the barrier of this sub-step -> the
+            // stage is free: K tile `ksrc` (two ahead) starts its flight NOW and has a whole K step to land (OPATH 1 issues the
+            // same pieces 1.5 - 2.5 sub-steps later, into the other stage)
+            if constexpr (OPATH == 2 && load && j >= 2) {
+                if constexpr (j < 6) dmaX(ox, ksrc, cur, std::integral_constant<int, j - 2>{});
+                else {
+                    dmaW(ow, ksrc, cur, std::integral_constant<int, 2 * (j - 6)>{});
+                    dmaW(ow, ksrc, cur, std::integral_constant<int, 2 * (j - 6) + 1>{});
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (j == 1 && sync) {
-                if constexpr (OPATH == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+                if constexpr (OPATH >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
                 __syncthreads();                                        // (register path: hipcc adds lgkmcnt(0) for the ds_writes)
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -515,11 +566,28 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     } else {
         static_for<4>([&](auto J) { dmaX(offX, 0, 0, J); });
         static_for<4>([&](auto J) { dmaW(offW, 0, 0, J); });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (OPATH == 2) {                       // K tile 1 is in flight before the first step as well
+            static_for<4>([&](auto J) { dmaX(offX, 1, 1, J); });
+            static_for<4>([&](auto J) { dmaW(offW, 1, 1, J); });
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     __syncthreads();
     int sb = 0;                                   // stage that holds K tile 0 of the current output tile
     char* slab = smem + EPI_OFF + wave * EPI_SLAB;
+#ifdef CFSAR_DEV
+    int trace_i = 0;
+    if (p.dbg & 128) {
+        const int n = ((blockIdx.x >> 3) & 31) * p.stagger_unit;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+    }
+#define CFSAR_TRACE(slot) do { if (p.trace && tid == 0 && trace_i < 64) p.trace[((size_t)blockIdx.x * 64 + trace_i) * 4 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CFSAR_TRACE(slot) do { } while (0)
+#endif
     for (;;) {
         const int bn = b + grid;
         const bool has_next = bn < nt;
@@ -563,6 +631,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cw[ni], mx[mi], zero, 0, 0, 0);
         }
         static_for<6>([&](auto J) { load_one(sb, 0, J, xfA, wfA); });
+        CFSAR_TRACE(0);
         int kt = 0;
         // The tail steps ALWAYS prefetch (one straight-line MFMA stream: a fork on has_next would merge two 128-register
         // accumulator sets through phi copies).  After the last output tile of this workgroup the "next" origin is the current
@@ -588,12 +657,21 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, T_{}, T_{}, T_{});           // loads K tile 0 of the next tile
             ++kt;
             step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 1, T_{}, T_{}, T_{}, F_{});           // writes it, loads K tile 1
-        } else {
+        } else if constexpr (OPATH == 1) {
             for (; kt < nk - 1; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 1, T_{}, F_{}, T_{}, T_{});
             offsets(m0n, n0n, offX, offW);
             residual_prefetch();
             step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, F_{});           // K tile 0 of the next tile
-        }
+        } else {
+            // step kt waits for K tile kt + 1 (issued by step kt - 1) and issues K tile kt + 2 into its own stage after its barrier
+            for (; kt < nk - 2; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 2, T_{}, F_{}, T_{}, T_{});
+            offsets(m0n, n0n, offX, offW);
+            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, T_{});           // K tile 0 of the next tile
+            ++kt;
+            residual_prefetch();
+            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 1, T_{}, F_{}, T_{}, F_{});           // K tile 1 of the next tile: in flight
+        }                                                                                            // through the epilogue, BEFORE its stores
+        CFSAR_TRACE(1);
         if constexpr (!kLateBias) load_bias(m0n, n0n);                   // lands during the epilogue
         if constexpr (!kLateStats) load_stats(m0n, n0n);
 #ifdef CFSAR_DEV
@@ -606,7 +684,14 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             if (mb + 128 <= p.M && nb + 64 <= p.N) epilogue_rows<TO, ACT, HAS_RES, STORE, true, LNFOLD, HAS_RES && OPATH == 1, HB>(acc, p, mb, nb, lane, slab, rscale, rv0);
             else epilogue_rows<TO, ACT, HAS_RES, STORE, false, LNFOLD, HAS_RES && OPATH == 1, HB>(acc, p, mb, nb, lane, slab, rscale, rv0);
         }
-        if (!has_next) break;
+        CFSAR_TRACE(2);
+#ifdef CFSAR_DEV
+        ++trace_i;
+#endif
+        if (!has_next) {
+            if constexpr (OPATH == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMA of the last step targets this workgroup's LDS
+            break;
+        }
         sb = (sb + nk) & 1;
         b = bn;
         m0 = m0n;
@@ -648,6 +733,10 @@ int launch_path(const VitGemmArgs& a, int mode, hipStream_t s) {
 
 }  // namespace
 
+#ifdef CFSAR_DEV
+static int g_stagger_unit = 0;
+static long long* g_trace = nullptr;
+#endif
 // Returns -2 when the call is outside this kernel's contract (the caller falls back to the generic kernels of gemm.hip).
 int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     const bool lnfold = c.rowstats != nullptr;
@@ -684,6 +773,8 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
         return cfsar_fail("cfsar_gemm_residual_stats: head-blocked A needs M a multiple of tokens");
 #ifdef CFSAR_DEV
     a.dbg = c.dbg;
+    a.stagger_unit = g_stagger_unit;
+    a.trace = g_trace;
 #endif
     int mode = lnfold ? 2 : (f16res ? 1 : 0);
 #ifdef CFSAR_DEV
@@ -694,6 +785,8 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
         case 2: return launch_path<0, 2>(a, mode, s);
         case 4: return launch_path<1, 0>(a, mode, s);
         case 6: return launch_path<1, 2>(a, mode, s);
+        case 8: return launch_path<2, 0>(a, mode, s);
+        case 10: return launch_path<2, 2>(a, mode, s);
 #ifdef CFSAR_DEV
         case 1: return launch_path<0, 1>(a, mode, s);
         case 5: return launch_path<1, 1>(a, mode, s);
@@ -724,6 +817,8 @@ int vit_policy_store(int dflt) {
 // dev builds only: operand path / store policy of cfsar_gemm_lnfold and cfsar_gemm_residual_stats; -1 = product policy
 extern "C" void cfsar_debug_set_vit_paths(int opath, int store) { g_force_opath = opath; g_force_store = store; }
 extern "C" void cfsar_debug_set_vit_dbg(int dbg) { g_force_dbg = dbg; }
+// trace buffer ([grid][64][4] long long, device memory; NULL = off) and stagger unit (x 64 cycles) for dbg bit 128
+extern "C" void cfsar_debug_set_vit_trace(void* trace, int stagger_unit) { g_trace = static_cast<long long*>(trace); g_stagger_unit = stagger_unit; }
 #endif
 
 // out = act(LayerNorm(x; gamma, beta) W^T + bias) with the LayerNorm folded into the GEMM (MODE 2 above).  See the header.

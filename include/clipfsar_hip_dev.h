@@ -24,6 +24,9 @@ void cfsar_debug_set_gemm_variant(int variant, int dbg);
 void cfsar_debug_set_vit_paths(int opath, int store);
 /* ablation bits of cfsar_gemm_lnfold (32 = bf16 MFMA instruction on the fp16 bits: timing A/B only) */
 void cfsar_debug_set_vit_dbg(int dbg);
+/* per-tile time stamps of the persistent ViT GEMM (device buffer [grid][64][4] of int64: s_memrealtime at tile start, K-loop end,
+ * epilogue end; NULL = off) and the unit (x 64 cycles) of the start-time stagger that dbg bit 128 switches on */
+void cfsar_debug_set_vit_trace(void* trace, int stagger_unit);
 /* workgroup shape of the bf16 attention kernel at 197 tokens (csrc/attention.hip); 0 = product */
 void cfsar_debug_set_attn_variant(int v);
 
