@@ -21,12 +21,16 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 DEV_LIB = os.path.join(HERE, "libclipfsar_hip_dev.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          "-Rpass-analysis=kernel-resource-usage"]      # per-kernel VGPR / scratch report -> build/resource_usage.json
-# Per-source flags.  gemm_vit.hip is compiled WITHOUT packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32):
-# builds of its LN-folded kernel that initialise / scale accumulators with v_pk_mul_f32 occasionally returned stale values in lanes
-# 48-63 of the HIGH register of one packed pair (once per ~100 launches, more often with a second kernel on the chip; DESIGN.md
-# "A fault worth recording").  Not reproduced by the microtests in tools/ubench/, root cause not isolated; with scalar fp32 VALU
-# code the fault has not been seen (0 of 900 stress launches against 44 of 150) and the kernels are as fast (same-box A/B).
-SOURCE_FLAGS = {"gemm_vit.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
+# Every source is compiled WITHOUT packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  Round 2: builds of the
+# LN-folded GEMM that scaled accumulators with v_pk_mul_f32 occasionally returned stale values in lanes 48-63 of the HIGH register of one
+# packed pair (once per ~100 launches, more often with a second kernel on the chip; DESIGN.md "A fault worth recording").  Neither the
+# round-2 microtests nor round 3's tools/ubench/pk_trans_waw.hip (transcendental -> packed WAW / RAW under a transcendental- or
+# MFMA-heavy partner wave) reproduce it, so it is FENCED, not explained: with scalar fp32 VALU code it has not been seen (0 of 1 500
+# stress launches against 44 of 150), and the fence now covers gemm.hip, attention.hip, tail.hip, conv.hip and rowops.hip as well (the same
+# epilogue patterns live there).  Same-box A/B: no measurable cost (profiles/r03_gemm_anatomy.md); MI355X_MICROARCH.md lists packed fp32
+# beside MFMAs as an anti-lever anyway.  `-DCFSAR_PACKED_FP32` in CFSAR_BUILD_DEFS (developer builds) switches the instructions back on.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+SOURCE_FLAGS = {src: NO_PACKED_FP32 for src in SOURCES}
 USAGE = os.path.join(HERE, "build", "resource_usage.json")
 
 

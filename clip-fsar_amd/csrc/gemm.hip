@@ -1458,7 +1458,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
         c.rowstats = nullptr; c.cvec = nullptr; c.stats_out = nullptr;
         c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = ldr;
         c.out_dtype = out_dtype; c.res_dtype = res_dtype; c.act = act; c.relu = relu;
-        c.opath = K <= 1024 ? 1 : 0;
+        c.opath = cfsar_vit_policy_opath(K);
         c.store = residual ? 0 : 2;
         c.group = kVitGroup; c.colfast = kVitColfast; c.dbg = 0;
         c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = 0;

@@ -49,3 +49,5 @@ struct VitGemmCall {          // host-side request
 
 // 0 = launched, > 0 = error (cfsar_last_error), -2 = outside this kernel's contract (caller falls back)
 int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s);
+// operand path the policy gives a launch with this K (0 register-staged, 1 LDS-DMA, 2 LDS-DMA issued one barrier earlier)
+int cfsar_vit_policy_opath(int K);

@@ -325,30 +325,13 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
 //         The MFMAs run on the raw fp16 residual stream (TI = f16: same rate as bf16, 3 more mantissa bits); the accumulators
 //         start at d_n * std_m - mean_m c_n, produced by ONE extra MFMA per 32x32 tile (a rank-2 outer product, operands split
 //         into fp16 hi + lo parts: ~22 bits), and the epilogue multiplies the row by 1 / std_m.
-#ifdef CFSAR_EARLY_STATS          // A/B only (build.py --dev with CFSAR_BUILD_DEFS=-DCFSAR_EARLY_STATS): prefetch the statistics before the epilogue
-constexpr bool kLateStats = false;
-#else
-constexpr bool kLateStats = true;
-#endif
-
-// The same for the bias vector.  Same-box A/B at 16 episodes per step (tools/r02_ab_builds.sh, episodes/s): both prefetched before the
-// epilogue 296 (r02 start) | statistics late 299.9 | + bias late for the register-staged c_proj instance (44 -> 26 spills) 304.9 |
-// bias late everywhere 305.7.  The loads are L2 hits issued right after the epilogue's stores; what they cost in exposed latency
-// is less than what the spills of the prefetched copies cost.
-#if defined(CFSAR_LATE_BIAS_NONE)         // A/B builds only (build.py --dev, CFSAR_BUILD_DEFS)
-#define CFSAR_LATE_BIAS(MODE, OPATH) false
-#elif defined(CFSAR_LATE_BIAS_CPROJ)
-#define CFSAR_LATE_BIAS(MODE, OPATH) ((MODE) == 1 && (OPATH) == 0)
-#else
-#define CFSAR_LATE_BIAS(MODE, OPATH) true
-#endif
-
-template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE>
+// SHORTK: K = 128 (two K tiles; the LDS-DMA path only): the first step is also the second-to-last one.
+template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE, bool SHORTK = false>
 __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
+    static_assert(!SHORTK || OPATH == 1, "K = 128 runs on the LDS-DMA path");
     constexpr bool HAS_RES = MODE == 1;
     constexpr bool LNFOLD = MODE == 2 || MODE == 4;       // 4 = LN-folded with head-blocked output (the QKV GEMM)
     constexpr bool HB = MODE == 4;
-    constexpr bool kLateBias = CFSAR_LATE_BIAS(MODE, OPATH);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -406,36 +389,93 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     }
 
     const int nk = p.K / 64;
+    int b = blockIdx.x;
+    if (b >= nt) return;
+    int m0 = 0, n0 = 0;                    // origin of the current output tile
     const unsigned akstride = p.ha_tokens > 0 ? (unsigned)p.ha_tokens * 128u : (unsigned)ROWB;     // bytes between K tiles of A
     f32x16 acc[4][2];
-    // The accumulators START at the bias: lane columns 32 ni + 8 g + 4 hi + j of the wave's 64 -> no bias add in the epilogue.
-    // The 8 x 16-byte loads for the NEXT output tile are issued before the current epilogue and consumed after it.
-    float4 bnext[2][4];
-    float4 rsn[LNFOLD ? 4 : 1];          // LNFOLD: (mean, std, 1/std, -) of rows 32 mi + lr of the next tile (cfsar_ln_stats_finalize)
-    float cn[LNFOLD ? 2 : 1];            // LNFOLD: c of columns 32 ni + lr
+    // Bias / LayerNorm terms are added by ONE extra MFMA per 32x32 tile AFTER the last K step (a rank-1 / rank-2 outer product, see
+    // tail_fold below); the accumulators start at zero (the first sub-step's MFMAs take the inline constant 0 as C).  What a lane
+    // needs for it is tiny -- the bias (or c / d) of ITS two columns 32 ni + lr and, LN-folded, (mean | std) and 1 / std of ITS four
+    // rows 32 mi + lr -- and is fetched by compiler-invisible loads during the second-to-last K step: nothing is loaded after the
+    // epilogue's stores any more (in-order memory returns: a load behind 16 stores waits for all of them; round 2 loaded 8 x 16 B of
+    // bias or 4 x 16 B of statistics per lane there and initialised 128 accumulators from them).
+    constexpr int NTL = LNFOLD ? 10 : 2;
+    float tl[NTL];                       // [0..1] bias | c (hi == 0) / d (hi == 1) of column 32 ni + lr; LNFOLD: [2..5] mean | std, [6..9] 1 / std
     float rscale[4] = {1.f, 1.f, 1.f, 1.f};
-    auto load_bias = [&](int m0_, int n0_) __attribute__((always_inline)) {
-        if constexpr (LNFOLD) return;                     // the LN-folded instance gets d through load_stats (see the initialisation)
+    auto asm_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
+        float v;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+        return v;
+    };
+    auto tail_loads = [&](int m0_, int n0_) __attribute__((always_inline)) {
         int nb_ = n0_ + wn * 64;
         nb_ = nb_ + 64 <= p.N ? nb_ : p.N - 64;
+        const float* cd = LNFOLD ? (hi ? p.bias : p.cvec) : p.bias;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bnext[ni][g] = *reinterpret_cast<const float4*>(p.bias + nb_ + ni * 32 + 8 * g + 4 * hi);
-    };
-    // LNFOLD: row statistics and c of the tile.  Loaded AFTER the epilogue (kLateStats): 18 fewer registers live across it.
-    auto load_stats = [&](int m0_, int n0_) __attribute__((always_inline)) {
+        for (int ni = 0; ni < 2; ++ni) tl[ni] = asm_load(cd + nb_ + ni * 32 + lr);
         if constexpr (LNFOLD) {
-            int nb_ = n0_ + wn * 64;
-            nb_ = nb_ + 64 <= p.N ? nb_ : p.N - 64;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 int m = m0_ + wm * 128 + mi * 32 + lr;
                 m = m < p.M ? m : p.M - 1;
-                rsn[mi] = *reinterpret_cast<const float4*>(p.rowstats + (size_t)m * 4);
+                tl[2 + mi] = asm_load(p.rowstats + (size_t)m * 4 + hi);
+                tl[6 + mi] = asm_load(p.rowstats + (size_t)m * 4 + 2);
+            }
+        }
+    };
+    // after the wait that covers tail_loads: the values are defined from here on (the compiler must not have copied them earlier)
+    auto tail_pin = [&]() __attribute__((always_inline)) {
+        if constexpr (LNFOLD)
+            asm volatile("" : "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]), "+v"(tl[3]), "+v"(tl[4]), "+v"(tl[5]), "+v"(tl[6]), "+v"(tl[7]), "+v"(tl[8]), "+v"(tl[NTL - 1]));
+        else
+            asm volatile("" : "+v"(tl[0]), "+v"(tl[1]));
+    };
+    // acc += bias (x) 1   |   acc += d (x) std - c (x) mean : the k slots 0..2 of the lanes with hi == 0 (k = 0..2) and, LN-folded, of the
+    // lanes with hi == 1 (k = 8..10) carry the factors split into three bf16 (24 bits) or two fp16 (22 bits) parts.
+    auto tail_fold = [&]() __attribute__((always_inline)) {
+        if constexpr (!LNFOLD) {
+            typedef typename Vec2B<TI>::v8 TI8;
+            TI8 bw[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const float bv = hi ? 0.f : tl[ni];
+                const TI h = (TI)bv;
+                const float r1 = bv - (float)h;
+                const TI m = (TI)r1;
+                const TI l = (TI)(r1 - (float)m);
+                bw[ni] = TI8{h, m, l, 0, 0, 0, 0, 0};
+            }
+            const TI one = (TI)(hi ? 0.f : 1.f);
+            const TI8 ones = TI8{one, one, one, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if constexpr (std::is_same<TI, _Float16>::value) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[ni], ones, acc[mi][ni], 0, 0, 0);
+                    else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[ni], ones, acc[mi][ni], 0, 0, 0);
+                }
+        } else {
+            // k slots 0..2 of the lanes with hi == 0 carry (c_hi, c_hi, c_lo) x (-mean_hi, -mean_lo, -mean_hi), the same slots of the
+            // lanes with hi == 1 (k = 8..10) carry (d_hi, d_hi, d_lo) x (std_hi, std_lo, std_hi): every other k slot is zero.
+            f16x8 cw[2], mx[4];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const _Float16 h = (_Float16)tl[ni], l = (_Float16)(tl[ni] - (float)h);
+                cw[ni] = f16x8{h, h, l, 0, 0, 0, 0, 0};
             }
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) cn[ni] = (hi ? p.bias : p.cvec)[nb_ + ni * 32 + lr];     // d for the k = 8.. lanes, c for k = 0..
+            for (int mi = 0; mi < 4; ++mi) {
+                const float nm = hi ? tl[2 + mi] : -tl[2 + mi];
+                const _Float16 h = (_Float16)nm, l = (_Float16)(nm - (float)h);
+                mx[mi] = f16x8{h, l, h, 0, 0, 0, 0, 0};
+                rscale[mi] = tl[6 + mi];
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cw[ni], mx[mi], acc[mi][ni], 0, 0, 0);
         }
     };
     u32x4 GX[4], GW[4];
@@ -460,6 +500,8 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         glds16_asm(p.W + (size_t)kt * ROWB + ow[decltype(J)::value],
                    ldsw + (unsigned)stage * (unsigned)STAGE + (unsigned)(TM * ROWB) + (unsigned)decltype(J)::value * 8192u);
     };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
     // read order = order of first use by the MFMA sequence (ni-major): x0 w0 x1 x2 x3 w1
     auto load_one = [&](int stage, int ss, auto J, uint4 (&xf)[4], uint4 (&wf)[2]) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
@@ -470,15 +512,15 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         if constexpr (isx[j] != 0) xf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdX[idx[j]] ^ x2));
         else wf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdW[idx[j]] ^ x2));
     };
-    auto mfma_one = [&](auto J, uint4 (&xf)[4], uint4 (&wf)[2]) __attribute__((always_inline)) {
+    auto mfma_one = [&](auto J, uint4 (&xf)[4], uint4 (&wf)[2], auto ZERO) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
         constexpr int ni = j >> 2, mi = j & 3;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const f32x16 c = decltype(ZERO)::value ? zero : acc[mi][ni];          // first sub-step of an output tile: C = 0 (inline constant)
         if constexpr (std::is_same<TI, _Float16>::value)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ni]), __builtin_bit_cast(f16x8, xf[mi]),
-                                                                 acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ni]), __builtin_bit_cast(f16x8, xf[mi]), c, 0, 0, 0);
         else
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]),
-                                                                  acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]), c, 0, 0, 0);
     };
     // One 128-byte K tile = 4 sub-steps of 8 MFMAs; `cur` / `nxt` = LDS stages of this K tile / the following one.
     //   LOAD : operands of a later K tile are fetched: (ox, ow, ksrc) name them (register path: two K tiles ahead -> VGPRs;
@@ -487,12 +529,12 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     //   SYNC : barrier after MFMA 1 of sub-step 3 (the following K tile is complete in LDS for every wave)
     //   FRAGS: prefetch the first fragments of the following K tile after the barrier (off at an output-tile boundary: the
     //          epilogue runs in between)
-    auto step = [&](int cur, int nxt, const unsigned (&ox)[4], const unsigned (&ow)[4], int ksrc, auto LOAD, auto WRITE, auto SYNC, auto FRAGS) __attribute__((always_inline)) {
+    auto step = [&](int cur, int nxt, const unsigned (&ox)[4], const unsigned (&ow)[4], int ksrc, auto LOAD, auto WRITE, auto SYNC, auto FRAGS, auto ZERO, auto TAIL) __attribute__((always_inline)) {
         constexpr bool load = decltype(LOAD)::value, write = decltype(WRITE)::value, sync = decltype(SYNC)::value,
-                       frags = decltype(FRAGS)::value;
+                       frags = decltype(FRAGS)::value, tail = decltype(TAIL)::value;
         static_for<8>([&](auto J) {                                     // sub-step 0
             constexpr int j = decltype(J)::value;
-            mfma_one(J, xfA, wfA);
+            mfma_one(J, xfA, wfA, ZERO);
             if constexpr (j < 6) load_one(cur, 1, J, xfB, wfB);
             if constexpr (j >= 4) {
                 if constexpr (OPATH == 0) { if constexpr (write) swriteX(nxt, std::integral_constant<int, j - 4>{}); }
@@ -502,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         });
         static_for<8>([&](auto J) {                                     // sub-step 1
             constexpr int j = decltype(J)::value;
-            mfma_one(J, xfB, wfB);
+            mfma_one(J, xfB, wfB, F_{});
             if constexpr (j < 6) load_one(cur, 2, J, xfA, wfA);
             if constexpr (j >= 4) {
                 if constexpr (OPATH == 0) { if constexpr (load) gloadX(ox, ksrc, std::integral_constant<int, j - 4>{}); }
@@ -512,14 +554,14 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         });
         static_for<8>([&](auto J) {                                     // sub-step 2
             constexpr int j = decltype(J)::value;
-            mfma_one(J, xfA, wfA);
+            mfma_one(J, xfA, wfA, F_{});
             if constexpr (j < 6) load_one(cur, 3, J, xfB, wfB);
             if constexpr (j >= 4 && OPATH == 0 && write) swriteW(nxt, std::integral_constant<int, j - 4>{});
             __builtin_amdgcn_sched_barrier(0);
         });
         static_for<8>([&](auto J) {                                     // sub-step 3
             constexpr int j = decltype(J)::value;
-            mfma_one(J, xfB, wfB);
+            mfma_one(J, xfB, wfB, F_{});
             if constexpr (j < 2) {
                 if constexpr (OPATH == 0 && load) {
                     gloadW(ow, ksrc, std::integral_constant<int, 2 * j>{});
@@ -529,6 +571,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             // OPATH 2: every wave has issued its last fragment reads of stage `cur` before the barrier of this sub-step -> the
             // stage is free: K tile `ksrc` (two ahead) starts its flight NOW and has a whole K step to land (OPATH 1 issues the
             // same pieces 1.5 - 2.5 sub-steps later, into the other stage)
+            if constexpr (tail && j == 2) tail_loads(m0, n0);          // this tile's bias / statistics: covered by the NEXT step's wait
             if constexpr (OPATH == 2 && load && j >= 2) {
                 if constexpr (j < 6) dmaX(ox, ksrc, cur, std::integral_constant<int, j - 2>{});
                 else {
@@ -544,17 +587,9 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             }
         });
     };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-
-    int b = blockIdx.x;
-    if (b >= nt) return;
-    int m0, n0;
     origin(b, m0, n0);
     unsigned offX[4], offW[4];
     offsets(m0, n0, offX, offW);
-    load_bias(m0, n0);
-    load_stats(m0, n0);
     // ---- pipeline fill for the first output tile of this workgroup
     if constexpr (OPATH == 0) {
         static_for<4>([&](auto J) { gloadX(offX, 0, J); });
@@ -593,43 +628,6 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         const bool has_next = bn < nt;
         int m0n = m0, n0n = n0;
         if (has_next) origin(bn, m0n, n0n);
-        if constexpr (!LNFOLD) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        acc[i][j][4 * g] = bnext[j][g].x;
-                        acc[i][j][4 * g + 1] = bnext[j][g].y;
-                        acc[i][j][4 * g + 2] = bnext[j][g].z;
-                        acc[i][j][4 * g + 3] = bnext[j][g].w;
-                    }
-        } else {
-            // The accumulators start at  d_n std_m - c_n mean_m : a rank-2 outer product, i.e. ONE MFMA per 32x32 tile with C = 0.
-            // k slots 0..2 of the lanes with hi == 0 carry (c_hi, c_hi, c_lo) x (-mean_hi, -mean_lo, -mean_hi), the same slots of
-            // the lanes with hi == 1 (k = 8..10) carry (d_hi, d_hi, d_lo) x (std_hi, std_lo, std_hi): both factors split into fp16
-            // hi + lo parts (~22 bits); every other k slot is zero.  No VALU initialisation, no per-lane bias vector.
-            f16x8 cw[2], mx[4];
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {                 // cn = c (hi == 0) or d (hi == 1) of column 32 ni + lr: load_stats
-                const _Float16 h = (_Float16)cn[ni], l = (_Float16)(cn[ni] - (float)h);
-                cw[ni] = f16x8{h, h, l, 0, 0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const float nm = hi ? rsn[mi].y : -rsn[mi].x;
-                const _Float16 h = (_Float16)nm, l = (_Float16)(nm - (float)h);
-                mx[mi] = f16x8{h, l, h, 0, 0, 0, 0, 0};
-                rscale[mi] = rsn[mi].z;
-            }
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cw[ni], mx[mi], zero, 0, 0, 0);
-        }
         static_for<6>([&](auto J) { load_one(sb, 0, J, xfA, wfA); });
         CFSAR_TRACE(0);
         int kt = 0;
@@ -651,29 +649,43 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                 }
             }
         };
+        // nk >= 3 (launcher; nk = 2 is the SHORTK instance).  Step 0 starts the accumulators (C = 0), step nk - 2 fetches the tail operands, then the bias /
+        // LayerNorm terms go in by one more MFMA per 32x32 tile.
         if constexpr (OPATH == 0) {
-            for (; kt < nk - 2; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 2, T_{}, T_{}, T_{}, T_{});
+            step(sb & 1, (sb + 1) & 1, offX, offW, 2, T_{}, T_{}, T_{}, T_{}, T_{}, F_{});
+            for (kt = 1; kt < nk - 2; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 2, T_{}, T_{}, T_{}, T_{}, F_{}, F_{});
             offsets(m0n, n0n, offX, offW);              // this tile's remaining K tiles are already in registers / LDS
-            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, T_{}, T_{}, T_{});           // loads K tile 0 of the next tile
+            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, T_{}, T_{}, T_{}, F_{}, T_{});      // loads K tile 0 of the next tile
             ++kt;
-            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 1, T_{}, T_{}, T_{}, F_{});           // writes it, loads K tile 1
-        } else if constexpr (OPATH == 1) {
-            for (; kt < nk - 1; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 1, T_{}, F_{}, T_{}, T_{});
+            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 1, T_{}, T_{}, T_{}, F_{}, F_{}, F_{});      // writes it, loads K tile 1
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // the tail operands (older than the 8 loads of K tile 1) have landed
+        } else if constexpr (OPATH == 1 && SHORTK) {
+            step(sb & 1, (sb + 1) & 1, offX, offW, 1, T_{}, F_{}, T_{}, T_{}, T_{}, T_{});
+            kt = 1;
             offsets(m0n, n0n, offX, offW);
             residual_prefetch();
-            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, F_{});           // K tile 0 of the next tile
+            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, F_{}, F_{}, F_{});      // K tile 0 of the next tile
+        } else if constexpr (OPATH == 1) {
+            step(sb & 1, (sb + 1) & 1, offX, offW, 1, T_{}, F_{}, T_{}, T_{}, T_{}, F_{});
+            for (kt = 1; kt < nk - 2; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 1, T_{}, F_{}, T_{}, T_{}, F_{}, F_{});
+            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 1, T_{}, F_{}, T_{}, T_{}, F_{}, T_{});
+            ++kt;
+            offsets(m0n, n0n, offX, offW);
+            residual_prefetch();
+            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, F_{}, F_{}, F_{});      // K tile 0 of the next tile
         } else {
             // step kt waits for K tile kt + 1 (issued by step kt - 1) and issues K tile kt + 2 into its own stage after its barrier
-            for (; kt < nk - 2; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 2, T_{}, F_{}, T_{}, T_{});
+            step(sb & 1, (sb + 1) & 1, offX, offW, 2, T_{}, F_{}, T_{}, T_{}, T_{}, F_{});
+            for (kt = 1; kt < nk - 2; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 2, T_{}, F_{}, T_{}, T_{}, F_{}, F_{});
             offsets(m0n, n0n, offX, offW);
-            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, T_{});           // K tile 0 of the next tile
+            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, T_{}, F_{}, T_{});      // K tile 0 of the next tile
             ++kt;
             residual_prefetch();
-            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 1, T_{}, F_{}, T_{}, F_{});           // K tile 1 of the next tile: in flight
-        }                                                                                            // through the epilogue, BEFORE its stores
+            step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 1, T_{}, F_{}, T_{}, F_{}, F_{}, F_{});      // K tile 1 of the next tile: in flight
+        }                                                                                                  // through the epilogue, BEFORE its stores
+        tail_pin();
+        tail_fold();
         CFSAR_TRACE(1);
-        if constexpr (!kLateBias) load_bias(m0n, n0n);                   // lands during the epilogue
-        if constexpr (!kLateStats) load_stats(m0n, n0n);
 #ifdef CFSAR_DEV
         if (p.dbg & 4) {                                                // ablation: no epilogue (keep the accumulators live)
             if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[3][1][2] + acc[2][0][1];
@@ -696,8 +708,6 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         b = bn;
         m0 = m0n;
         n0 = n0n;
-        if constexpr (kLateBias) load_bias(m0, n0);
-        if constexpr (kLateStats) load_stats(m0, n0);
     }
 }
 
@@ -706,13 +716,19 @@ int persistent_grid() {
     return n >= 8 ? n : 8;
 }
 
-template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE>
-int launch_inst(const VitGemmArgs& a, hipStream_t s) {
-    auto* fn = &vit_gemm_kernel<TI, TO, ACT, MODE, OPATH, STORE>;
+template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE, bool SHORTK>
+int launch_inst2(const VitGemmArgs& a, hipStream_t s) {
+    auto* fn = &vit_gemm_kernel<TI, TO, ACT, MODE, OPATH, STORE, SHORTK>;
     if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(fn), LDS_BYTES, "cfsar_gemm(vit)")) return rc;
     const int grid = a.ntiles < persistent_grid() ? ((a.ntiles + 7) & ~7) : persistent_grid();
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), LDS_BYTES, s, a);
     return cfsar_check_launch("cfsar_gemm(vit)");
+}
+
+template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE>
+int launch_inst(const VitGemmArgs& a, hipStream_t s) {
+    if (a.K == 128) return launch_inst2<TI, TO, ACT, MODE, 1, STORE, true>(a, s);       // two K tiles: its own instance
+    return launch_inst2<TI, TO, ACT, MODE, OPATH, STORE, false>(a, s);
 }
 
 // mode: 0 bias -> bf16, 1 residual -> fp16 in place, 2 LN-folded (fp16 operands) -> bf16
@@ -799,11 +815,14 @@ namespace {
 #ifdef CFSAR_DEV
 int g_force_opath = -1, g_force_store = -1, g_force_dbg = 0;
 #endif
-int vit_policy_opath(int K) {                                   // measured, see the policy comment in gemm.hip
+// Operand path by K (same-box A/B at 16 episodes, profiles/r03_gemm_anatomy.md): short K -- QKV, out_proj, c_fc -- takes the LDS-DMA
+// path with the pieces issued right behind the previous step's barrier (2); the long-K c_proj the register-staged path (0).
+int vit_policy_opath(int K) {
 #ifdef CFSAR_DEV
-    if (g_force_opath >= 0) return g_force_opath;
+    if (g_force_opath >= 10) { if (K <= 1024) return g_force_opath - 10; }     // 10 + path: short-K launches only
+    else if (g_force_opath >= 0) return g_force_opath;
 #endif
-    return K <= 1024 ? 1 : 0;
+    return K <= 1024 ? 2 : 0;
 }
 int vit_policy_store(int dflt) {
 #ifdef CFSAR_DEV
@@ -812,6 +831,7 @@ int vit_policy_store(int dflt) {
     return dflt;
 }
 }
+int cfsar_vit_policy_opath(int K) { return vit_policy_opath(K); }      // the cfsar_gemm dispatcher (gemm.hip) uses the same policy
 #ifdef CFSAR_DEV
 #include "../../include/clipfsar_hip_dev.h"
 // dev builds only: operand path / store policy of cfsar_gemm_lnfold and cfsar_gemm_residual_stats; -1 = product policy

@@ -78,6 +78,9 @@ def lib():
             L.cfsar_debug_set_gemm_variant.restype = None
             L.cfsar_debug_set_vit_paths.argtypes = [ctypes.c_int, ctypes.c_int]
             L.cfsar_debug_set_vit_paths.restype = None
+            if os.environ.get("CFSAR_DEV_VIT_PATHS"):          # "opath,store" (10 + opath: short-K launches only; -1 = policy): bench A/B
+                o, st = (int(v) for v in os.environ["CFSAR_DEV_VIT_PATHS"].split(","))
+                L.cfsar_debug_set_vit_paths(o, st)
         _lib = L
     return _lib
 

@@ -385,7 +385,7 @@ def test_gemm_policy_reaches_every_kernel(hip, M, N, K):
 
 
 @pytest.mark.skipif(os.environ.get("CFSAR_DEV_LIB", "0") != "1", reason="developer library only (CFSAR_DEV_LIB=1)")
-@pytest.mark.parametrize("variant", [1, 2, 10, 11, 12, 13, 20, 21, 22, 24, 25, 26])
+@pytest.mark.parametrize("variant", [1, 2, 10, 11, 12, 13, 20, 21, 22, 24, 25, 26, 28, 30])
 def test_gemm_forced_variants_dev(hip, variant):
     """Developer build: every kernel / operand path / store policy forced on ragged shapes (incl. shapes the policy would not
     give it), plus the alternative tile walks of the ViT kernel."""
@@ -499,7 +499,7 @@ def test_fp16_residual_stream_ops(hip):
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm folded into the GEMMs
-@pytest.mark.parametrize("M,N,K,act", [(777, 384, 128, "none"), (5000, 2304, 768, "none"), (44000, 3072, 768, "gelu"),
+@pytest.mark.parametrize("M,N,K,act", [(777, 384, 128, "none"), (900, 320, 192, "none"), (5000, 2304, 768, "none"), (44000, 3072, 768, "gelu"),
                                        (300, 512, 1024, "gelu"), (20500, 768, 256, "none")])
 def test_gemm_lnfold_matches_layernorm_then_gemm(hip, M, N, K, act):
     _check_lnfold(hip, M, N, K, act)
@@ -542,14 +542,14 @@ def _check_lnfold(hip, M, N, K, act):
     assert maxdiff(out.float(), ref2) < 6e-3 * scale, (M, N, K, act)          # bf16 output rounding (2^-9) dominates
 
 
-@pytest.mark.parametrize("M,N,K", [(777, 128, 128), (5000, 768, 768), (44000, 768, 3072), (20500, 1024, 256)])
+@pytest.mark.parametrize("M,N,K", [(777, 128, 128), (1300, 192, 192), (5000, 768, 768), (44000, 768, 3072), (20500, 1024, 256)])
 def test_gemm_residual_stats_and_finalize(hip, M, N, K):
     _check_residual_stats(hip, M, N, K)
 
 
 def test_vit_gemm_random_shapes(hip):
     """The LN-folded and the residual + statistics GEMMs on 14 seeded random shapes: ragged M (last row band partial, also M < one
-    tile), N any multiple of 64 (partial column tiles), K any multiple of 64 from 128 (both operand paths: K <= 1024 LDS-DMA,
+    tile), N any multiple of 64 (partial column tiles), K any multiple of 64 from 128 (K = 128 is its own instance; both operand paths: K <= 1024 LDS-DMA,
     longer K register-staged)."""
     import random
     rng = random.Random(20260928)
