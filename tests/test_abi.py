@@ -110,10 +110,14 @@ def test_hot_kernels_use_no_scratch():
         # instance (c_proj) spills tile-boundary values (never in the K loop)
         "vit_gemm_kernelIDF16bDF16bLi0ELi0ELi1E": 0, "vit_gemm_kernelIDF16bDF16_Li0ELi1ELi1E": 0,
         "vit_gemm_kernelIDF16_DF16bLi0ELi2ELi1E": 0, "vit_gemm_kernelIDF16_DF16bLi1ELi2ELi1E": 0,
+        # round 3 product policy for K <= 1024: the LDS-DMA path with the pieces issued one barrier earlier (OPATH 2)
+        "vit_gemm_kernelIDF16bDF16bLi0ELi0ELi2E": 0, "vit_gemm_kernelIDF16bDF16_Li0ELi1ELi2E": 0,
+        "vit_gemm_kernelIDF16_DF16bLi0ELi2ELi2E": 0, "vit_gemm_kernelIDF16_DF16bLi1ELi2ELi2E": 0,
         "vit_gemm_kernelIDF16bDF16_Li0ELi1ELi0E": 128,
         # p12 (QKV, c_fc, out_proj / c_proj): a few loop-invariant epilogue scalars are spilled at kernel entry and reloaded
         # after the K loop (checked in the ISA: nothing inside the main loop); a main-loop spill would be hundreds of bytes
-        "gemm_kernel_p12IDF16bLi0ELb0E": 64, "gemm_kernel_p12IDF16bLi1ELb0E": 64, "gemm_kernel_p12IfLi0ELb1E": 128,
+        # (round 3: 68 B without packed-fp32 VALU ops -- two more entry scalars)
+        "gemm_kernel_p12IDF16bLi0ELb0E": 96, "gemm_kernel_p12IDF16bLi1ELb0E": 96, "gemm_kernel_p12IfLi0ELb1E": 128,
         "gemm_kernel_p12IDF16_Li0ELb1E": 128,              # fp16 residual stream (out_proj / c_proj of the bf16 mode)
         "gemm_kernel_p10IDF16bLi0ELb0ELb0ELb0E": 0, "gemm_kernel_p10IfLi0ELb1ELb0ELb0E": 0,
         "gemm_kernel_p3IDF16bDF16bLi0ELb0ELb0ELb1ELb0E": 0, "gemm_kernel_p3IDF16bDF16bLi0ELb0ELb0ELb1ELb1E": 0,   # RN50 implicit convs
