@@ -57,9 +57,13 @@ def build_loader(cfg, split):
     idx = du.shard_episodes(len(ds))
     sub = torch.utils.data.Subset(ds, idx)
     bs = int(getattr(cfg.TEST, "EPISODES_PER_STEP", 1))
-    return torch.utils.data.DataLoader(sub, batch_size=bs, shuffle=False,
-                                       num_workers=int(getattr(getattr(cfg, "DATA_LOADER", None), "NUM_WORKERS", 0) or 0),
-                                       drop_last=False)
+    # DATA_LOADER.{NUM_WORKERS, PIN_MEMORY} as in the reference (datasets/base/builder.py:83-92; its configs pin): pinned batches are what
+    # makes the copy-stream upload of runs/test_net_few_shot.py asynchronous (utils/prefetch.py).  Pinning needs a GPU runtime.
+    dl = getattr(cfg, "DATA_LOADER", None)
+    workers = int(getattr(dl, "NUM_WORKERS", 0) or 0)
+    pin = bool(getattr(dl, "PIN_MEMORY", True)) and torch.cuda.is_available() and int(getattr(cfg, "NUM_GPUS", 1) or 0) > 0
+    kw = dict(persistent_workers=True, prefetch_factor=2) if workers > 0 else {}
+    return torch.utils.data.DataLoader(sub, batch_size=bs, shuffle=False, num_workers=workers, pin_memory=pin, drop_last=False, **kw)
 
 
 def shuffle_dataset(loader, cur_epoch):

@@ -20,6 +20,7 @@ from ..utils import logging
 from ..utils import metrics
 from ..utils import misc
 from ..utils.meters import ValMeter
+from ..utils.prefetch import DevicePrefetcher
 
 logger = logging.get_logger(__name__)
 
@@ -31,20 +32,23 @@ def test_epoch(val_loader, model, val_meter, cur_epoch, cfg, writer=None):
     dev = torch.device("cuda", torch.cuda.current_device()) if misc.get_num_gpus(cfg) else torch.device("cpu")
     stats, preds_all, real_all, lab_all = [], [], [], []
     n_local = 0
-    for cur_iter, task_dict in enumerate(val_loader):
+    batches = val_loader
+    if misc.get_num_gpus(cfg):
+        # Host -> device ingestion: the reference uploads with `.cuda(non_blocking=True)` from its pinned loader (:59-62).  Here the
+        # upload of step i + 1 runs on a copy stream into a second device buffer while step i computes (utils/prefetch.py).  The head
+        # checks the label vectors on the host (class ids inside the text table, `way` distinct labels per episode): that happens on the
+        # loader's CPU tensors BEFORE the upload, so the forward itself needs no device -> host copy -- a copy there waits for the
+        # previous episode's kernels and stalls the launch queue once per step.
+        head = getattr(getattr(model, "module", model), "head", None)
+
+        def check_on_host(host):
+            if head is not None and hasattr(head, "validate_labels_host") and not host["support_labels"].is_cuda:
+                return {"_labels_validated_way": head.validate_labels_host(host["support_labels"], host["real_support_labels"])}
+            return None
+        batches = DevicePrefetcher(val_loader, dev, pre_upload=check_on_host)
+    for cur_iter, task_dict in enumerate(batches):
         if n_local >= cfg.TRAIN.NUM_TEST_TASKS:
             break
-        if misc.get_num_gpus(cfg):
-            # the head checks the label vectors on the host (class ids inside the text table, `way` distinct labels per episode): do it
-            # on the loader's CPU tensors BEFORE the upload, so that the forward itself needs no device -> host copy -- a copy there
-            # waits for the previous episode's kernels and stalls the launch queue once per step
-            head = getattr(getattr(model, "module", model), "head", None)
-            checked = None
-            if head is not None and hasattr(head, "validate_labels_host") and not task_dict["support_labels"].is_cuda:
-                checked = head.validate_labels_host(task_dict["support_labels"], task_dict["real_support_labels"])
-            task_dict = {k: v.cuda(non_blocking=True) for k, v in task_dict.items()}
-            if checked is not None:
-                task_dict["_labels_validated_way"] = checked
         model_dict = model(task_dict)
         logits = model_dict["logits"]                                  # [B, Q, way]
         labels = task_dict["target_labels"]

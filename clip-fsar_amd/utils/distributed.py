@@ -88,8 +88,9 @@ def gather_episode_stats(local_stats: torch.Tensor, num_episodes: int):
     world, rank = get_world_size(), get_rank()
     if local_stats.dim() == 1:
         local_stats = local_stats.unsqueeze(1)
-    if world == 1:
+    if world == 1 and not is_initialized():
         return local_stats[:num_episodes]
+    # (a one-rank GROUP still issues the collective: the RCCL path is then exercised by the single-GPU tests as well)
     per = (num_episodes + world - 1) // world
     k = local_stats.shape[1]
     pad = torch.zeros(per, k, device=local_stats.device, dtype=torch.float32)

@@ -40,6 +40,36 @@ def test_self_spawn_dry_run_gloo():
     assert out["scaling"] == "weak" and out["higher_is_better"] is True
 
 
+def test_self_spawn_dry_run_gloo_8_ranks():
+    """The shape of the driver's 8-GPU run (BASELINE config[4]), rehearsed on CPU: eight self-spawned ranks, rendezvous, the pre-timing
+    check-in, ONE all-gather that must have seen every rank, max-over-ranks timing, one JSON line."""
+    out = _run([sys.executable, BENCH, "--gpus", "8", "--steps", "3", "--warmup", "1", "--episodes-per-step", "2", "--dry-run"])
+    assert out["dry_run"] is True and out["n_gpus"] == 8
+    assert out["gathered_rank_ids"] == list(range(8))
+    assert out["config"]["launcher"] == "bench.py self-spawn"
+
+
+def test_torchrun_dry_run_gloo_8_ranks():
+    port = 29900 + (os.getpid() % 90)
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--episodes-per-step", "1",
+                "--dry-run"])
+    assert out["n_gpus"] == 8 and out["gathered_rank_ids"] == list(range(8))
+    assert out["config"]["launcher"] == "torch.distributed.run"
+
+
+def test_missing_rank_is_named_not_hung():
+    """A rank that never shows up must end the run with a message, within the rendezvous timeout."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29990 - (os.getpid() % 80)))
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--rendezvous-timeout", "5"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert p.returncode != 0
+    assert "rendezvous" in p.stderr or "did not reach" in p.stderr, p.stderr[-2000:]
+
+
 def test_torchrun_dry_run_gloo():
     port = 29600 + (os.getpid() % 300)
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

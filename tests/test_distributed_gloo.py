@@ -78,6 +78,27 @@ def test_world_size_2_gloo():
         assert abs(acc - sum(exp) / n) < 1e-4, (rank, acc, exp)
 
 
+def test_world_size_8_gloo_ragged():
+    """Eight ranks (the node the reference's launcher fills, utils/launcher.py:29-34) with an episode count that does not divide:
+    19 episodes -> three ranks hold 3, five hold 2; EPISODES_PER_STEP = 2 makes the last step of the 3-episode ranks ragged too."""
+    n, world = 19, 8
+    port = 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    exp = _expected(n)
+    assert sorted(r for r, _, _ in out) == list(range(world))
+    for rank, episodes, acc in out:
+        assert episodes == n
+        assert abs(acc - sum(exp) / n) < 1e-4, (rank, acc, exp)
+
+
 def test_single_process_matches():
     from clip_fsar_amd.utils.meters import ValMeter
     from clip_fsar_amd.datasets.base.builder import build_loader

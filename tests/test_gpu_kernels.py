@@ -644,6 +644,94 @@ def test_vit_gemms_are_bit_stable_under_a_second_stream(hip):
                 assert torch.equal(t, r), (it, name, float((t.float() - r.float()).abs().max()))
 
 
+def _two_stream_bit_stability(make, names, iters=8):
+    """Two independent instances of a launch sequence: reference results alone, then both concurrently on two streams, `iters` times."""
+    runs = [make(100), make(200)]
+    refs = []
+    for run, outs in runs:
+        run()
+        torch.cuda.synchronize()
+        refs.append([t.clone() for t in outs()])
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for it in range(iters):
+        torch.cuda.synchronize()
+        for st, (run, _) in zip(streams, runs):
+            with torch.cuda.stream(st):
+                run()
+                run()
+        torch.cuda.synchronize()
+        for (run, outs), ref in zip(runs, refs):
+            for name, t, r in zip(names, outs(), ref):
+                assert torch.equal(t, r), (it, name, float((t.float() - r.float()).abs().max()))
+
+
+def test_p12_gemms_are_bit_stable_under_a_second_stream(hip):
+    """gemm_kernel_p12 (gemm.hip) serves the ViT-block GEMMs between 240 and 512 output tiles -- out_proj / c_proj of a 2-episode
+    step (124 row bands x 3) with the fp16 residual stream, QKV-shaped plain launches of ~30 row bands.  Same accumulator-scaling
+    epilogue patterns as the kernel that showed the round-2 stale-lanes fault; compiled without packed-fp32 ops since round 3."""
+    D = 768
+    M = 160 * 197                                   # 124 bands: N = 768 -> 372 tiles (p12), N = 2304 -> 1 116 (vit kernel)
+    Mq = 8000                                       # 32 bands x 9 = 288 tiles: p12 with bf16 output
+
+    def make(seed):
+        o = _rand(M, D, seed=seed).to(torch.bfloat16).cuda()
+        uin = _rand(M, 4 * D, seed=seed + 1).to(torch.bfloat16).cuda()
+        Wo = _rand(D, D, seed=seed + 2, scale=D ** -0.5).to(torch.bfloat16).cuda()
+        Wp = _rand(D, 4 * D, seed=seed + 3, scale=(4 * D) ** -0.5).to(torch.bfloat16).cuda()
+        bo = _rand(D, seed=seed + 4).cuda()
+        x0 = _rand(M, D, seed=seed + 5).to(torch.float16).cuda()
+        xa, xb = x0.clone(), x0.clone()
+        h = _rand(Mq, D, seed=seed + 6).to(torch.bfloat16).cuda()
+        Wq = _rand(3 * D, D, seed=seed + 7, scale=D ** -0.5).to(torch.bfloat16).cuda()
+        bq = _rand(3 * D, seed=seed + 8).cuda()
+        qkv = torch.empty(Mq, 3 * D, device="cuda", dtype=torch.bfloat16)
+        ug = torch.empty(Mq, 3 * D, device="cuda", dtype=torch.bfloat16)
+
+        def run():
+            xa.copy_(x0)
+            hip.gemm(o, Wo, xa, bias=bo, residual=xa)
+            xb.copy_(x0)
+            hip.gemm(uin, Wp, xb, bias=bo, residual=xb)
+            hip.gemm(h, Wq, qkv, bias=bq)
+            hip.gemm(h, Wq, ug, bias=bq, act=hip.ACT_QUICKGELU)
+        return run, lambda: [xa, xb, qkv, ug]
+    _two_stream_bit_stability(make, ("out_proj p12 f16", "c_proj p12 f16", "qkv p12", "gelu p12"))
+
+
+def test_patch_embed_attention_and_rn50_conv_are_bit_stable_under_a_second_stream(hip):
+    """The other hot kernels of the towers under the same two-stream regime: the patch-embed GEMM (gemm_kernel_p3, row-scatter + positional
+    epilogue into the fp16 stream), the attention kernel at 197 tokens (ViT-B/16) and at 257 tokens / 16 heads (vit_attn_bf16_kernel<9,
+    ...>, ViT-L/14) and the RN50 implicit-GEMM 3x3 convolutions (p3 CONV with 64 and 128 output channels, p10 CONV with 256)."""
+    def make(seed):
+        F_, npatch, D = 80, 196, 768
+        patches = _rand(F_ * npatch, D, seed=seed).to(torch.bfloat16).cuda()
+        wp = _rand(D, D, seed=seed + 1, scale=D ** -0.5).to(torch.bfloat16).cuda()
+        pos = _rand(npatch + 1, D, seed=seed + 2).cuda()
+        x = torch.zeros(F_ * (npatch + 1), D, device="cuda", dtype=torch.float16)
+        qkvB = _rand(40 * 197, 3 * 768, seed=seed + 3).to(torch.bfloat16).cuda()
+        oB = torch.empty(40 * 197, 768, device="cuda", dtype=torch.bfloat16)
+        qkvL = _rand(24 * 257, 3 * 1024, seed=seed + 4).to(torch.bfloat16).cuda()
+        oL = torch.empty(24 * 257, 1024, device="cuda", dtype=torch.bfloat16)
+        convs = []
+        for i, (C, H, Co) in enumerate(((64, 56, 64), (128, 28, 128), (256, 14, 256))):
+            Fn = 16
+            xc = _rand(Fn * H * H, C, seed=seed + 10 + i).to(torch.bfloat16).cuda()
+            w = _rand(Co, 9 * C, seed=seed + 20 + i, scale=(9 * C) ** -0.5).to(torch.bfloat16).cuda()
+            b = _rand(Co, seed=seed + 30 + i).cuda()
+            out = torch.empty(Fn * H * H, Co, device="cuda", dtype=torch.bfloat16)
+            convs.append((xc, w, b, out, Fn, H, C))
+
+        def run():
+            hip.gemm(patches, wp, x, residual=pos, M=F_ * npatch, N=D, K=D, ldo=D, ldr=D, row_group=npatch, row_gap=1, row_off=1,
+                     res_mod=npatch, res_off=1)
+            hip.vit_attention(qkvB, oB, 40, 197, 768, 12)
+            hip.vit_attention(qkvL, oL, 24, 257, 1024, 16)
+            for xc, w, b, out, Fn, H, C in convs:
+                hip.conv3x3(xc, w, out, Fn, H, H, C, bias=b, relu=True)
+        return run, lambda: [x, oB, oL] + [c[3] for c in convs]
+    _two_stream_bit_stability(make, ("patch embed p3", "attention 197", "attention 257 (ViT-L)", "conv 64", "conv 128", "conv 256"))
+
+
 # ------------------------------------------------------------------------------------------------ head-blocked layouts
 @pytest.mark.parametrize("F_,T,H", [(5, 197, 12), (3, 257, 16), (9, 128, 4)])
 def test_head_blocked_qkv_attention_outproj_chain(hip, F_, T, H):

@@ -325,3 +325,47 @@ def test_few_shot_under_rccl():
     for rank, episodes, a, l in out:
         assert episodes == n
         assert abs(a - acc) < 1e-4 and abs(l - loss) < 2e-3, (rank, a, acc, l, loss)
+
+
+@gpu
+@needs_gpu
+def test_test_epoch_with_pinned_host_inputs_keeps_up_with_resident_inputs():
+    """the product harness must not pay the host -> device upload on the compute stream.  test_epoch over a pinned
+    loader of full-size cfg2 steps (16 episodes = 771 MB per step, ViT-B/16, bf16) through DevicePrefetcher has to run at >= 0.95 x the
+    rate of the same loop over device-resident steps (reference upload: runs/test_net_few_shot.py:59-62, non_blocking from a pinned loader)."""
+    import time
+    from clip_fsar_amd.models.base.builder import build_model
+    from clip_fsar_amd.runs.test_net_few_shot import test_epoch
+    from clip_fsar_amd.utils.meters import ValMeter
+    B, steps = 16, 6
+    a = synth.ARCHS["ViT-B/16"]
+    cfg = NS(VIDEO=NS(HEAD=NS(NAME="CNN_OTAM_CLIPFSAR", BACKBONE_NAME="ViT-B/16", PRECISION="bf16"), BACKBONE=NS(META_ARCH="Identity")),
+             TRAIN=NS(CLASS_NAME=["c%d" % i for i in range(N_TRAIN)], WAY=5, SHOT=1, QUERY_PER_CLASS=1, NUM_TEST_TASKS=B * steps,
+                      BATCH_SIZE=1, CHECKPOINT_FILE_PATH=""),
+             TEST=NS(CLASS_NAME=["t%d" % i for i in range(N_TEST)], DATASET="Synthetic_few_shot", EPISODES_PER_STEP=B, CHECKPOINT_FILE_PATH=""),
+             DATA=NS(NUM_INPUT_FRAMES=8, TEST_CROP_SIZE=a["res"]), MODEL=NS(NAME="BaseVideoModel", EMA=NS(ENABLE=False)),
+             BN=NS(FREEZE=False), NUM_GPUS=1, NUM_SHARDS=1, RANDOM_SEED=18, LOG_PERIOD=100, OUTPUT_DIR="")
+    model, _ = build_model(cfg)
+    eps = [{k: torch.from_numpy(v) for k, v in synth.make_episode(5, 1, 1, 8, a["res"], N_TEST, e, 18).items()} for e in range(4)]
+    host = [{k: torch.stack([eps[(j + i) % 4][k] for i in range(B)]).pin_memory() for k in eps[0]} for j in range(2)]
+    resident = [{k: v.cuda() for k, v in b.items()} for b in host]
+
+    class _Steps:                                    # a "loader": len() + iteration over pre-built steps; .dataset for the harness
+        def __init__(self, items):
+            self.items, self.dataset = items, list(range(B * steps))
+        def __len__(self):
+            return steps
+        def __iter__(self):
+            return (self.items[i % len(self.items)] for i in range(steps))
+
+    def timed(loader):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = test_epoch(loader, model, ValMeter(steps, cfg), 0, cfg)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, res
+    timed(_Steps(resident))                         # warm-up: engine build, workspaces
+    t_res, r_res = timed(_Steps(resident))
+    t_host, r_host = timed(_Steps(host))
+    assert r_host["episodes"] == B * steps and abs(r_host["top1_acc"] - r_res["top1_acc"]) < 1e-6
+    assert t_res / t_host >= 0.95, "host-input harness %.1f episodes/s vs resident %.1f" % (B * steps / t_host, B * steps / t_res)
