@@ -62,6 +62,8 @@ def build_loader(cfg, split):
     dl = getattr(cfg, "DATA_LOADER", None)
     workers = int(getattr(dl, "NUM_WORKERS", 0) or 0)
     pin = bool(getattr(dl, "PIN_MEMORY", True)) and torch.cuda.is_available() and int(getattr(cfg, "NUM_GPUS", 1) or 0) > 0
+    if bool(getattr(getattr(cfg, "AUGMENTATION", None), "USE_GPU", False)):
+        pin = False                 # the dataset's transform runs on the device (preprocess.py): its items are already device tensors
     kw = dict(persistent_workers=True, prefetch_factor=2) if workers > 0 else {}
     return torch.utils.data.DataLoader(sub, batch_size=bs, shuffle=False, num_workers=workers, pin_memory=pin, drop_last=False, **kw)
 

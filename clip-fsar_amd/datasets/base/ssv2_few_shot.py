@@ -202,7 +202,9 @@ class Ssv2_few_shot(torch.utils.data.Dataset):
         with open(path) as f:
             lines = f.readlines()
         self._samples = [l.strip() for l in lines]
-        self.split_few_shot = Split_few_shot(lines, self.split, dataset=self.dataset_name)
+        # a non-train split ("test", and "val" as the training script's validation pass uses it) reads test_few_shot.txt, whose lines
+        # start with "test<class id>" (reference :146-188)
+        self.split_few_shot = Split_few_shot(lines, "train" if self.split == "train" else "test", dataset=self.dataset_name)
         assert len(self.split_few_shot) != 0, "Empty sample list {}".format(path)
         logger.info("Dataset {} split {} loaded. Length {}.".format(self.dataset_name, self.split, len(self.split_few_shot)))
 
@@ -216,9 +218,14 @@ class Ssv2_few_shot(torch.utils.data.Dataset):
         ts = d.TEST_SCALE
         self._scale = [int(ts[0]), int(ts[1])] if isinstance(ts, (list, tuple)) else [int(ts), int(ts)]
         self._crop = int(d.TEST_CROP_SIZE)
+        # The reference derives (temporal clip, spatial crop) of a video from _spatial_temporal_index[vid_id] (base_dataset.py:253-262);
+        # its few-shot configs run ONE view (NUM_ENSEMBLE_VIEWS = NUM_SPATIAL_CROPS = 1).  get_seq takes clip 0 / crop 0, so a config
+        # that asks for more views would silently diverge from the reference: refuse it.
         self._nsc = int(getattr(self.cfg.TEST, "NUM_SPATIAL_CROPS", 1))
-        if self._nsc not in (1, 3):
-            raise NotImplementedError("NUM_SPATIAL_CROPS must be 1 or 3 (reference transformations.py:693-716)")
+        nev = int(getattr(self.cfg.TEST, "NUM_ENSEMBLE_VIEWS", 1))
+        if self._nsc != 1 or nev != 1:
+            raise NotImplementedError("TEST.NUM_SPATIAL_CROPS = %d / NUM_ENSEMBLE_VIEWS = %d: only the single-view episode sampling of the "
+                                      "CLIP-FSAR configs is implemented (reference base_dataset.py:253-262)" % (self._nsc, nev))
         self._mean, self._std = [float(x) for x in d.MEAN], [float(x) for x in d.STD]
 
     def transform(self, frames_u8, spatial_idx=0):

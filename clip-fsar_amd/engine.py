@@ -108,6 +108,9 @@ class HipViT:
                 warnings.warn("LayerNorm folding disabled: folded weights / vectors exceed the fp16 range (max |c|,|d| = %.3g, "
                               "max |W gamma| = %.3g); using the unfolded block" % (big, wmax))
                 self.fold = False
+            if self.fold:
+                for blk in self.blocks:          # the unfolded 16-bit copies would only serve the fallback above: free ~1/3 of the tower's weights
+                    blk["w_qkv"] = blk["w_fc"] = None
         # head-blocked qkv / attention-output layout (bf16 folded path, >= 128 tokens per frame, 64-wide heads): OFF by default.
         # Measured at 16 episodes per step, same box, alternating runs: the attention kernel gains 3-14 us per layer from the 75 KB
         # contiguous (frame, head) blocks (9 % in isolation), the QKV GEMM's scattered 128-byte line stores lose 15-18 us, out_proj
@@ -464,7 +467,7 @@ class ClipFsarEngine:
         self.text_train, self.text_test = f32(text_train), f32(text_test)
         self.scale = f32(head_sd["scale"])
         # frames per tower launch: the kernels address an activation matrix with 32-bit byte offsets, the widest one is the MLP
-        # hidden [F * tokens, 4 D] in 2 bytes (ViT-B/16: 3 548 frames); larger episode batches run the tower in chunks
+        # hidden [F * tokens, 4 D] in 2 bytes (ViT-B/16: 3 548 frames fit; the engine keeps one frame of margin: 3 547); larger episode batches run the tower in chunks
         limit = getattr(self.vit, "max_frames_32bit", None)
         self.max_frames = min(max_frames, limit) if limit else max_frames
         # Small batches (one or two episodes): the support and the query frames go through the tower as two concurrent forwards

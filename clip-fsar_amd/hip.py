@@ -114,12 +114,14 @@ def _code(dtype):
     raise RuntimeError("clip_fsar_amd.hip: unsupported dtype %s" % dtype)
 
 
-_last_dev = [None]
+import threading
+
+_tls = threading.local()        # per host thread: the device of the operands of the wrapper call in progress
 
 
 def _dev(t, dtype=None, name="tensor"):
     p = _dev_ptr(t, dtype, name)
-    _last_dev[0] = t.device
+    _tls.dev = t.device
     return p
 
 
@@ -127,7 +129,7 @@ def _stream():
     """Stream handle for the launch: the current stream OF THE DEVICE THE OPERANDS LIVE ON (the wrappers evaluate their
     tensor arguments first), and that device must be the thread's current device -- HIP launches go to the current device,
     so a mismatch would run the kernel on the wrong GPU."""
-    d = _last_dev[0]
+    d = getattr(_tls, "dev", None)      # thread-local: two host threads driving two GPUs cannot pick each other's device
     if d is not None and d.index is not None and d.index != torch.cuda.current_device():
         raise RuntimeError("clip_fsar_amd.hip: operands live on %s but the current device is cuda:%d -- wrap the call in "
                            "torch.cuda.device(%d) (one process per GPU sets it once)" % (d, torch.cuda.current_device(), d.index))

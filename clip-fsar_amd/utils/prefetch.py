@@ -31,6 +31,14 @@ class DevicePrefetcher:
     def _stage(self, i, host):
         extra = self.pre_upload(host) if self.pre_upload is not None else None
         tens = {k: v for k, v in host.items() if isinstance(v, torch.Tensor)}
+        if tens and all(v.is_cuda for v in tens.values()):              # already resident: hand it through
+            out = dict(host)
+            if extra:
+                out.update(extra)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+            self._ready[i] = ev
+            return out
         buf = self._bufs[i]
         if buf is None or any(k not in buf or buf[k].shape[1:] != v.shape[1:] or buf[k].dtype != v.dtype or buf[k].shape[0] < v.shape[0]
                               for k, v in tens.items()):
