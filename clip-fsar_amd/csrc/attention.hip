@@ -11,17 +11,25 @@ namespace {
 
 typedef unsigned att_u32x4 __attribute__((ext_vector_type(4)));
 
+// v_mfma_f32_16x16x32_{bf16,f16} by element type (the fp16 numerics mode runs the same kernel on fp16 q / k / v and fp16 P)
+template <typename T>
+__device__ __forceinline__ f32x4 att_mfma(typename Vec2B<T>::v8 a, typename Vec2B<T>::v8 b, f32x4 c) {
+    if constexpr (std::is_same<T, _Float16>::value) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // O^T tile -> global, 16 bytes per lane.  A lane (q = lane&15, g = lane>>4) holds d = 16dt + 4g + r of its query row; lanes g
 // and g^1 hold the two halves of each 8-wide d chunk.  After one exchange with lane^16 (4 dwords each way) the even-g lane owns
 // the chunks of dt 0,1 and the odd-g lane those of dt 2,3: two dwordx4 stores per lane instead of four dwordx2 (the
 // attention epilogue is store-ISSUE bound: 59 of 273 us at 640 frames were the 8-byte stores).
+template <typename T>
 __device__ __forceinline__ void pack_o_tile(const f32x4 (&o)[4], float inv, int g, uint4 (&val)[2]) {
     unsigned pk[4][2];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 v;
+        typename Vec2B<T>::v4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (__bf16)(o[dt][r] * inv);
+        for (int r = 0; r < 4; ++r) v[r] = (T)(o[dt][r] * inv);
         const uint2 u = __builtin_bit_cast(uint2, v);
         pk[dt][0] = u.x;
         pk[dt][1] = u.y;
@@ -40,16 +48,18 @@ __device__ __forceinline__ void pack_o_tile(const f32x4 (&o)[4], float inv, int 
         val[i] = odd ? make_uint4(recv[i][0], recv[i][1], pk[dt][0], pk[dt][1]) : make_uint4(pk[dt][0], pk[dt][1], recv[i][0], recv[i][1]);
     }
 }
-__device__ __forceinline__ void store_o_packed(const uint4 (&val)[2], bool valid, __bf16* orow, int g) {
+template <typename T>
+__device__ __forceinline__ void store_o_packed(const uint4 (&val)[2], bool valid, T* orow, int g) {
     if (valid) {
         const bool odd = g & 1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(orow + (odd ? 2 + i : i) * 16 + (g >> 1) * 8) = val[i];
     }
 }
-__device__ __forceinline__ void store_o_tile(const f32x4 (&o)[4], float inv, bool valid, __bf16* orow, int g) {
+template <typename T>
+__device__ __forceinline__ void store_o_tile(const f32x4 (&o)[4], float inv, bool valid, T* orow, int g) {
     uint4 val[2];
-    pack_o_tile(o, inv, g, val);
+    pack_o_tile<T>(o, inv, g, val);
     store_o_packed(val, valid, orow, g);
 }
 
@@ -120,20 +130,21 @@ struct AttLane {
 // The LDS fragment reads run TWO steps ahead of the MFMAs that consume them (S^T: two 16-key tiles; PV: one 32-key block = 8
 // transpose reads): left to itself hipcc emits read -> wait -> MFMA pairs, and a wave then spends an LDS round trip per MFMA pair
 // (13 + 28 round trips per tile; measured 12.7 K cycles per (frame, head) against 2.8 K of matrix-pipe work).
-template <int NKB, int NTV, int KPF_ = 0>
-__device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const AttLane& L, const bf16x8 (&qf)[2], int ntok,
+template <typename T, int NKB, int NTV, int KPF_ = 0>
+__device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const AttLane& L, const typename Vec2B<T>::v8 (&qf)[2], int ntok,
                                           float scale_log2e, f32x4 (&o)[4], float& inv) {
     constexpr int NT = NKB * 2;
     constexpr int nt_valid = NTV > 0 ? NTV : NT;
     const char* kbase = sK + L.krow;
     const char* vbase = sV + L.vrow;
     const int g = L.g;
+    typedef typename Vec2B<T>::v8 T8;
     f32x4 s[NT];
-    bf16x8 kf[nt_valid][2];
+    T8 kf[nt_valid][2];
     auto kload = [&](auto J) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) kf[j][ks] = *reinterpret_cast<const bf16x8*>(kbase + j * 2048 + L.koff[ks]);
+        for (int ks = 0; ks < 2; ++ks) kf[j][ks] = *reinterpret_cast<const T8*>(kbase + j * 2048 + L.koff[ks]);
     };
     // read-ahead in tiles: two, except that the 288-key instance (72 score registers) affords only one inside a 128-register budget
     constexpr int KPF = KPF_ > 0 ? KPF_ : (NKB >= 9 ? 1 : 2);
@@ -146,7 +157,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
         if constexpr (j < nt_valid) {
             if constexpr (j + KPF < nt_valid) kload(std::integral_constant<int, j + KPF>{});
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j][ks], qf[ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) acc = att_mfma<T>(kf[j][ks], qf[ks], acc);
             __builtin_amdgcn_sched_barrier(0);
         }
         s[j] = acc;
@@ -168,7 +179,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     float sum = 0.f;
     // P fragment of key block kb: exp2 of tiles 2 kb, 2 kb + 1 (raw v_exp_f32), summed in fp32, rounded to bf16
     auto pblock = [&](int kb) __attribute__((always_inline)) {
-        bf16x8 pf;
+        T8 pf;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int j = 2 * kb + t;
@@ -181,7 +192,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
                     asm volatile("" : "+v"(pv) : "v"(z));       // operand pin kept from the round-2 fault hunt (csrc/gemm_vit.hip, above quick_gelu4): no instruction, no measured cost
                     sum += pv;
                 }
-                pf[4 * t + r] = (__bf16)pv;
+                pf[4 * t + r] = (T)pv;
             }
         }
         return pf;
@@ -204,17 +215,17 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     vload(0, vf[0]);
-    bf16x8 pcur = pblock(0);
+    T8 pcur = pblock(0);
     att_static_for<NBLK>([&](auto KB) {
         constexpr int kb = decltype(KB)::value;
-        bf16x8 pnext = pcur;
+        T8 pnext = pcur;
         if constexpr (kb + 1 < NBLK) {
             vload(kb + 1, vf[(kb + 1) & 1]);                      // next block's transpose reads ...
             pnext = pblock(kb + 1);                                // ... and its exponentials, under the MFMAs below
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf[kb & 1][dt]), pcur, o[dt], 0, 0, 0);
+            o[dt] = att_mfma<T>(__builtin_bit_cast(T8, vf[kb & 1][dt]), pcur, o[dt]);
         __builtin_amdgcn_sched_barrier(0);
         pcur = pnext;
     });
@@ -223,8 +234,8 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     inv = __builtin_amdgcn_rcpf(sum);
 }
 
-template <int NKB, int NTV, int NW, int WPS, int KPFK = 0>
-__global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
+template <typename T, int NKB, int NTV, int NW, int WPS, int KPFK = 0>
+__global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                                      int ntok, int D, float scale_log2e, int dbg) {
     constexpr int NT = NKB * 2;                                    // 16-key tiles
     constexpr int nt_valid = NTV > 0 ? NTV : NT;                   // tiles that are computed
@@ -238,7 +249,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const __bf1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t ld = (size_t)3 * D;
-    const __bf16* base = qkv + (size_t)f * ntok * ld + h * 64;
+    typedef typename Vec2B<T>::v8 T8;
+    const T* base = qkv + (size_t)f * ntok * ld + h * 64;
     const char* baseb = reinterpret_cast<const char*>(base);
 
     // ---- stage K and V: piece p = rows 8p .. 8p+7; lane (r = lane >> 3, c = lane & 7) fills LDS chunk c of its row with the
@@ -275,12 +287,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const __bf1
     // Q fragment ("B" operand) of this wave's first tile, in flight while the DMA lands: Q[qrow][32 ks + 8 g .. +8].
     // (Tried: Q by LDS-DMA into a wave-private 2 KiB buffer that then stages the O tile for whole-line stores -- 404 vs 410 us at
     // 1 280 frames, inside the noise, for 14-18 KiB of LDS; removed.)
-    bf16x8 qf[2];
+    T8 qf[2];
     {
         int qrow = wave * 16 + q16;
         qrow = qrow < ntok ? qrow : ntok - 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + ks * 32 + g * 8);
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const T8*>(base + (size_t)qrow * ld + ks * 32 + g * 8);
     }
     // One wait for everything.  (Tried: K first / V under the S phase with counted vmcnt -- LDS-DMA and VGPR loads share the
     // counter but do not retire in one order, so a counted wait across the two kinds is not a guarantee (wrong results), and
@@ -292,12 +304,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const __bf1
         int qrow = qt * 16 + q16;
         const bool qvalid = qrow < ntok;
         if (!qvalid) qrow = ntok - 1;
-        bf16x8 qn[2];                                               // the next tile's Q rows: in flight during this tile's computation
+        T8 qn[2];                                               // the next tile's Q rows: in flight during this tile's computation
         {
             int qr2 = (qt + NW) * 16 + q16;
             qr2 = qr2 < ntok ? qr2 : ntok - 1;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) qn[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qr2 * ld + ks * 32 + g * 8);
+            for (int ks = 0; ks < 2; ++ks) qn[ks] = *reinterpret_cast<const T8*>(base + (size_t)qr2 * ld + ks * 32 + g * 8);
         }
         f32x4 o[4];
         float inv;
@@ -308,9 +320,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const __bf1
             for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{(float)qf[0][0], 0.f, 0.f, (float)qf[1][1]};
         } else
 #endif
-        attn_tile<NKB, NTV, ((KPFK > 0) ? KPFK : ((NKB >= 9 && WPS > 2) ? 1 : 2))>(sK, sV, L, qf, ntok, scale_log2e, o, inv);
+        attn_tile<T, NKB, NTV, ((KPFK > 0) ? KPFK : ((NKB >= 9 && WPS > 2) ? 1 : 2))>(sK, sV, L, qf, ntok, scale_log2e, o, inv);
         // O^T[d][q]: lane owns query q16, d = 16 dt + 4 g + r
-        store_o_tile(o, inv, qvalid, out + ((size_t)f * ntok + qrow) * D + h * 64, g);
+        store_o_tile<T>(o, inv, qvalid, out + ((size_t)f * ntok + qrow) * D + h * 64, g);
         qf[0] = qn[0];
         qf[1] = qn[1];
     }
@@ -411,11 +423,11 @@ __global__ __launch_bounds__((NTV + 1) * 64, 4) void vit_attn_ring_kernel(const 
         }
         f32x4 o[4];
         float inv;
-        attn_tile<NKB, NTV>(sK, sK + KROWS * 128, L, qf, ntok, scale_log2e, o, inv);
+        attn_tile<__bf16, NKB, NTV>(sK, sK + KROWS * 128, L, qf, ntok, scale_log2e, o, inv);
         {
             const int item = first + k * stride;
             const int f = item / heads, h = item - f * heads;
-            store_o_tile(o, inv, qvalid, out + ((size_t)f * ntok + qrow) * D + h * 64, g);
+            store_o_tile<__bf16>(o, inv, qvalid, out + ((size_t)f * ntok + qrow) * D + h * 64, g);
         }
         qf[0] = qn[0];
         qf[1] = qn[1];
@@ -484,15 +496,15 @@ static inline int attn_dbg() {
 #endif
 }
 
-template <int NKB, int NTV, int NW, int WPS, int KPFK = 0>
+template <int NKB, int NTV, int NW, int WPS, int KPFK = 0, typename T = __bf16>
 int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
     constexpr int KROWS = (NTV > 0 ? NTV : NKB * 2) * 16;
     constexpr int LDS = 2 * KROWS * 128;
-    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<NKB, NTV, NW, WPS, KPFK>), LDS, "cfsar_vit_attention")) return rc;
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<T, NKB, NTV, NW, WPS, KPFK>), LDS, "cfsar_vit_attention")) return rc;
     const float scale_log2e = 0.125f * 1.4426950408889634f;
-    hipLaunchKernelGGL((vit_attn_bf16_kernel<NKB, NTV, NW, WPS, KPFK>), dim3(heads, F), dim3(NW * 64), LDS, s,
-                       static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, scale_log2e, attn_dbg());
-    return cfsar_check_launch("cfsar_vit_attention(bf16)");
+    hipLaunchKernelGGL((vit_attn_bf16_kernel<T, NKB, NTV, NW, WPS, KPFK>), dim3(heads, F), dim3(NW * 64), LDS, s,
+                       static_cast<const T*>(qkv), static_cast<T*>(out), ntok, D, scale_log2e, attn_dbg());
+    return cfsar_check_launch("cfsar_vit_attention(16-bit)");
 }
 
 template <int NKB, int NTV>
@@ -561,6 +573,13 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
         if (ntok == 257) return launch_bf16<9, 17, 4, 2, 5>(qkv, out, F, ntok, D, heads, s);
         if (ntok > 224) return launch_bf16<9, 0, 4, 2>(qkv, out, F, ntok, D, heads, s);
         return launch_bf16<7, 0, 7, 4>(qkv, out, F, ntok, D, heads, s);
+    }
+    if (dtype == CFSAR_F16) {                    // the fp16 numerics mode: the same kernel on fp16 q / k / v, P rounded to fp16
+        CFSAR_REQUIRE(ntok <= 288, "cfsar_vit_attention: ntok=%d > 288", ntok);
+        if (ntok == 197) return launch_bf16<7, 13, 8, 4, 3, _Float16>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257) return launch_bf16<9, 17, 4, 2, 5, _Float16>(qkv, out, F, ntok, D, heads, s);
+        if (ntok > 224) return launch_bf16<9, 0, 4, 2, 0, _Float16>(qkv, out, F, ntok, D, heads, s);
+        return launch_bf16<7, 0, 7, 4, 0, _Float16>(qkv, out, F, ntok, D, heads, s);
     }
     if (dtype == CFSAR_F32) {
         const int lds = ntok * 64 * 4 * 2;

@@ -21,6 +21,16 @@ template <> struct Vec2B<float> { typedef f32x4 v4; typedef f32x4 v8; };   // pl
 
 #define CFSAR_WAVE 64
 
+// v_mfma_f32_32x32x16_{bf16,f16} on 16-byte operand fragments, selected by the 2-byte element type
+#include <type_traits>
+template <typename T2>
+__device__ __forceinline__ f32x16 cfsar_mfma_32x32x16(uint4 a, uint4 b, f32x16 c) {
+    if constexpr (std::is_same<T2, _Float16>::value)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 extern thread_local char cfsar_err_buf[512];
 int cfsar_fail(const char* fmt, ...);
 int cfsar_check_launch(const char* what);

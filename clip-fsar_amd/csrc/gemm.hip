@@ -156,8 +156,7 @@ __device__ __forceinline__ void mma_slice(f32x16 (&acc)[2][2], const char* sX, c
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 if constexpr (sizeof(TI) == 2) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]), acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = cfsar_mfma_32x32x16<TI>(wf[ni], xf[mi], acc[mi][ni]);
                 } else {
                     const f32x4 a = __builtin_bit_cast(f32x4, wf[ni]);
                     const f32x4 bb = __builtin_bit_cast(f32x4, xf[mi]);
@@ -426,9 +425,7 @@ __device__ __forceinline__ void mma_slice_db(f32x16 (&acc)[MI][2], const char* s
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 if constexpr (sizeof(TI) == 2) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[cur][ni]),
-                                                                          __builtin_bit_cast(bf16x8, xf[cur][mi]),
-                                                                          acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = cfsar_mfma_32x32x16<TI>(wf[cur][ni], xf[cur][mi], acc[mi][ni]);
                 } else {
                     const f32x4 a = __builtin_bit_cast(f32x4, wf[cur][ni]);
                     const f32x4 bb = __builtin_bit_cast(f32x4, xf[cur][mi]);
@@ -517,8 +514,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     if constexpr (kBf16) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]), acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = cfsar_mfma_32x32x16<TI>(wf[ni], xf[mi], acc[mi][ni]);
                     } else {
                         const f32x4 a = __builtin_bit_cast(f32x4, wf[ni]);
                         const f32x4 bb = __builtin_bit_cast(f32x4, xf[mi]);
@@ -1402,12 +1398,14 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
                              cfsar_stream_t stream) {
     CFSAR_REQUIRE(A && W && out, "cfsar_gemm: null operand");
     CFSAR_REQUIRE(M > 0 && N > 0 && K > 0, "cfsar_gemm: bad shape M=%d N=%d K=%d", M, N, K);
-    CFSAR_REQUIRE(in_dtype == CFSAR_F32 || in_dtype == CFSAR_BF16, "cfsar_gemm: bad in_dtype %d", in_dtype);
+    CFSAR_REQUIRE(in_dtype == CFSAR_F32 || in_dtype == CFSAR_BF16 || in_dtype == CFSAR_F16, "cfsar_gemm: bad in_dtype %d", in_dtype);
     CFSAR_REQUIRE(out_dtype == CFSAR_F32 || out_dtype == CFSAR_BF16 || out_dtype == CFSAR_F16, "cfsar_gemm: bad out_dtype %d", out_dtype);
-    // fp16 output = the residual-stream update of the bf16 mode: bf16 operands, no activation, a residual
-    CFSAR_REQUIRE(out_dtype != CFSAR_F16 || (in_dtype == CFSAR_BF16 && act == CFSAR_ACT_NONE && residual),
-                  "cfsar_gemm: fp16 output needs bf16 operands, no activation and a residual");
-    const int esz = in_dtype == CFSAR_BF16 ? 2 : 4;
+    // fp16 output = a residual-stream update: 16-bit operands, no activation, a residual.  fp16 OPERANDS (the fp16 mode's patch embedding and
+    // small-shape fallbacks; its block GEMMs are cfsar_gemm_lnfold / cfsar_gemm_residual_stats) go to fp16 or fp32 outputs.
+    CFSAR_REQUIRE(out_dtype != CFSAR_F16 || (in_dtype != CFSAR_F32 && act == CFSAR_ACT_NONE && residual),
+                  "cfsar_gemm: fp16 output needs 16-bit operands, no activation and a residual");
+    CFSAR_REQUIRE(in_dtype != CFSAR_F16 || (out_dtype != CFSAR_BF16 && !relu), "cfsar_gemm: fp16 operands write fp16 or fp32 outputs");
+    const int esz = in_dtype == CFSAR_F32 ? 4 : 2;
     const int bk = ROWB / esz;
     CFSAR_REQUIRE(K % bk == 0, "cfsar_gemm: K=%d must be a multiple of %d for this dtype", K, bk);
     CFSAR_REQUIRE(N % 4 == 0, "cfsar_gemm: N=%d must be a multiple of 4", N);
@@ -1444,6 +1442,17 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     constexpr int forced = 0;
 #endif
     const long tiles4 = (long)((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
+    if (in_dtype == CFSAR_F16) {                  // v_mfma_f32_32x32x16_f16: the patch-embed scatter on the 256x128 kernel, anything else on v1
+        if (out_dtype == CFSAR_F16) {
+            if (M >= 1024 && (row_group > 0 || res_mod > 0)) {
+                GemmArgs b = a;
+                b.tiles_n = (N + BN2 - 1) / BN2;
+                return launch_p3_inst<_Float16, _Float16, CFSAR_ACT_NONE, true, true>(b, s);
+            }
+            return launch<_Float16, _Float16>(a, s);
+        }
+        return launch<_Float16, float>(a, s);
+    }
     // fp32, at most 192 rows: the skinny kernel (the temporal head and the final ViT projection of one or two episodes)
     if (in_dtype == CFSAR_F32 && out_dtype == CFSAR_F32 && res_dtype == CFSAR_F32 && res_mod == 0 && K % 32 == 0 &&
         lda % 4 == 0 && ldw % 4 == 0 && M <= 256 && (forced == 14 || (forced == 0 && M <= 192)))
@@ -1457,7 +1466,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
         c.A = A; c.W = W; c.out = out; c.bias = bias; c.res = residual;
         c.rowstats = nullptr; c.cvec = nullptr; c.stats_out = nullptr;
         c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = ldr;
-        c.out_dtype = out_dtype; c.res_dtype = res_dtype; c.act = act; c.relu = relu;
+        c.in_dtype = in_dtype; c.out_dtype = out_dtype; c.res_dtype = res_dtype; c.act = act; c.relu = relu;
         c.opath = cfsar_vit_policy_opath(K);
         c.store = residual ? 0 : 2;
         c.group = kVitGroup; c.colfast = kVitColfast; c.dbg = 0;

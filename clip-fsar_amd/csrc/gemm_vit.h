@@ -40,7 +40,7 @@ struct VitGemmCall {          // host-side request
     const float* cvec;
     float* stats_out;
     int M, N, K, lda, ldw, ldo, ldr;
-    int out_dtype, res_dtype, act, relu;
+    int in_dtype, out_dtype, res_dtype, act, relu;      // in_dtype: A / W (bf16, or fp16 in the fp16 numerics mode and LN-folded)
     int opath, store;         // operand path (0 register-staged, 1 LDS-DMA), store policy (0 default, 1 nt, 2 sc1; dev builds)
     int group, colfast;
     int dbg;

@@ -731,11 +731,20 @@ int launch_inst(const VitGemmArgs& a, hipStream_t s) {
     return launch_inst2<TI, TO, ACT, MODE, OPATH, STORE, false>(a, s);
 }
 
-// mode: 0 bias -> bf16, 1 residual -> fp16 in place, 2 LN-folded (fp16 operands) -> bf16
+// mode: 0 bias -> bf16, 1 residual -> fp16 in place, 2 LN-folded (fp16 operands) -> bf16; f16io (the fp16 numerics mode): fp16
+// operands in mode 1, fp16 output in mode 2
 template <int OPATH, int STORE>
-int launch_path(const VitGemmArgs& a, int mode, hipStream_t s) {
-    if (mode == 1) return launch_inst<__bf16, _Float16, CFSAR_ACT_NONE, 1, OPATH, STORE>(a, s);
+int launch_path(const VitGemmArgs& a, int mode, bool f16io, hipStream_t s) {
+    if (mode == 1) {
+        if (f16io) return launch_inst<_Float16, _Float16, CFSAR_ACT_NONE, 1, OPATH, STORE>(a, s);
+        return launch_inst<__bf16, _Float16, CFSAR_ACT_NONE, 1, OPATH, STORE>(a, s);
+    }
     if (mode == 2) {
+        if (f16io) {
+            if (a.hb_tokens > 0) return -2;
+            if (a.act == CFSAR_ACT_QUICKGELU) return launch_inst<_Float16, _Float16, CFSAR_ACT_QUICKGELU, 2, OPATH, STORE>(a, s);
+            return launch_inst<_Float16, _Float16, CFSAR_ACT_NONE, 2, OPATH, STORE>(a, s);
+        }
         if (a.act == CFSAR_ACT_QUICKGELU) return launch_inst<_Float16, __bf16, CFSAR_ACT_QUICKGELU, 2, OPATH, STORE>(a, s);
         if (a.hb_tokens > 0) return launch_inst<_Float16, __bf16, CFSAR_ACT_NONE, 4, OPATH, STORE>(a, s);
         return launch_inst<_Float16, __bf16, CFSAR_ACT_NONE, 2, OPATH, STORE>(a, s);
@@ -756,8 +765,11 @@ static long long* g_trace = nullptr;
 // Returns -2 when the call is outside this kernel's contract (the caller falls back to the generic kernels of gemm.hip).
 int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     const bool lnfold = c.rowstats != nullptr;
+    const bool f16io = lnfold ? c.out_dtype == CFSAR_F16 : c.in_dtype == CFSAR_F16;     // the fp16 numerics mode (see launch_path)
     const bool f16res = !lnfold && c.out_dtype == CFSAR_F16 && c.res && c.res_dtype == CFSAR_F16 && c.act == CFSAR_ACT_NONE;
-    const bool bf16plain = c.out_dtype == CFSAR_BF16 && !c.res && (c.act == CFSAR_ACT_NONE || c.act == CFSAR_ACT_QUICKGELU);
+    const bool bf16plain = (c.out_dtype == CFSAR_BF16 || (lnfold && c.out_dtype == CFSAR_F16)) && !c.res &&
+                           (c.act == CFSAR_ACT_NONE || c.act == CFSAR_ACT_QUICKGELU);
+    if (!lnfold && c.in_dtype == CFSAR_F16 && !f16res) return -2;
     if (!(f16res || bf16plain) || !c.bias || c.relu) return -2;
     if (lnfold && (!bf16plain || !c.cvec)) return -2;
     if (c.stats_out && !f16res) return -2;
@@ -797,15 +809,15 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     if (mode == 0 && c.act == CFSAR_ACT_NONE && (c.dbg & 64)) mode = 3;
 #endif
     switch (c.opath * 4 + c.store) {
-        case 0: return launch_path<0, 0>(a, mode, s);
-        case 2: return launch_path<0, 2>(a, mode, s);
-        case 4: return launch_path<1, 0>(a, mode, s);
-        case 6: return launch_path<1, 2>(a, mode, s);
-        case 8: return launch_path<2, 0>(a, mode, s);
-        case 10: return launch_path<2, 2>(a, mode, s);
+        case 0: return launch_path<0, 0>(a, mode, f16io, s);
+        case 2: return launch_path<0, 2>(a, mode, f16io, s);
+        case 4: return launch_path<1, 0>(a, mode, f16io, s);
+        case 6: return launch_path<1, 2>(a, mode, f16io, s);
+        case 8: return launch_path<2, 0>(a, mode, f16io, s);
+        case 10: return launch_path<2, 2>(a, mode, f16io, s);
 #ifdef CFSAR_DEV
-        case 1: return launch_path<0, 1>(a, mode, s);
-        case 5: return launch_path<1, 1>(a, mode, s);
+        case 1: return launch_path<0, 1>(a, mode, f16io, s);
+        case 5: return launch_path<1, 1>(a, mode, f16io, s);
 #endif
         default: return -2;
     }
@@ -843,8 +855,9 @@ extern "C" void cfsar_debug_set_vit_trace(void* trace, int stagger_unit) { g_tra
 
 // out = act(LayerNorm(x; gamma, beta) W^T + bias) with the LayerNorm folded into the GEMM (MODE 2 above).  See the header.
 static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
-                            const float* rowstats, int M, int N, int K, int lda, int ldw, int ldo, int act, int hb_tokens, int hb_heads,
-                            cfsar_stream_t stream) {
+                            const float* rowstats, int M, int N, int K, int lda, int ldw, int ldo, int act, int out_dtype, int hb_tokens,
+                            int hb_heads, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(out_dtype == CFSAR_BF16 || out_dtype == CFSAR_F16, "cfsar_gemm_lnfold: out_dtype must be bf16 or fp16, got %d", out_dtype);
     CFSAR_REQUIRE(x && Wg && out && cvec && dvec && rowstats, "cfsar_gemm_lnfold: null pointer");
     CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_lnfold: bad shape M=%d N=%d K=%d (K %% 64, N %% 64, K >= 128)", M, N, K);
     CFSAR_REQUIRE(lda >= K && ldw >= K && ldo >= N && lda % 8 == 0 && ldw % 8 == 0 && ldo % 8 == 0, "cfsar_gemm_lnfold: bad leading dimension");
@@ -852,7 +865,7 @@ static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const floa
     VitGemmCall c;
     c.A = x; c.W = Wg; c.out = out; c.bias = dvec; c.res = nullptr; c.rowstats = rowstats; c.cvec = cvec; c.stats_out = nullptr;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = 0;
-    c.out_dtype = CFSAR_BF16; c.res_dtype = CFSAR_F32; c.act = act; c.relu = 0;
+    c.out_dtype = out_dtype; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F32; c.act = act; c.relu = 0;
     c.opath = vit_policy_opath(K); c.store = vit_policy_store(2); c.group = 8; c.colfast = 0; c.dbg = 0;
     c.hb_tokens = hb_tokens; c.hb_heads = hb_heads; c.ha_tokens = 0;
 #ifdef CFSAR_DEV
@@ -863,9 +876,9 @@ static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const floa
 }
 
 extern "C" int cfsar_gemm_lnfold(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
-                                 const float* rowstats, int M, int N, int K, int lda, int ldw, int ldo, int act,
+                                 const float* rowstats, int M, int N, int K, int lda, int ldw, int ldo, int act, int out_dtype,
                                  cfsar_stream_t stream) {
-    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats, M, N, K, lda, ldw, ldo, act, 0, 0, stream);
+    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream);
 }
 
 // The QKV form with head-blocked output: out[((f heads + h) tokens + t) * 192 + 64 which + c] (see the header).
@@ -875,20 +888,21 @@ extern "C" int cfsar_gemm_lnfold_heads(const void* x, const void* Wg, void* out,
     CFSAR_REQUIRE(tokens >= 128 && heads > 0 && N == 192 * heads && M % tokens == 0,
                   "cfsar_gemm_lnfold_heads: needs tokens >= 128, N = 192 heads, M a multiple of tokens (M=%d N=%d tokens=%d heads=%d)", M, N,
                   tokens, heads);
-    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats, M, N, K, lda, ldw, N, CFSAR_ACT_NONE, tokens, heads, stream);
+    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats, M, N, K, lda, ldw, N, CFSAR_ACT_NONE, CFSAR_BF16, tokens, heads, stream);
 }
 
 // x = x + A W^T + bias (fp16 residual stream, in place) and, if stats_partial != NULL, the per-row partial LayerNorm
 // statistics of the NEW x: stats_partial[m][n / 64] = (sum, sum of squares) over columns [64 (n/64), +64).  See the header.
 static int gemm_residual_stats_impl(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M,
-                                    int N, int K, int lda, int ldw, int ldx, int ha_tokens, cfsar_stream_t stream) {
+                                    int N, int K, int lda, int ldw, int ldx, int in_dtype, int ha_tokens, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(in_dtype == CFSAR_BF16 || in_dtype == CFSAR_F16, "cfsar_gemm_residual_stats: in_dtype must be bf16 or fp16, got %d", in_dtype);
     CFSAR_REQUIRE(A && W && x && bias, "cfsar_gemm_residual_stats: null pointer");
     CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_residual_stats: bad shape M=%d N=%d K=%d", M, N, K);
     CFSAR_REQUIRE(lda >= K && ldw >= K && ldx >= N && lda % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, "cfsar_gemm_residual_stats: bad leading dimension");
     VitGemmCall c;
     c.A = A; c.W = W; c.out = x; c.bias = bias; c.res = x; c.rowstats = nullptr; c.cvec = nullptr; c.stats_out = stats_partial;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldx; c.ldr = ldx;
-    c.out_dtype = CFSAR_F16; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
+    c.out_dtype = CFSAR_F16; c.in_dtype = in_dtype; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
     c.opath = vit_policy_opath(K); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;
     c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = ha_tokens;
     const int rc = cfsar_gemm_vit_try(c, static_cast<hipStream_t>(stream));
@@ -896,13 +910,13 @@ static int gemm_residual_stats_impl(const void* A, const void* W, void* x, const
 }
 
 extern "C" int cfsar_gemm_residual_stats(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M,
-                                         int N, int K, int lda, int ldw, int ldx, cfsar_stream_t stream) {
-    return gemm_residual_stats_impl(A, W, x, bias, stats_partial, M, N, K, lda, ldw, ldx, 0, stream);
+                                         int N, int K, int lda, int ldw, int ldx, int in_dtype, cfsar_stream_t stream) {
+    return gemm_residual_stats_impl(A, W, x, bias, stats_partial, M, N, K, lda, ldw, ldx, in_dtype, 0, stream);
 }
 
 // The out_proj form: A is the attention output in head-blocked layout A[((f heads + h) tokens + t) * 64 + c], heads = K / 64.
 extern "C" int cfsar_gemm_residual_stats_heads(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M,
                                                int N, int K, int ldw, int ldx, int tokens, cfsar_stream_t stream) {
     CFSAR_REQUIRE(tokens >= 8 && M % tokens == 0, "cfsar_gemm_residual_stats_heads: M=%d is not a multiple of tokens=%d", M, tokens);
-    return gemm_residual_stats_impl(A, W, x, bias, stats_partial, M, N, K, K, ldw, ldx, tokens, stream);
+    return gemm_residual_stats_impl(A, W, x, bias, stats_partial, M, N, K, K, ldw, ldx, CFSAR_BF16, tokens, stream);
 }

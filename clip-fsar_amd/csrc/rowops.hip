@@ -29,10 +29,11 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ f
             v = *reinterpret_cast<const float2*>(src);
         }
         if constexpr (sizeof(TO) == 2) {
-            bf16x2 o;
-            o[0] = (__bf16)v.x;
-            o[1] = (__bf16)v.y;
-            *reinterpret_cast<bf16x2*>(out + row * k_pad + k) = o;
+            typedef TO to2 __attribute__((ext_vector_type(2)));
+            to2 o;
+            o[0] = (TO)v.x;
+            o[1] = (TO)v.y;
+            *reinterpret_cast<to2*>(out + row * k_pad + k) = o;
         } else {
             *reinterpret_cast<float2*>(out + row * k_pad + k) = v;
         }
@@ -43,8 +44,10 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ f
 // sector) -> 16 bf16 (two 16-byte stores).  Lane = dy + 16 * (patch within a group of 4): 16 consecutive lanes write 512 contiguous
 // bytes of one output row, a wave instruction writes 4 x 512 B and reads 64 whole 64-byte sectors.  No division in the inner path
 // (grid.y = frame x channel, grid.x walks patches).  2.85 -> ~5 TB/s on 1 280 frames.
-__global__ __launch_bounds__(256) void im2col_p16_bf16_kernel(const float* __restrict__ frames, __bf16* __restrict__ out, int H, int W,
+template <typename TO>
+__global__ __launch_bounds__(256) void im2col_p16_bf16_kernel(const float* __restrict__ frames, TO* __restrict__ out, int H, int W,
                                                               int k_pad) {
+    typedef typename Vec2B<TO>::v8 TO8;
     const int gw = W >> 4, gh = H >> 4, npatch = gw * gh;
     const int fc = blockIdx.y;                       // frame * 3 + channel
     const int f = fc / 3, c = fc - 3 * f;
@@ -54,14 +57,14 @@ __global__ __launch_bounds__(256) void im2col_p16_bf16_kernel(const float* __res
     const int py = p / gw, px = p - py * gw;
     const float4* src = reinterpret_cast<const float4*>(frames + ((size_t)fc * H + (py * 16 + dy)) * W + px * 16);
     const float4 a = src[0], b = src[1], c4 = src[2], d = src[3];
-    bf16x8 lo, hi8;
-    lo[0] = (__bf16)a.x; lo[1] = (__bf16)a.y; lo[2] = (__bf16)a.z; lo[3] = (__bf16)a.w;
-    lo[4] = (__bf16)b.x; lo[5] = (__bf16)b.y; lo[6] = (__bf16)b.z; lo[7] = (__bf16)b.w;
-    hi8[0] = (__bf16)c4.x; hi8[1] = (__bf16)c4.y; hi8[2] = (__bf16)c4.z; hi8[3] = (__bf16)c4.w;
-    hi8[4] = (__bf16)d.x; hi8[5] = (__bf16)d.y; hi8[6] = (__bf16)d.z; hi8[7] = (__bf16)d.w;
-    __bf16* dst = out + ((size_t)f * npatch + p) * k_pad + c * 256 + dy * 16;
-    *reinterpret_cast<bf16x8*>(dst) = lo;
-    *reinterpret_cast<bf16x8*>(dst + 8) = hi8;
+    TO8 lo, hi8;
+    lo[0] = (TO)a.x; lo[1] = (TO)a.y; lo[2] = (TO)a.z; lo[3] = (TO)a.w;
+    lo[4] = (TO)b.x; lo[5] = (TO)b.y; lo[6] = (TO)b.z; lo[7] = (TO)b.w;
+    hi8[0] = (TO)c4.x; hi8[1] = (TO)c4.y; hi8[2] = (TO)c4.z; hi8[3] = (TO)c4.w;
+    hi8[4] = (TO)d.x; hi8[5] = (TO)d.y; hi8[6] = (TO)d.z; hi8[7] = (TO)d.w;
+    TO* dst = out + ((size_t)f * npatch + p) * k_pad + c * 256 + dy * 16;
+    *reinterpret_cast<TO8*>(dst) = lo;
+    *reinterpret_cast<TO8*>(dst + 8) = hi8;
 }
 
 template <typename TX>
@@ -433,13 +436,19 @@ extern "C" int cfsar_im2col_patches(const float* frames, void* out, int out_dtyp
     long long blocks = (pairs + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (out_dtype == CFSAR_BF16 && P == 16 && k_pad == 768 && W % 16 == 0 && (long long)F * 3 <= 65535) {
+    if ((out_dtype == CFSAR_BF16 || out_dtype == CFSAR_F16) && P == 16 && k_pad == 768 && W % 16 == 0 && (long long)F * 3 <= 65535) {
         const int npatch = (H / 16) * (W / 16);
-        hipLaunchKernelGGL(im2col_p16_bf16_kernel, dim3((unsigned)((npatch + 15) / 16), (unsigned)(F * 3)), dim3(256), 0, s, frames,
-                           static_cast<__bf16*>(out), H, W, k_pad);
+        const dim3 grid((unsigned)((npatch + 15) / 16), (unsigned)(F * 3));
+        if (out_dtype == CFSAR_BF16)
+            hipLaunchKernelGGL(im2col_p16_bf16_kernel<__bf16>, grid, dim3(256), 0, s, frames, static_cast<__bf16*>(out), H, W, k_pad);
+        else
+            hipLaunchKernelGGL(im2col_p16_bf16_kernel<_Float16>, grid, dim3(256), 0, s, frames, static_cast<_Float16*>(out), H, W, k_pad);
         return cfsar_check_launch("cfsar_im2col_patches");
     }
-    if (out_dtype == CFSAR_BF16)
+    if (out_dtype == CFSAR_F16)
+        hipLaunchKernelGGL((im2col_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, s, frames,
+                           static_cast<_Float16*>(out), F, H, W, P, k_pad, pairs);
+    else if (out_dtype == CFSAR_BF16)
         hipLaunchKernelGGL((im2col_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, s, frames,
                            static_cast<__bf16*>(out), F, H, W, P, k_pad, pairs);
     else if (out_dtype == CFSAR_F32)

@@ -32,20 +32,25 @@ class HipViT:
     """CLIP VisionTransformer.forward (reference few_shot.py:671-688) on the HIP kernels."""
 
     def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda", stream_dtype=None):
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision not in ("bf16", "fp16", "fp32"):
+            raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
         self.arch = dict(arch)
         self.precision = precision
         self.dev = torch.device(device)
-        self.cd = torch.bfloat16 if precision == "bf16" else torch.float32
+        # compute dtype of the 16-bit modes: bf16 = throughput mode; fp16 = the same kernels on IEEE half operands everywhere (weights,
+        # patches, q / k / v, attention probabilities and output, MLP hidden): 3 more mantissa bits for ~3-6 % of the throughput (the
+        # fp16 multipliers toggle more bits: the chip runs these kernels power-limited) -- the 16-bit mode that meets the 1e-3 logits
+        # tolerance (profiles/r03_parity_table.md).  Range: |x| < 65 504; checked for the weights below, the LN-fold guard covers the
+        # folded vectors, activations of CLIP-scale weights are O(1) ... O(100).
+        self.cd = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[precision]
         # residual stream: fp32 in the validation mode.  The bf16 mode keeps it in IEEE fp16, as CLIP's own GPU path does
         # (fp16 model, few_shot.py:605-611 casts LayerNorm to fp32 and back): out_proj / c_proj / LayerNorm are bound by the
         # stream's bytes, and on top of bf16 operands the fp16 rounding is not measurable (feature rms error 0.0064 with an
         # fp16 stream vs 0.0067 with an fp32 one, against 0.0092 for a bf16 stream; DESIGN.md "Numerics modes").
         if stream_dtype is None:
-            stream_dtype = os.environ.get("CFSAR_STREAM", "fp16" if precision == "bf16" else "fp32")
-        if stream_dtype not in ("fp16", "fp32") or (precision == "fp32" and stream_dtype != "fp32"):
-            raise ValueError("stream_dtype must be 'fp32' (any precision) or 'fp16' (bf16 precision only)")
+            stream_dtype = "fp16" if precision == "fp16" else os.environ.get("CFSAR_STREAM", "fp16" if precision == "bf16" else "fp32")
+        if stream_dtype not in ("fp16", "fp32") or (precision == "fp32" and stream_dtype != "fp32") or (precision == "fp16" and stream_dtype != "fp16"):
+            raise ValueError("stream_dtype must be 'fp32' (bf16 / fp32 precision) or 'fp16' (bf16 / fp16 precision)")
         self.xd = torch.float16 if stream_dtype == "fp16" else torch.float32
         D, P = arch["width"], arch["patch"]
         if D != arch["heads"] * 64:
@@ -53,7 +58,7 @@ class HipViT:
         self.D, self.P, self.L, self.H, self.E = D, P, arch["layers"], arch["heads"], arch["embed"]
         self.grid = arch["res"] // P
         self.ntok = self.grid * self.grid + 1
-        kq = 64 if precision == "bf16" else 32
+        kq = 32 if precision == "fp32" else 64
         self.kpad = _round_up(3 * P * P, kq)
 
         def g(name):
@@ -86,8 +91,15 @@ class HipViT:
         #     LN(x) W^T + b = (x (W diag(gamma))^T - mean c) / std + d,    c_n = sum_k Wg[n,k],   d = W beta + b;
         # out_proj / c_proj emit the row statistics of the stream they write (cfsar_gemm_residual_stats).  Weight folding is
         # init-time host logic (like the BatchNorm folding of the RN50 tower).  CFSAR_LN_FOLD=0 keeps the separate LN kernels.
-        self.fold = (precision == "bf16" and self.xd == torch.float16 and D % 64 == 0 and D >= 128
-                     and os.environ.get("CFSAR_LN_FOLD", "1") != "0")
+        self.fold = (precision in ("bf16", "fp16") and self.xd == torch.float16 and D % 64 == 0 and D >= 128
+                     and (precision == "fp16" or os.environ.get("CFSAR_LN_FOLD", "1") != "0"))
+        if precision == "fp16":
+            if not self.fold:
+                raise ValueError("precision 'fp16' needs the LayerNorm-folded block (width a multiple of 64, >= 128)")
+            wmax16 = max(float(blk[k].float().abs().max()) for blk in self.blocks for k in ("w_out", "w_pr"))
+            wmax16 = max(wmax16, float(self.w_patch.float().abs().max()))
+            if not wmax16 < 6.0e4:
+                raise ValueError("precision 'fp16': a weight exceeds the fp16 range (max |w| = %.3g); use 'bf16' or 'fp32'" % wmax16)
         if self.fold:
             for i, blk in enumerate(self.blocks):
                 b = "transformer.resblocks.%d." % i
@@ -105,6 +117,9 @@ class HipViT:
             wmax = max(float(max(blk[k].float().abs().max() for k in ("wg_qkv", "wg_fc"))) for blk in self.blocks)
             if not (big < 3.0e4 and wmax < 6.0e4):
                 import warnings
+                if precision == "fp16":
+                    raise ValueError("precision 'fp16': folded weights / vectors exceed the fp16 range (max |c|,|d| = %.3g, "
+                                     "max |W gamma| = %.3g); use 'bf16' or 'fp32'" % (big, wmax))
                 warnings.warn("LayerNorm folding disabled: folded weights / vectors exceed the fp16 range (max |c|,|d| = %.3g, "
                               "max |W gamma| = %.3g); using the unfolded block" % (big, wmax))
                 self.fold = False

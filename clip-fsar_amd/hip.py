@@ -32,8 +32,8 @@ SIGNATURES = {
     "cfsar_cls_rows_ex": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_gemm": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 15 + [_c_p],
     "cfsar_gemm_ex": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 17 + [_c_p],
-    "cfsar_gemm_lnfold": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
-    "cfsar_gemm_residual_stats": [_c_p] * 5 + [_c_int] * 6 + [_c_p],
+    "cfsar_gemm_lnfold": [_c_p] * 6 + [_c_int] * 8 + [_c_p],
+    "cfsar_gemm_residual_stats": [_c_p] * 5 + [_c_int] * 7 + [_c_p],
     "cfsar_gemm_lnfold_heads": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
     "cfsar_gemm_residual_stats_heads": [_c_p] * 5 + [_c_int] * 6 + [_c_p],
     "cfsar_ln_stats_finalize": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p],
@@ -151,7 +151,7 @@ def preprocess_frames(frames_u8, out, scale_hw, crop, y0, x0, mean, std):
 
 # ----------------------------------------------------------------------------------------------- ViT tower ops
 def im2col_patches(frames, out, patch):
-    """frames [F,3,H,W] f32 -> out [F*(H/P)*(W/P), k_pad] (f32|bf16), zero-padded columns."""
+    """frames [F,3,H,W] f32 -> out [F*(H/P)*(W/P), k_pad] (f32 | bf16 | fp16), zero-padded columns."""
     F_, C, H, W = frames.shape
     assert C == 3
     _check(lib().cfsar_im2col_patches(_dev(frames, torch.float32, "frames"), _dev(out, None, "out"), _code(out.dtype),
@@ -198,20 +198,26 @@ def gemm(A, W, out, bias=None, residual=None, act=ACT_NONE, M=None, N=None, K=No
 
 
 def gemm_lnfold(x, Wg, out, cvec, dvec, rowstats, act=ACT_NONE, M=None):
-    """out = act(LayerNorm(x) @ W.T + bias) with the LayerNorm folded into the GEMM (include/clipfsar_hip.h: cfsar_gemm_lnfold)."""
+    """out = act(LayerNorm(x) @ W.T + bias) with the LayerNorm folded into the GEMM (include/clipfsar_hip.h: cfsar_gemm_lnfold).
+    out is bf16 (throughput mode) or fp16 (fp16 numerics mode)."""
     M = x.shape[0] if M is None else M
-    _check(lib().cfsar_gemm_lnfold(_dev(x, torch.float16, "x"), _dev(Wg, torch.float16, "Wg"), _dev(out, torch.bfloat16, "out"),
+    if out.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError("gemm_lnfold: out must be bf16 or fp16, got %s" % out.dtype)
+    _check(lib().cfsar_gemm_lnfold(_dev(x, torch.float16, "x"), _dev(Wg, torch.float16, "Wg"), _dev(out, None, "out"),
                                    _dev(cvec, torch.float32, "cvec"), _dev(dvec, torch.float32, "dvec"),
                                    _dev(rowstats, torch.float32, "rowstats"), M, Wg.shape[0], Wg.shape[1], x.shape[1],
-                                   Wg.shape[1], out.shape[1], act, _stream()), "cfsar_gemm_lnfold")
+                                   Wg.shape[1], out.shape[1], act, _code(out.dtype), _stream()), "cfsar_gemm_lnfold")
 
 
 def gemm_residual_stats(A, W, x, bias, stats_partial=None, M=None):
-    """x += A @ W.T + bias in place (fp16 stream) + optional partial LayerNorm statistics of the new x."""
+    """x += A @ W.T + bias in place (fp16 stream) + optional partial LayerNorm statistics of the new x.  A and W: bf16, or fp16 in
+    the fp16 numerics mode."""
     M = A.shape[0] if M is None else M
-    _check(lib().cfsar_gemm_residual_stats(_dev(A, torch.bfloat16, "A"), _dev(W, torch.bfloat16, "W"), _dev(x, torch.float16, "x"),
+    if A.dtype != W.dtype or A.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError("gemm_residual_stats: A and W must both be bf16 or both fp16 (%s, %s)" % (A.dtype, W.dtype))
+    _check(lib().cfsar_gemm_residual_stats(_dev(A, None, "A"), _dev(W, None, "W"), _dev(x, torch.float16, "x"),
                                            _dev(bias, torch.float32, "bias"), _opt(stats_partial, torch.float32, "stats_partial"),
-                                           M, W.shape[0], W.shape[1], A.shape[1], W.shape[1], x.shape[1], _stream()),
+                                           M, W.shape[0], W.shape[1], A.shape[1], W.shape[1], x.shape[1], _code(A.dtype), _stream()),
            "cfsar_gemm_residual_stats")
 
 

@@ -196,10 +196,10 @@ int cfsar_cos_otam_logits(const float* Xq, const float* protos, float* logits, f
  * out[m,n] = act(sum_k LN(x)[m,k] W[n,k] + bias[n]) computed on the RAW fp16 residual stream, without materialising LN(x):
  *     LN(x) W^T + bias = (x Wg^T - mean_m c_n) / std_m + d_n,   Wg = W diag(gamma),  c_n = sum_k Wg[n,k],
  *     d_n = sum_k beta_k W[n,k] + bias_n      (Wg, c, d are prepared once by the caller; c must be the sum of the ROUNDED Wg).
- * x [M, lda] fp16, Wg [N, ldw] fp16, out [M, ldo] bf16, cvec / dvec [N] fp32, rowstats [M, 4] fp32 = (mean, std, 1/std, -) of each
+ * x [M, lda] fp16, Wg [N, ldw] fp16, out [M, ldo] out_dtype (bf16; fp16 in the fp16 numerics mode), cvec / dvec [N] fp32, rowstats [M, 4] fp32 = (mean, std, 1/std, -) of each
  * row of x (cfsar_row_stats / cfsar_ln_stats_finalize).  K % 64 == 0, K >= 128, N % 64 == 0; act = NONE | QUICKGELU. */
 int cfsar_gemm_lnfold(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec, const float* rowstats,
-                      int M, int N, int K, int lda, int ldw, int ldo, int act, cfsar_stream_t stream);
+                      int M, int N, int K, int lda, int ldw, int ldo, int act, int out_dtype, cfsar_stream_t stream);
 
 /* The QKV form of cfsar_gemm_lnfold with HEAD-BLOCKED output (act = NONE, N = 192 heads: q | k | v, tokens per frame >= 128,
  * M a multiple of tokens): row m = f tokens + t, column n = 64 (which heads + h) + c is written to
@@ -211,11 +211,11 @@ int cfsar_gemm_lnfold_heads(const void* x, const void* Wg, void* out, const floa
                             int M, int N, int K, int lda, int ldw, int tokens, int heads, cfsar_stream_t stream);
 
 /* ---- A5/A6 residual update + the statistics of the next LayerNorm (few_shot.py:633-635 / :639-640 followed by :636 / :626).
- * x[m,n] = x[m,n] + sum_k A[m,k] W[n,k] + bias[n] in place on the fp16 residual stream (A, W bf16).  If stats_partial != NULL it
+ * x[m,n] = x[m,n] + sum_k A[m,k] W[n,k] + bias[n] in place on the fp16 residual stream (A, W of in_dtype: bf16 or fp16).  If stats_partial != NULL it
  * receives, per row m and 64-column slot s = n / 64, (sum, sum of squares) of the NEW (rounded) x[m, 64 s .. 64 s + 63]:
  * [M, N / 64, 2] fp32.  Deterministic (no atomics).  K % 64 == 0, K >= 128, N % 64 == 0. */
 int cfsar_gemm_residual_stats(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M, int N,
-                              int K, int lda, int ldw, int ldx, cfsar_stream_t stream);
+                              int K, int lda, int ldw, int ldx, int in_dtype, cfsar_stream_t stream);
 
 /* The out_proj form of cfsar_gemm_residual_stats whose A operand is the head-blocked attention output
  * A[((f heads + h) tokens + t) * 64 + c], heads = K / 64 (K tile kt of the GEMM = head kt), M a multiple of tokens. */

@@ -3,8 +3,11 @@ the real reference and (b) the CPU oracle, for every golden case; layer-by-layer
 consistency; the registry/builder drop-in surface.
 
 Tolerances: fp32 mode -- logits within 1e-3 of the reference (north star); observed ~1e-5.
-            bf16 mode -- deviation is REPORTED; the test bounds it at 0.05 absolute (observed <= 0.024) on logits whose
-            spread is ~1-3, and requires the fp32-mode argmax to be reproduced on clearly separated queries.
+            fp16 mode -- the 16-bit mode that meets the north star on the ViT-B/16 configurations: cfg2 / cfg3 asserted < 1e-3 (measured
+            7.6e-4 / 7.5e-4); ViT-L/14 (cfg4, 24 layers, an extension the reference head rejects) and the tiny test architectures are
+            bounded at 2 x their measured deviation (tests/_cases.py: MEASURED_DLOGITS).
+            bf16 mode -- deviation is REPORTED; every case is bounded at 2 x its measured deviation (3e-3 ... 2.3e-2 on
+            logits whose spread is ~1-3), and the fp32-mode argmax must be reproduced on clearly separated queries.
 """
 import json
 import os
@@ -17,7 +20,8 @@ pytestmark = pytest.mark.gpu
 
 import clip_fsar_amd.synth as synth  # noqa: E402
 import clipfsar_oracle as orc  # noqa: E402
-from _cases import GOLD, SMALL_CASES, case_inputs, load_golden, maxdiff, run_engine  # noqa: E402
+from _cases import GOLD, SMALL_CASES, bound, case_inputs, load_golden, maxdiff, run_engine  # noqa: E402
+from clip_fsar_amd import LOGITS_TOLERANCE, NORTH_STAR_TOLERANCE  # noqa: E402
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -69,11 +73,32 @@ def test_small_cases_bf16_bounded(name):
     m = g["meta"]
     a, sd, tt, te, ep = case_inputs(m)
     logits, cl = run_engine(m, a, sd, tt, te, [ep], "bf16")
-    assert maxdiff(logits[0], g["logits"]) < 0.05
+    assert maxdiff(logits[0], g["logits"]) < bound(name, "bf16")
     ref = torch.from_numpy(g["logits"])
     top2 = ref.topk(2, dim=1).values
     clear = (top2[:, 0] - top2[:, 1]) > 0.3                      # queries whose decision is not marginal
     assert torch.equal(logits[0].argmax(1)[clear], ref.argmax(1)[clear])
+
+
+@pytest.mark.parametrize("name", [n for n in SMALL_CASES if not n.startswith("rn")])
+def test_small_cases_fp16_bounded(name):
+    """precision "fp16" (IEEE-half operands everywhere) on the small ViT cases: about 4 x closer to the reference than bf16."""
+    g = load_golden(name)
+    m = g["meta"]
+    a, sd, tt, te, ep = case_inputs(m)
+    logits, cl = run_engine(m, a, sd, tt, te, [ep], "fp16")
+    assert maxdiff(logits[0], g["logits"]) < bound(name, "fp16")
+    ref = torch.from_numpy(g["logits"])
+    assert torch.equal(logits[0].argmax(1), ref.argmax(1))
+
+
+def test_fp16_mode_refuses_what_it_cannot_represent():
+    """The RN50 tower has no fp16 path; the engine says so instead of silently running bf16."""
+    g = load_golden("rn_t_5w2s_T4")
+    m = g["meta"]
+    a, sd, tt, te, ep = case_inputs(m)
+    with pytest.raises(ValueError, match="precision"):
+        run_engine(m, a, sd, tt, te, [ep], "fp16")
 
 
 def test_batched_episodes_match_single(tmp_path):
@@ -105,7 +130,10 @@ def test_cfg2_full_size_fp32_and_bf16():
     assert maxdiff(logits[0], g["logits"]) < 1e-3
     assert maxdiff(cl[0], g["class_logits"]) < 1e-3
     lb, _ = run_engine(m, a, sd, tt, te, [ep], "bf16")
-    assert maxdiff(lb[0], g["logits"]) < 0.05
+    assert maxdiff(lb[0], g["logits"]) < LOGITS_TOLERANCE["bf16"]
+    lh, ch = run_engine(m, a, sd, tt, te, [ep], "fp16")
+    assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE            # the 16-bit mode that meets the north star (measured 7.6e-4)
+    assert torch.equal(lh[0].argmax(1), torch.from_numpy(g["logits"]).argmax(1))
 
 
 def test_timed_configuration_b16_equals_b1_and_golden():
@@ -118,7 +146,9 @@ def test_timed_configuration_b16_equals_b1_and_golden():
     a, sd, tt, te, ep0 = case_inputs(m)
     eps = [ep0] + [case_inputs(m, episode=m["episode"] + e)[4] for e in range(1, 16)]
     lb16, cb16 = run_engine(m, a, sd, tt, te, eps, "bf16")
-    assert maxdiff(lb16[0], g["logits"]) < 0.05
+    assert maxdiff(lb16[0], g["logits"]) < LOGITS_TOLERANCE["bf16"]
+    lh16, _ = run_engine(m, a, sd, tt, te, eps, "fp16")
+    assert maxdiff(lh16[0], g["logits"]) < NORTH_STAR_TOLERANCE          # fp16 mode at 16 episodes per step
     for i in (0, 5, 15):
         l1, c1 = run_engine(m, a, sd, tt, te, [eps[i]], "bf16")
         # the ViT tower is bit-identical at any batch size; the fp32 tail picks its GEMM kernel by row count (skinny FMA kernel for
@@ -140,7 +170,9 @@ def test_cfg3_four_episodes_per_step():
     assert maxdiff(lf[0], g["logits"]) < 1e-3
     assert maxdiff(cf[0], g["class_logits"]) < 1e-3
     lb, _ = run_engine(m, a, sd, tt, te, eps, "bf16")
-    assert maxdiff(lb[0], g["logits"]) < 0.05
+    assert maxdiff(lb[0], g["logits"]) < LOGITS_TOLERANCE["bf16"]
+    lh, _ = run_engine(m, a, sd, tt, te, eps, "fp16")
+    assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE
     l1, _ = run_engine(m, a, sd, tt, te, [eps[2]], "bf16")
     assert maxdiff(lb[2], l1[0]) <= 4e-6
 
@@ -162,7 +194,12 @@ def test_cfg3_cfg4_full_size(name, tol_feat):
     assert maxdiff(logits[0], g["logits"]) < 1e-3
     assert maxdiff(cl[0], g["class_logits"]) < 1e-3
     lb, _ = run_engine(m, a, sd, tt, te, [ep], "bf16")
-    assert maxdiff(lb[0], g["logits"]) < 0.05
+    assert maxdiff(lb[0], g["logits"]) < bound(name, "bf16")
+    if a.get("kind") != "rn":
+        lh, _ = run_engine(m, a, sd, tt, te, [ep], "fp16")
+        # cfg3 (ViT-B/16): north star.  cfg4 (ViT-L/14, 24 layers): 1.5e-3 measured -- twice the layers' worth of fp16 stream / weight
+        # roundings (tools/fp16_error_budget.py); bounded at 2 x measured, fp32 is the mode that meets 1e-3 there.
+        assert maxdiff(lh[0], g["logits"]) < (NORTH_STAR_TOLERANCE if name.startswith("cfg3") else bound(name, "fp16")), name
     print("%s: fp32 |dlogits| %.2e, bf16 |dlogits| %.3f" % (name, maxdiff(logits[0], g["logits"]), maxdiff(lb[0], g["logits"])))
 
 

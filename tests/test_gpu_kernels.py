@@ -141,7 +141,7 @@ def test_im2col_and_cls_rows(hip, P, res):
     kreal = 3 * P * P
     kpad = (kreal + 63) // 64 * 64
     ref = frames.reshape(F_, 3, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(F_ * g * g, kreal)
-    for td in (torch.float32, torch.bfloat16):
+    for td in (torch.float32, torch.bfloat16, torch.float16):
         out = torch.full((F_ * g * g, kpad), 9.0, device="cuda", dtype=td)
         hip.im2col_patches(frames.cuda(), out, P)
         got = out.float().cpu()
@@ -163,17 +163,17 @@ def _ref_attention(qkv, F_, ntok, D, heads):
 
 
 @pytest.mark.parametrize("ntok", [5, 17, 197, 257])
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_vit_attention(hip, ntok, dtype):
     F_, heads = 3, 2
     D = heads * 64
-    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    td = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dtype]
     qkv = (_rand(F_ * ntok, 3 * D, seed=15) * 1.5).to(td)
     # spike one key against one query so the softmax is far from uniform somewhere
     ref = _ref_attention(qkv, F_, ntok, D, heads)
     out = torch.empty(F_ * ntok, D, device="cuda", dtype=td)
     hip.vit_attention(qkv.cuda(), out, F_, ntok, D, heads)
-    tol = 2e-5 if dtype == "f32" else 3e-2
+    tol = {"f32": 2e-5, "bf16": 3e-2, "f16": 4e-3}[dtype]                # 16-bit: P and the output are rounded to the operand type
     assert maxdiff(out.float().cpu(), ref) < tol
 
 
@@ -505,7 +505,7 @@ def test_gemm_lnfold_matches_layernorm_then_gemm(hip, M, N, K, act):
     _check_lnfold(hip, M, N, K, act)
 
 
-def _check_lnfold(hip, M, N, K, act):
+def _check_lnfold(hip, M, N, K, act, od=torch.bfloat16):
     """cfsar_row_stats + cfsar_gemm_lnfold == act(F.layer_norm(x) @ W.T + b) (few_shot.py:605-611 + :626-628 / :636-640) on the
     raw fp16 stream: the reference of the folded form is the UNFOLDED fp32 computation, so the test covers the algebra (Wg, c, d,
     the rank-1 mean term, the 1/std row scale) and not just the kernel.  Rows get different means / scales (column offsets,
@@ -531,7 +531,7 @@ def _check_lnfold(hip, M, N, K, act):
     mean, var = x.float().mean(1), x.float().var(1, unbiased=False)
     assert maxdiff(rstat[:, 0], mean) < 1e-4 * max(1.0, float(mean.abs().max()))
     assert maxdiff(rstat[:, 2], torch.rsqrt(var + 1e-5)) < 2e-4 * float(torch.rsqrt(var + 1e-5).max())
-    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=od)
     hip.gemm_lnfold(x, Wg, out, c, d, rstat, act=hip.ACT_QUICKGELU if act == "gelu" else hip.ACT_NONE)
     scale = max(1.0, float(ref.abs().max()))
     assert maxdiff(out.float(), ref) < 2e-2 * scale, (M, N, K, act)
@@ -539,12 +539,45 @@ def _check_lnfold(hip, M, N, K, act):
     ref2 = ((x.float() @ Wg.float().t()) - mean[:, None] * c[None, :]) * torch.rsqrt(var + 1e-5)[:, None] + d
     if act == "gelu":
         ref2 = orc.quick_gelu(ref2)
-    assert maxdiff(out.float(), ref2) < 6e-3 * scale, (M, N, K, act)          # bf16 output rounding (2^-9) dominates
+    assert maxdiff(out.float(), ref2) < (6e-3 if od == torch.bfloat16 else 1.5e-3) * scale, (M, N, K, act)    # output rounding (2^-9 / 2^-12) dominates
 
 
 @pytest.mark.parametrize("M,N,K", [(777, 128, 128), (1300, 192, 192), (5000, 768, 768), (44000, 768, 3072), (20500, 1024, 256)])
 def test_gemm_residual_stats_and_finalize(hip, M, N, K):
     _check_residual_stats(hip, M, N, K)
+
+
+@pytest.mark.parametrize("M,N,K", [(777, 128, 128), (5000, 768, 768), (30000, 768, 3072)])
+def test_gemm_residual_stats_fp16_operands(hip, M, N, K):
+    _check_residual_stats(hip, M, N, K, td=torch.float16)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(777, 384, 128, "none"), (5000, 2304, 768, "none"), (30000, 3072, 768, "gelu")])
+def test_gemm_lnfold_fp16_output(hip, M, N, K, act):
+    _check_lnfold(hip, M, N, K, act, od=torch.float16)
+
+
+def test_gemm_fp16_operands_patch_embed_and_small(hip):
+    """cfsar_gemm with fp16 operands (the fp16 numerics mode): the patch-embed scatter (row remap + positional residual into the fp16
+    stream; 256x128 kernel from 1 024 rows on, 128x128 kernel below) and a plain fp32-output launch."""
+    for F_ in (2, 9):
+        npatch, D, K = 196, 256, 768
+        patches = _rand(F_ * npatch, K, seed=31).to(torch.float16).cuda()
+        w = _rand(D, K, seed=32, scale=K ** -0.5).to(torch.float16).cuda()
+        pos = _rand(npatch + 1, D, seed=33).cuda()
+        x = torch.zeros(F_ * (npatch + 1), D, device="cuda", dtype=torch.float16)
+        hip.gemm(patches, w, x, residual=pos, M=F_ * npatch, N=D, K=K, ldo=D, ldr=D, row_group=npatch, row_gap=1, row_off=1,
+                 res_mod=npatch, res_off=1)
+        ref = (patches.float() @ w.float().t()).reshape(F_, npatch, D) + pos[1:]
+        got = x.float().reshape(F_, npatch + 1, D)
+        assert maxdiff(got[:, 1:], ref) < 4e-3 * max(1.0, float(ref.abs().max())), F_
+        assert torch.all(got[:, 0] == 0)
+    A = _rand(300, 256, seed=34).to(torch.float16).cuda()
+    W = _rand(192, 256, seed=35, scale=1.0 / 16).to(torch.float16).cuda()
+    b = _rand(192, seed=36).cuda()
+    out = torch.empty(300, 192, device="cuda")
+    hip.gemm(A, W, out, bias=b)
+    assert maxdiff(out, A.float() @ W.float().t() + b) < 1e-4
 
 
 def test_vit_gemm_random_shapes(hip):
@@ -563,11 +596,12 @@ def test_vit_gemm_random_shapes(hip):
             _check_residual_stats(hip, M, N, K)
 
 
-def _check_residual_stats(hip, M, N, K):
+def _check_residual_stats(hip, M, N, K, td=torch.bfloat16):
     """cfsar_gemm_residual_stats: x += A W^T + b in place on the fp16 stream, and its partial statistics, finalized by
-    cfsar_ln_stats_finalize, are the LayerNorm statistics of the NEW (stored, fp16-rounded) x."""
-    A = _rand(M, K, seed=11).to(torch.bfloat16).cuda()
-    W = _rand(N, K, seed=12, scale=K ** -0.5).to(torch.bfloat16).cuda()
+    cfsar_ln_stats_finalize, are the LayerNorm statistics of the NEW (stored, fp16-rounded) x.  td: operand type (bf16, or fp16 in the
+    fp16 numerics mode)."""
+    A = _rand(M, K, seed=11).to(td).cuda()
+    W = _rand(N, K, seed=12, scale=K ** -0.5).to(td).cuda()
     bias = _rand(N, seed=13).cuda()
     x = (_rand(M, N, seed=14) * 2.0 + 1.5).to(torch.float16).cuda()
     x0 = x.clone()
