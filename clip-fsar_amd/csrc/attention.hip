@@ -435,6 +435,108 @@ __global__ __launch_bounds__((NTV + 1) * 64, 4) void vit_attn_ring_kernel(const 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Pipelined persistent form (round 3) for ntok <= 16 NTV <= 256 (ViT-B/16: 197 tokens, NTV = 13 waves): ONE workgroup per CU walks
+// (frame, head) items with TWO K + V buffers; while item k is computed, item k + 1 is in flight -- issued by ALL waves (4 LDS-DMA
+// pieces each), not by a loader wave.
+//
+// Why: the one-item-per-workgroup kernel keeps nothing in flight while its two workgroups per CU compute (378 us at 1 280 frames
+// against a 294 us memory-only pipeline, 1.55 GB); the round-2 ring kept two items in flight but fed them through ONE loader wave, whose
+// 52 serial DMA issues per item (~25 GB/s per CU, MI355X_MICROARCH.md "ldsdma-fill") capped it at 409 us.  Here every wave issues its
+// 2 + 2 pieces right behind the barrier that frees the buffer, one query tile per wave (same S / softmax / PV routine), and the
+// iteration time is the item's memory time as long as the tile computation (~3.5 K cycles) is shorter than it (~9 K cycles).
+//   per item and wave:   compute tile of item k (buffer k & 1)
+//                        s_waitcnt vmcnt(0)   -- this wave's pieces and Q rows of item k + 1 have landed (issued one item ago)
+//                        store O(k)           -- after the wait: the stores drain under the next item's computation
+//                        barrier              -- buffer k & 1 is free, item k + 1 is complete in the other one
+//                        issue item k + 2 -> buffer k & 1, load its Q rows
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int NKB, int NTV>
+__global__ __launch_bounds__(NTV * 64, 4) void vit_attn_pipe_kernel(const T* __restrict__ qkv, T* __restrict__ out, int ntok, int D,
+                                                                    int heads, int nitems, float scale_log2e) {
+    typedef typename Vec2B<T>::v8 T8;
+    constexpr int KROWS = NTV * 16;
+    constexpr int NPIECE = KROWS / 8;                               // 1 KiB pieces per operand: 2 per wave
+    constexpr int BUF = 2 * KROWS * 128;
+    static_assert(NPIECE == 2 * NTV, "two K and two V pieces per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t ld = (size_t)3 * D;
+    const int first = blockIdx.x, stride = gridDim.x;
+    const int nmine = first < nitems ? (nitems - first + stride - 1) / stride : 0;       // same for every wave of the workgroup
+    if (nmine == 0) return;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int r = lane >> 3, c = lane & 7;
+    const int q16 = lane & 15, g = lane >> 4;
+    int qrow = wave * 16 + q16;
+    const bool qvalid = qrow < ntok;
+    if (!qvalid) qrow = ntok - 1;
+    const AttLane L(lane);
+    auto base_of = [&](int k) __attribute__((always_inline)) {
+        const int item = first + k * stride;
+        const int f = item / heads, h = item - f * heads;
+        return qkv + (size_t)f * ntok * ld + h * 64;
+    };
+    auto issue = [&](int k) __attribute__((always_inline)) {           // this wave's pieces {wave, wave + NTV} of K and of V -> buffer k & 1
+        const char* baseb = reinterpret_cast<const char*>(base_of(k));
+        const unsigned slot = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(k & 1) * (unsigned)BUF);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pc = wave + i * NTV;
+            const int row = pc * 8 + r;
+            const int srow = row < ntok ? row : ntok - 1;
+            att_glds16(baseb + (size_t)srow * ld * 2 + (size_t)D * 2 + ((c ^ ((row >> 1) & 7)) << 4),
+                       __builtin_amdgcn_readfirstlane(slot + (unsigned)pc * 1024u));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pc = wave + i * NTV;
+            const int row = pc * 8 + r;
+            const int srow = row < ntok ? row : ntok - 1;
+            att_glds16(baseb + (size_t)srow * ld * 2 + (size_t)D * 4 + ((c ^ (((row >> 1) & 3) << 1)) << 4),
+                       __builtin_amdgcn_readfirstlane(slot + (unsigned)(KROWS * 128) + (unsigned)pc * 1024u));
+        }
+    };
+    auto loadq = [&](int k, T8 (&q)[2]) __attribute__((always_inline)) {
+        const T* qp = base_of(k) + (size_t)qrow * ld;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) q[ks] = *reinterpret_cast<const T8*>(qp + ks * 32 + g * 8);
+    };
+    T8 qf[2], qn[2];
+    issue(0);
+    loadq(0, qf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    qn[0] = qf[0];
+    qn[1] = qf[1];
+    if (nmine > 1) {
+        issue(1);
+        loadq(1, qn);
+    }
+    for (int k = 0; k < nmine; ++k) {
+        const char* sK = smem + (k & 1) * BUF;
+        f32x4 o[4];
+        float inv;
+        attn_tile<T, NKB, NTV, 3>(sK, sK + KROWS * 128, L, qf, ntok, scale_log2e, o, inv);
+        uint4 val[2];
+        pack_o_tile<T>(o, inv, g, val);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // item k + 1: my pieces and Q rows are here (and O(k - 1) has left)
+        {
+            const int item = first + k * stride;
+            const int f = item / heads, h = item - f * heads;
+            store_o_packed<T>(val, qvalid, out + ((size_t)f * ntok + qrow) * D + h * 64, g);
+        }
+        __syncthreads();
+        qf[0] = qn[0];
+        qf[1] = qn[1];
+        if (k + 2 < nmine) {
+            issue(k + 2);
+            loadq(k + 2, qn);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // fp32 VALU kernel (validation mode).  One workgroup per (head, frame); K and V rows in LDS (fp32); one thread per
 // query row with an online softmax (running max / sum, fp32) -- all lanes read the same K/V row (LDS broadcast).
 // ------------------------------------------------------------------------------------------------------------
@@ -507,6 +609,18 @@ int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, h
     return cfsar_check_launch("cfsar_vit_attention(16-bit)");
 }
 
+template <typename T, int NKB, int NTV>
+int launch_pipe(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
+    constexpr int LDS = 2 * 2 * NTV * 16 * 128;
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_pipe_kernel<T, NKB, NTV>), LDS, "cfsar_vit_attention")) return rc;
+    const int nitems = F * heads;
+    const int cus = cfsar_num_cus();
+    const int grid = nitems < cus ? nitems : cus;
+    hipLaunchKernelGGL((vit_attn_pipe_kernel<T, NKB, NTV>), dim3(grid), dim3(NTV * 64), LDS, s, static_cast<const T*>(qkv),
+                       static_cast<T*>(out), ntok, D, heads, nitems, 0.125f * 1.4426950408889634f);
+    return cfsar_check_launch("cfsar_vit_attention(pipelined)");
+}
+
 template <int NKB, int NTV>
 int launch_ring(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
     constexpr int LDS = 3 * 2 * NTV * 16 * 128;
@@ -543,6 +657,8 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
         // 257 tokens (ViT-L/14 @224): 17 tiles, 68 KiB
 #ifdef CFSAR_DEV
         if (ntok == 197 && g_attn_variant == 7) return launch_ring<7, 13>(qkv, out, F, ntok, D, heads, s);           // persistent ring
+        if (ntok == 197 && g_attn_variant == 30) return launch_pipe<__bf16, 7, 13>(qkv, out, F, ntok, D, heads, s);   // pipelined persistent (r03)
+        if (ntok == 197 && g_attn_variant == 31) return launch_bf16<7, 13, 8, 4, 3>(qkv, out, F, ntok, D, heads, s);  // r02 product kernel
         if (ntok == 257 && g_attn_variant == 8) return launch_bf16<9, 17, 9, 4>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 257 && g_attn_variant == 20) return launch_bf16<9, 17, 8, 4>(qkv, out, F, ntok, D, heads, s);   // r02 mid-round default
         if (ntok == 257 && g_attn_variant == 9) return launch_bf16<9, 17, 6, 4>(qkv, out, F, ntok, D, heads, s);

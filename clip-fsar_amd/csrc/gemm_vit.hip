@@ -103,14 +103,24 @@ __device__ __forceinline__ float dpp_sum8(float v) {
     return v;
 }
 
-// 16-byte global store with a cache policy: 0 = default (write-back, line stays in this XCD's L2), 1 = nt, 2 = sc1
-// (write-through: the line is not kept, MI355X_MICROARCH.md "stores of each flavour")
+// 16-byte global store with a cache policy: 0 = default (write-back, line stays in this XCD's L2), 1 = nt, 2 = sc1 nt
+// (write-through: the line is not kept, MI355X_MICROARCH.md "stores of each flavour"; nt on top of it measured another 1 %)
 template <int POLICY>
 __device__ __forceinline__ void store16(void* dst, u32x4 v) {
     if constexpr (POLICY == 1) {
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
-    } else if constexpr (POLICY == 2) {
+    } else if constexpr (POLICY == 2) {              // write-through + non-temporal (round 3: QKV 825 -> 814 us, c_fc 1180 -> 1171 us against sc1 alone)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+#ifdef CFSAR_DEV
+    } else if constexpr (POLICY == 3) {              // A/B only: write-through alone (the round-2 policy)
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+    } else if constexpr (POLICY == 4) {              // A/B only: system scope
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+    } else if constexpr (POLICY == 5) {              // A/B only: system scope + nt
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+    } else if constexpr (POLICY == 6) {              // A/B only: sc0
+        asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+#endif
     } else {
         *reinterpret_cast<u32x4*>(dst) = v;
     }
@@ -818,6 +828,10 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
 #ifdef CFSAR_DEV
         case 1: return launch_path<0, 1>(a, mode, f16io, s);
         case 5: return launch_path<1, 1>(a, mode, f16io, s);
+        case 11: return launch_path<2, 3>(a, mode, f16io, s);     // store-policy A/B on the early-DMA path: variants 31 (sc1 nt),
+        case 12: return launch_path<2, 4>(a, mode, f16io, s);     // 32 (sc0 sc1), 33 (sc0 sc1 nt), 34 (sc0)
+        case 13: return launch_path<2, 5>(a, mode, f16io, s);
+        case 14: return launch_path<2, 6>(a, mode, f16io, s);
 #endif
         default: return -2;
     }
