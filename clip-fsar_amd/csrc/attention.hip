@@ -35,17 +35,21 @@ __device__ __forceinline__ void pack_o_tile(const f32x4 (&o)[4], float inv, int 
         pk[dt][1] = u.y;
     }
     const bool odd = g & 1;
-    // send the two dt chunks the partner will store, keep the two this lane stores
-    unsigned recv[2][2];
+    // send the two dt chunks the partner will store, keep the two this lane stores.  Written as explicit two-way selects: indexing pk[]
+    // with a lane-dependent dt made the compiler build 7-deep compare / select chains over all eight words (71 VALU instructions per
+    // tile, round 3 ISA audit).
+    unsigned recv[2][2], mine[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int w = 0; w < 2; ++w) recv[i][w] = __shfl_xor(odd ? pk[i][w] : pk[2 + i][w], 16, 64);
+        for (int w = 0; w < 2; ++w) {
+            recv[i][w] = __shfl_xor(odd ? pk[i][w] : pk[2 + i][w], 16, 64);
+            mine[i][w] = odd ? pk[2 + i][w] : pk[i][w];
+        }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int dt = odd ? 2 + i : i;
-        // chunk of 8 d values starting at 16dt + 8(g>>1): low half from the even-g lane, high half from the odd-g lane
-        val[i] = odd ? make_uint4(recv[i][0], recv[i][1], pk[dt][0], pk[dt][1]) : make_uint4(pk[dt][0], pk[dt][1], recv[i][0], recv[i][1]);
+        // chunk of 8 d values starting at 16 dt + 8 (g >> 1), dt = odd ? 2 + i : i: low half from the even-g lane, high half from the odd-g lane
+        val[i] = odd ? make_uint4(recv[i][0], recv[i][1], mine[i][0], mine[i][1]) : make_uint4(mine[i][0], mine[i][1], recv[i][0], recv[i][1]);
     }
 }
 template <typename T>
@@ -98,6 +102,11 @@ __device__ __forceinline__ void att_glds16(const char* src, unsigned lds_addr) {
         : "memory");
 }
 typedef short att_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float att_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 template <typename F, int... Is>
 __device__ __forceinline__ void att_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
     (f(std::integral_constant<int, Is>{}), ...);
@@ -171,13 +180,17 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
             for (int r = 0; r < 4; ++r)
                 if (j * 16 + g * 4 + r >= ntok) s[j][r] = -1e30f;
         }
-        if (j < nt_valid) mx = fmaxf(fmaxf(mx, fmaxf(s[j][0], s[j][1])), fmaxf(s[j][2], s[j][3]));
+        // v_max3_f32 from inline asm: fmaxf on MFMA results makes hipcc put a canonicalising v_max in front of every operand
+        // (82 + 13 instead of 26 instructions per tile)
+        if (j < nt_valid) mx = att_max3(att_max3(mx, s[j][0], s[j][1]), s[j][2], s[j][3]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mxs = mx * scale_log2e;
-    float sum = 0.f;
-    // P fragment of key block kb: exp2 of tiles 2 kb, 2 kb + 1 (raw v_exp_f32), summed in fp32, rounded to bf16
+    // P fragment of key block kb: exp2 of tiles 2 kb, 2 kb + 1 (raw v_exp_f32), rounded to the operand type.  The row sums come from the
+    // matrix pipe: one more MFMA per key block with an all-ones "A" fragment adds the block's (rounded) probabilities of every query --
+    // 7 MFMAs instead of 52 VALU adds and two cross-lane shuffles per tile (the tile routine is VALU-issue bound), and the normaliser is
+    // the sum of exactly the values the PV product uses.
     auto pblock = [&](int kb) __attribute__((always_inline)) {
         T8 pf;
 #pragma unroll
@@ -190,7 +203,6 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
                     const float z = fmaf(s[j][r], scale_log2e, -mxs);
                     pv = __builtin_amdgcn_exp2f(z);
                     asm volatile("" : "+v"(pv) : "v"(z));       // operand pin kept from the round-2 fault hunt (csrc/gemm_vit.hip, above quick_gelu4): no instruction, no measured cost
-                    sum += pv;
                 }
                 pf[4 * t + r] = (T)pv;
             }
@@ -216,6 +228,9 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     vload(0, vf[0]);
     T8 pcur = pblock(0);
+    const T one = (T)1.0f;
+    const T8 ones = T8{one, one, one, one, one, one, one, one};
+    f32x4 osum = {0.f, 0.f, 0.f, 0.f};
     att_static_for<NBLK>([&](auto KB) {
         constexpr int kb = decltype(KB)::value;
         T8 pnext = pcur;
@@ -226,12 +241,11 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
             o[dt] = att_mfma<T>(__builtin_bit_cast(T8, vf[kb & 1][dt]), pcur, o[dt]);
+        osum = att_mfma<T>(ones, pcur, osum);
         __builtin_amdgcn_sched_barrier(0);
         pcur = pnext;
     });
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    inv = __builtin_amdgcn_rcpf(sum);
+    inv = __builtin_amdgcn_rcpf(osum[0]);                       // every row of the ones product is the query's sum over all keys
 }
 
 template <typename T, int NKB, int NTV, int NW, int WPS, int KPFK = 0>
@@ -659,6 +673,14 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
         if (ntok == 197 && g_attn_variant == 7) return launch_ring<7, 13>(qkv, out, F, ntok, D, heads, s);           // persistent ring
         if (ntok == 197 && g_attn_variant == 30) return launch_pipe<__bf16, 7, 13>(qkv, out, F, ntok, D, heads, s);   // pipelined persistent (r03)
         if (ntok == 197 && g_attn_variant == 31) return launch_bf16<7, 13, 8, 4, 3>(qkv, out, F, ntok, D, heads, s);  // r02 product kernel
+        if (ntok == 197 && g_attn_variant == 40) return launch_bf16<7, 13, 4, 3, 3>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197 && g_attn_variant == 41) return launch_bf16<7, 13, 4, 3, 5>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197 && g_attn_variant == 42) return launch_bf16<7, 13, 3, 3>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197 && g_attn_variant == 43) return launch_bf16<7, 13, 4, 4>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197 && g_attn_variant == 44) return launch_bf16<7, 13, 5, 3>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257 && g_attn_variant == 45) return launch_bf16<9, 17, 4, 3>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257 && g_attn_variant == 46) return launch_bf16<9, 17, 4, 3, 3>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 257 && g_attn_variant == 47) return launch_bf16<9, 17, 5, 3>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 257 && g_attn_variant == 8) return launch_bf16<9, 17, 9, 4>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 257 && g_attn_variant == 20) return launch_bf16<9, 17, 8, 4>(qkv, out, F, ntok, D, heads, s);   // r02 mid-round default
         if (ntok == 257 && g_attn_variant == 9) return launch_bf16<9, 17, 6, 4>(qkv, out, F, ntok, D, heads, s);
@@ -683,7 +705,10 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
         if (ntok == 197 && g_attn_variant == 11) return launch_bf16<7, 13, 4, 2>(qkv, out, F, ntok, D, heads, s);  // (2-3) x 4 waves, 256 regs
         if (ntok == 197 && g_attn_variant == 12) return launch_bf16<7, 13, 6, 4>(qkv, out, F, ntok, D, heads, s);  // 2 x 6 waves
 #endif
-        if (ntok == 197) return launch_bf16<7, 13, 8, 4, 3>(qkv, out, F, ntok, D, heads, s);      // K fragments 3 tiles ahead: 394 -> 386 us
+        // Round 3: after the VALU diet of the tile routine (canonicalising maxes, select chains, row sums on the matrix pipe: 387 -> 365 us)
+        // THREE workgroups of 4 waves per CU (156 KiB of LDS, 168-register budget) beat two of 8: 380 -> 355 us at 1 280 frames on
+        // one box (3 x 50 KB of K / V in flight per CU instead of 2 x 50 KB), equal at 80 frames.
+        if (ntok == 197) return launch_bf16<7, 13, 4, 3>(qkv, out, F, ntok, D, heads, s);
         // 257 tokens (ViT-L/14): 4 waves per workgroup in a 256-register budget -- no spills (15 at 128 registers) and K fragments
         // two tiles ahead: 488 -> 426 us at 640 frames (8 x 128-register waves: 488, 6 x 170: 475, 3 x 256: 460, 5 x 256: 550)
         if (ntok == 257) return launch_bf16<9, 17, 4, 2, 5>(qkv, out, F, ntok, D, heads, s);
@@ -692,7 +717,7 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
     }
     if (dtype == CFSAR_F16) {                    // the fp16 numerics mode: the same kernel on fp16 q / k / v, P rounded to fp16
         CFSAR_REQUIRE(ntok <= 288, "cfsar_vit_attention: ntok=%d > 288", ntok);
-        if (ntok == 197) return launch_bf16<7, 13, 8, 4, 3, _Float16>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197) return launch_bf16<7, 13, 4, 3, 0, _Float16>(qkv, out, F, ntok, D, heads, s);
         if (ntok == 257) return launch_bf16<9, 17, 4, 2, 5, _Float16>(qkv, out, F, ntok, D, heads, s);
         if (ntok > 224) return launch_bf16<9, 0, 4, 2, 0, _Float16>(qkv, out, F, ntok, D, heads, s);
         return launch_bf16<7, 0, 7, 4, 0, _Float16>(qkv, out, F, ntok, D, heads, s);

@@ -103,8 +103,8 @@ def test_hot_kernels_use_no_scratch():
     usage = json.load(open(b.USAGE))
     assert len(usage) > 40, len(usage)
     hot = {  # substring of the mangled name -> max scratch bytes per lane
-        "vit_attn_bf16_kernelIDF16bLi7ELi13E": 0, "vit_attn_bf16_kernelIDF16bLi9ELi17E": 0,
-        "vit_attn_bf16_kernelIDF16_Li7ELi13E": 0, "vit_attn_bf16_kernelIDF16_Li9ELi17E": 0,      # the fp16 numerics mode
+        "vit_attn_bf16_kernelIDF16bLi7ELi13ELi4ELi3E": 0, "vit_attn_bf16_kernelIDF16bLi9ELi17E": 0,
+        "vit_attn_bf16_kernelIDF16_Li7ELi13ELi4ELi3E": 0, "vit_attn_bf16_kernelIDF16_Li9ELi17E": 0,      # the fp16 numerics mode
         "vit_gemm_kernelIDF16_DF16_Li0ELi1ELi2E": 0, "vit_gemm_kernelIDF16_DF16_Li0ELi2ELi2E": 0, "vit_gemm_kernelIDF16_DF16_Li1ELi2ELi2E": 0, "layernorm_kernel": 0,
         # the persistent ViT GEMM (gemm_vit.hip): the LDS-DMA instances keep (nearly) everything in registers -- an LN-folded build
         # with 12 spilled registers returned stale lanes under a concurrent second stream (tests/test_gpu_kernels.py::
