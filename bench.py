@@ -108,7 +108,7 @@ def measured_traffic(episodes_per_step):
     cannot run inside the timed bench, so the value is read from profiles/ and only reported when it was measured at the
     same episodes-per-step; otherwise null."""
     try:
-        path = next(p for p in (os.path.join(ROOT, "profiles", n) for n in ("r02_gemm_traffic.json", "r01_gemm_traffic.json")) if os.path.exists(p))
+        path = next(p for p in (os.path.join(ROOT, "profiles", n) for n in ("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")) if os.path.exists(p))
         d = json.load(open(path))["_all_bf16_gemm"]
         if re.search(r"--episodes-per-step %d\b" % episodes_per_step, d["note"]):
             return round(d["hbm_bytes_per_launch"])
@@ -428,7 +428,8 @@ def run(args):
                                "(utils/prefetch.py, the product harness's path)"}
 
     fp16_mode = None
-    if (not dry and rank == 0 and world == 1 and args.precision == "bf16" and ARCH.startswith("ViT") and not args.no_fp16_leg):
+    if (not dry and rank == 0 and world == 1 and args.precision == "bf16" and ARCH.startswith("ViT") and not args.no_fp16_leg
+            and B * frames_per_ep > 160):              # (small steps: a handful of them does not time anything)
         # The 16-bit mode that meets the north-star tolerance (precision "fp16": IEEE-half operands everywhere, same kernels), timed
         # in the same process on the same resident steps: `value` stays BASELINE's bf16 configuration, this object says what the
         # 1e-3-conforming mode costs.  `python bench.py --precision fp16` makes it the headline instead.

@@ -70,6 +70,18 @@ __device__ __forceinline__ void glds16_asm(const char* src, unsigned lds_addr) {
         : "memory");
 }
 
+#ifdef CFSAR_DEV
+// A/B only: the same with a cache policy on the load (1 = nt, 2 = sc1)
+template <int POL>
+__device__ __forceinline__ void glds16_asm_pol(const char* src, unsigned lds_addr) {
+    unsigned keep;
+    if constexpr (POL == 1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
+}
+#endif
+
 // x * sigmoid(1.702 x) for four values, few_shot.py:614-616: v_exp_f32 + v_rcp_f32 (1 ulp each).
 //
 // History of a fault (round 2), kept here because this function was its first victim.  Builds of the LN-folded instances of this
@@ -503,12 +515,21 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         *reinterpret_cast<u32x4*>(smem + stage * STAGE + TM * ROWB + wr_off + decltype(J)::value * 8192) = GW[decltype(J)::value];
     };
     auto dmaX = [&](const unsigned (&ox)[4], int kt, int stage, auto J) __attribute__((always_inline)) {
-        glds16_asm(p.A + (size_t)kt * akstride + ox[decltype(J)::value],
-                   ldsw + (unsigned)stage * (unsigned)STAGE + (unsigned)decltype(J)::value * 8192u);
+        const char* src = p.A + (size_t)kt * akstride + ox[decltype(J)::value];
+        const unsigned dst = ldsw + (unsigned)stage * (unsigned)STAGE + (unsigned)decltype(J)::value * 8192u;
+#ifdef CFSAR_DEV
+        if (p.dbg & 4096) { glds16_asm_pol<1>(src, dst); return; }       // A/B: streaming operand loaded nt / sc1
+        if (p.dbg & 16384) { glds16_asm_pol<2>(src, dst); return; }
+#endif
+        glds16_asm(src, dst);
     };
     auto dmaW = [&](const unsigned (&ow)[4], int kt, int stage, auto J) __attribute__((always_inline)) {
-        glds16_asm(p.W + (size_t)kt * ROWB + ow[decltype(J)::value],
-                   ldsw + (unsigned)stage * (unsigned)STAGE + (unsigned)(TM * ROWB) + (unsigned)decltype(J)::value * 8192u);
+        const char* src = p.W + (size_t)kt * ROWB + ow[decltype(J)::value];
+        const unsigned dst = ldsw + (unsigned)stage * (unsigned)STAGE + (unsigned)(TM * ROWB) + (unsigned)decltype(J)::value * 8192u;
+#ifdef CFSAR_DEV
+        if (p.dbg & 8192) { glds16_asm_pol<1>(src, dst); return; }
+#endif
+        glds16_asm(src, dst);
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
