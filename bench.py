@@ -454,7 +454,17 @@ def run(args):
     if rank == 0:
         episodes = world * args.steps * B
         eps_per_s = episodes / elapsed
-        tflop_per_ep = GFLOP_PER_FRAME * frames_per_ep / 1e3
+        tflop_per_ep = GFLOP_PER_FRAME * frames_per_ep / 1e3            # the reference path's algorithmic work
+        # executed work: the last ViT block is computed for the class-token rows only (engine.py: prune_last; few_shot.py:683 reads
+        # nothing else of it) -- (N - 1) (18 D^2 + 4 N D) FLOPs per frame fewer; every end-to-end fraction below is priced on THIS figure
+        gflop_exec = GFLOP_PER_FRAME
+        pruned = False
+        if not dry and ARCH.startswith("ViT") and getattr(eng.vit, "prune_last", False):
+            a_ = synth.ARCHS[ARCH]
+            n_, d_ = (a_["res"] // a_["patch"]) ** 2 + 1, a_["width"]
+            gflop_exec = GFLOP_PER_FRAME - (n_ - 1) * (18.0 * d_ * d_ + 4.0 * n_ * d_) / 1e9
+            pruned = True
+        tflop_exec = gflop_exec * frames_per_ep / 1e3
         out = {
             "metric": "episodes/sec (5-way %d-shot, %d frames, %s)" % (SHOT, T, ARCH), "value": round(eps_per_s, 3),
             "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -462,7 +472,10 @@ def run(args):
             "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision], "data": "synthetic",
             "config": {"workload": cfgsel["name"] + ", random-init CLIP weights, synthetic structured frames",
                        "episodes_per_step_per_gpu": B, "frames_per_episode": frames_per_ep,
-                       "tflop_per_episode": round(tflop_per_ep, 4), "precision": args.precision,
+                       "tflop_per_episode": round(tflop_per_ep, 4), "tflop_per_episode_executed": round(tflop_exec, 4),
+                       "last_block": ("class-token rows only behind the attention (the path reads x[:, 0] after the last block: "
+                                      "few_shot.py:683); CFSAR_FULL_LAST_BLOCK=1 computes it whole") if pruned else "whole",
+                       "precision": args.precision,
                        "numerics": ("%s MFMA operands, fp32 accumulation / LayerNorm + softmax statistics / final projection / "
                                     "temporal head, fp16 residual stream" % args.precision + (" (ViT)" if ARCH.startswith("ViT") else " n/a (RN50: bf16 activations)")
                                     if args.precision != "fp32" else "fp32 throughout"),
@@ -477,7 +490,7 @@ def run(args):
             out["config"]["workload"] = "DRY RUN (no-op step on CPU, gloo): launch / collective / timing protocol only"
             out["gathered_rank_ids"] = sorted({int(v) for v in gathered.tolist()})
         else:
-            e2e_tflops = eps_per_s / world * tflop_per_ep
+            e2e_tflops = eps_per_s / world * tflop_exec                      # executed FLOPs, not the reference path's
             out["end_to_end_vit_tflops_per_gpu"] = round(e2e_tflops, 2)
             if timer is not None and timer.launches:
                 ms, flops, n = timer.result()

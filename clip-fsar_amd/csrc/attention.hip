@@ -601,6 +601,85 @@ __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Class-token attention (round 3).  VisionTransformer.forward keeps ONLY the class token of the last block's output
+// (few_shot.py:683: `x = self.ln_post(x[:, 0, :])`), so in that block the attention output -- and everything behind it -- is needed
+// for query row 0 of every frame alone: softmax(q_0 K^T / 8) V per (frame, head), 1 query x ntok keys.  One wave per item; an
+// instruction covers 64 / LPR key rows of 64 elements (LPR lanes x 16 bytes = one whole row), scores and probabilities live in a
+// per-wave LDS row, all arithmetic in fp32.  Reads K and V once (2/3 of the qkv matrix): memory bound.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void vit_attn_cls_kernel(const T* __restrict__ qkv, T* __restrict__ out, int ntok, int D, int heads,
+                                                           int nitems, float scale) {
+    constexpr int EPL = 16 / (int)sizeof(T);                      // elements per lane (16 bytes)
+    constexpr int LPR = 64 / EPL;                                  // lanes per 64-element row: 8 (2-byte types) or 16 (fp32)
+    constexpr int RPI = 64 / LPR;                                  // key rows per wave-instruction
+    typedef T tvec __attribute__((ext_vector_type(EPL)));
+    __shared__ float sp[4][320];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= nitems) return;
+    const int f = item / heads, h = item - f * heads;
+    const size_t ld = (size_t)3 * D;
+    const T* base = qkv + (size_t)f * ntok * ld + h * 64;
+    const int r = lane / LPR, c = lane % LPR;
+    float q[EPL];
+    {
+        const tvec qv = *reinterpret_cast<const tvec*>(base + c * EPL);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) q[e] = (float)qv[e] * scale;
+    }
+    float* p = sp[wave];
+    const int nit = (ntok + RPI - 1) / RPI;
+    for (int it = 0; it < nit; ++it) {
+        const int k = it * RPI + r;
+        const int kk = k < ntok ? k : ntok - 1;
+        const tvec kv = *reinterpret_cast<const tvec*>(base + (size_t)kk * ld + D + c * EPL);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) d = fmaf(q[e], (float)kv[e], d);
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if (c == 0 && k < ntok) p[k] = d;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0): this wave's LDS writes (one wave per row: no barrier needed)
+    float mx = -1e30f;
+    for (int k = lane; k < ntok; k += 64) mx = fmaxf(mx, p[k]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < ntok; k += 64) {
+        const float e = __expf(p[k] - mx);
+        p[k] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int it = 0; it < nit; ++it) {
+        const int k = it * RPI + r;
+        const bool ok = k < ntok;
+        const int kk = ok ? k : ntok - 1;
+        const tvec vv = *reinterpret_cast<const tvec*>(base + (size_t)kk * ld + 2 * D + c * EPL);
+        const float pk = ok ? p[kk] : 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pk, (float)vv[e], acc[e]);
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+    }
+    if (r == 0) {
+        tvec ov;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) ov[e] = (T)(acc[e] * inv);
+        *reinterpret_cast<tvec*>(out + (size_t)f * D + h * 64 + c * EPL) = ov;
+    }
+}
+
 #ifdef CFSAR_DEV
 int g_attn_dbg = 0;
 #endif
@@ -731,4 +810,24 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
         return cfsar_check_launch("cfsar_vit_attention(f32)");
     }
     return cfsar_fail("cfsar_vit_attention: bad dtype %d", dtype);
+}
+
+// The class-token form: out[f, :] = attention output of query row 0 of frame f (see vit_attn_cls_kernel).  qkv [F*ntok, 3*D] as for
+// cfsar_vit_attention; out [F, D]; dtype bf16 | fp16 | f32; ntok <= 320.
+extern "C" int cfsar_vit_attention_cls(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(qkv && out, "cfsar_vit_attention_cls: null pointer");
+    CFSAR_REQUIRE(F > 0 && ntok > 0 && ntok <= 320 && heads > 0 && D == heads * 64,
+                  "cfsar_vit_attention_cls: need D == heads*64, ntok <= 320 (D=%d heads=%d ntok=%d)", D, heads, ntok);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nitems = F * heads;
+    const dim3 grid((unsigned)((nitems + 3) / 4)), block(256);
+    if (dtype == CFSAR_BF16)
+        hipLaunchKernelGGL(vit_attn_cls_kernel<__bf16>, grid, block, 0, s, static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, heads, nitems, 0.125f);
+    else if (dtype == CFSAR_F16)
+        hipLaunchKernelGGL(vit_attn_cls_kernel<_Float16>, grid, block, 0, s, static_cast<const _Float16*>(qkv), static_cast<_Float16*>(out), ntok, D, heads, nitems, 0.125f);
+    else if (dtype == CFSAR_F32)
+        hipLaunchKernelGGL(vit_attn_cls_kernel<float>, grid, block, 0, s, static_cast<const float*>(qkv), static_cast<float*>(out), ntok, D, heads, nitems, 0.125f);
+    else
+        return cfsar_fail("cfsar_vit_attention_cls: bad dtype %d", dtype);
+    return cfsar_check_launch("cfsar_vit_attention_cls");
 }

@@ -132,6 +132,11 @@ class HipViT:
         # 3 us: GPU busy time 311.4 vs 308.7 ms per 6 steps.  Kept (bit-identical results, tests/test_gpu_kernels.py) for a future
         # attention kernel that can use whole contiguous items.
         self.head_blocked = (self.fold and self.ntok >= 128 and D == 64 * self.H and os.environ.get("CFSAR_HEAD_BLOCKED", "0") == "1")
+        # Last block, class token only.  VisionTransformer.forward reads x[:, 0] after the last block and nothing else of it
+        # (few_shot.py:683), so in THAT block the attention output, out_proj and the MLP are needed for row 0 of every frame alone
+        # (K and V still come from all tokens): -6.3 % of the tower's FLOPs (ViT-B/16, 12 layers), same class-token arithmetic.
+        # CFSAR_FULL_LAST_BLOCK=1 computes the whole block like the reference's PyTorch code does (taps always do).
+        self.prune_last = os.environ.get("CFSAR_FULL_LAST_BLOCK", "0") != "1"
         self._slots = {}
         self.max_frames_32bit = (2 ** 32 - 1) // (self.ntok * 4 * self.D * 2) - 1
 
@@ -153,6 +158,13 @@ class HipViT:
             if self.fold:
                 ws["part"] = torch.empty(M, D // 64, 2, device=dev, dtype=torch.float32)    # partial row statistics
                 ws["rstat"] = torch.empty(M, 4, device=dev, dtype=torch.float32)            # (mean, std, 1/std, -)
+            # class-token rows of the last block (prune_last): [F, .]
+            ws["xc"] = torch.empty(F_, D, device=dev, dtype=self.xd)
+            ws["hc"] = torch.empty(F_, D, device=dev, dtype=cd)
+            ws["oc"] = torch.empty(F_, D, device=dev, dtype=cd)
+            ws["uc"] = torch.empty(F_, 4 * D, device=dev, dtype=cd)
+            ws["partc"] = torch.empty(F_, D // 64 if D % 64 == 0 else 1, 2, device=dev, dtype=torch.float32)
+            ws["rstatc"] = torch.empty(F_, 4, device=dev, dtype=torch.float32)
             self._slots[slot] = (F_, ws)
         return ws
 
@@ -189,10 +201,24 @@ class HipViT:
         hip.layernorm(x, x, self.ln_pre[0], self.ln_pre[1], M, D)                     # ln_pre (:677), in place
         if taps is not None:
             taps["ln_pre"] = x[:M].clone()
+        xc_final = None
         if self.fold:
             part, rstat, S = ws["part"], ws["rstat"], D // 64
             hip.row_stats(x, rstat, M, D)                                             # statistics of ln_pre's output
+            prune = self.prune_last and taps is None and not self.head_blocked
             for i, b in enumerate(self.blocks):                                       # :679-681, LayerNorms folded away
+                if prune and i == self.L - 1:
+                    # last block: K / V from every token, everything behind the attention for the class-token rows only
+                    xc, oc, uc, partc, rstatc = ws["xc"][:F_], ws["oc"][:F_], ws["uc"][:F_], ws["partc"][:F_], ws["rstatc"][:F_]
+                    hip.gemm_lnfold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], rstat, M=M)
+                    hip.vit_attention_cls(qkv, oc, F_, N, D, self.H)
+                    xc.copy_(x[:M].view(F_, N, D)[:, 0, :])                           # class-token rows of the stream
+                    hip.gemm_residual_stats(oc, b["w_out"], xc, b["b_out"], partc, M=F_)
+                    hip.ln_stats_finalize(partc, rstatc, F_, S, D)
+                    hip.gemm_lnfold(xc, b["wg_fc"], uc, b["c_fc"], b["d_fc"], rstatc, act=hip.ACT_QUICKGELU, M=F_)
+                    hip.gemm_residual_stats(uc, b["w_pr"], xc, b["b_pr"], None, M=F_)
+                    xc_final = xc
+                    break
                 if self.head_blocked:
                     # qkv and the attention output in head-blocked layout: 75 KB contiguous per (frame, head) for the attention
                     # kernel (called as frames x heads one-head problems), K tile kt of out_proj = head kt
@@ -210,6 +236,18 @@ class HipViT:
                 if taps is not None:
                     taps["block%d" % i] = x[:M].clone()
         for i, b in enumerate(self.blocks if not self.fold else []):                  # :679-681
+            if self.prune_last and taps is None and i == self.L - 1:
+                xc, hc, oc, uc = ws["xc"][:F_], ws["hc"][:F_], ws["oc"][:F_], ws["uc"][:F_]
+                hip.layernorm(x, h, b["ln1"][0], b["ln1"][1], M, D)
+                hip.gemm(h, b["w_qkv"], qkv, bias=b["b_qkv"], M=M)
+                hip.vit_attention_cls(qkv, oc, F_, N, D, self.H)
+                xc.copy_(x[:M].view(F_, N, D)[:, 0, :])
+                hip.gemm(oc, b["w_out"], xc, bias=b["b_out"], residual=xc, M=F_)
+                hip.layernorm(xc, hc, b["ln2"][0], b["ln2"][1], F_, D)
+                hip.gemm(hc, b["w_fc"], uc, bias=b["b_fc"], act=hip.ACT_QUICKGELU, M=F_)
+                hip.gemm(uc, b["w_pr"], xc, bias=b["b_pr"], residual=xc, M=F_)
+                xc_final = xc
+                break
             hip.layernorm(x, h, b["ln1"][0], b["ln1"][1], M, D)
             hip.gemm(h, b["w_qkv"], qkv, bias=b["b_qkv"], M=M)
             hip.vit_attention(qkv, o, F_, N, D, self.H)
@@ -220,7 +258,10 @@ class HipViT:
             if taps is not None:
                 taps["block%d" % i] = x[:M].clone()
         # A8: ln_post on the class-token rows (stride N*D) then @ proj, fp32
-        hip.layernorm(x, ws["c"], self.ln_post[0], self.ln_post[1], F_, D, in_stride=N * D, out_stride=D)
+        if xc_final is not None:
+            hip.layernorm(xc_final, ws["c"], self.ln_post[0], self.ln_post[1], F_, D, in_stride=D, out_stride=D)
+        else:
+            hip.layernorm(x, ws["c"], self.ln_post[0], self.ln_post[1], F_, D, in_stride=N * D, out_stride=D)
         off = 0
         for c, (rg, gap, roff) in zip(counts, row_maps):
             hip.gemm(ws["c"][off:off + c], self.w_proj_t, feats_out, M=c, N=self.E, K=D, ldo=self.E,

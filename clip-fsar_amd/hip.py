@@ -46,6 +46,7 @@ SIGNATURES = {
     "cfsar_attnpool_attend": [_c_p, _c_p, _c_p] + [_c_int] * 4 + [ctypes.c_float, _c_p],
     "cfsar_stem_conv3x3_s2": [_c_p] * 4 + [_c_int] * 6 + [_c_p],
     "cfsar_vit_attention": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_vit_attention_cls": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_class_text_logits": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_build_sequences": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p],
     "cfsar_seq_attention": [_c_p, _c_p] + [_c_int] * 6 + [_c_f, _c_int, _c_p],
@@ -254,6 +255,14 @@ def vit_attention(qkv, out, F_, ntok, D, heads):
         raise RuntimeError("vit_attention: qkv/out dtype mismatch")
     _check(lib().cfsar_vit_attention(_dev(qkv, None, "qkv"), _dev(out, None, "out"), _code(qkv.dtype), F_, ntok, D,
                                      heads, _stream()), "cfsar_vit_attention")
+
+
+def vit_attention_cls(qkv, out, F_, ntok, D, heads):
+    """Attention output of query row 0 (the class token) of every frame: out [F, D] (include/clipfsar_hip.h: cfsar_vit_attention_cls)."""
+    if qkv.dtype != out.dtype:
+        raise RuntimeError("vit_attention_cls: qkv/out dtype mismatch")
+    _check(lib().cfsar_vit_attention_cls(_dev(qkv, None, "qkv"), _dev(out, None, "out"), _code(qkv.dtype), F_, ntok, D,
+                                         heads, _stream()), "cfsar_vit_attention_cls")
 
 
 # ----------------------------------------------------------------------------------------------- few-shot tail ops

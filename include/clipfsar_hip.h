@@ -137,6 +137,11 @@ int cfsar_conv3x3_nhwc(const void* in, const void* W, void* out, const float* bi
 int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads,
                         cfsar_stream_t stream);
 
+/* The class-token form of the same attention: VisionTransformer.forward keeps only x[:, 0] after the LAST block
+ * (few_shot.py:683), so that block needs the attention output of query row 0 of every frame alone.  qkv as above;
+ * out [F, D] (row f = frame f).  dtype bf16 | fp16 | f32; ntok <= 320. */
+int cfsar_vit_attention_cls(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads, cfsar_stream_t stream);
+
 /* ---- A15b aux class logits: cos_sim(mean_T(feats), text_train) * scale  (few_shot.py:2937-2939, cos_sim :1115-1124).
  * feats [n_videos, T, E] f32, text [n_cls, E] f32, scale [1] f32 (device), out [n_videos, n_cls] f32. */
 int cfsar_class_text_logits(const float* feats, const float* text, const float* scale, float* out, int n_videos,

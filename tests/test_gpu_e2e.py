@@ -48,6 +48,26 @@ def test_vit_layer_taps_tiny_fp32():
     assert maxdiff(out.cpu(), z["out"]) < 2e-4
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("fp16", 4e-3), ("bf16", 3e-2)])
+def test_last_block_class_token_pruning_equals_full_block(precision, tol):
+    """VisionTransformer.forward reads only x[:, 0] of the last block's output (few_shot.py:683): the engine computes that block's
+    attention output / out_proj / MLP for the class-token rows alone.  Same features as the full block (taps force the full block)."""
+    z = np.load(os.path.join(GOLD, "vit_taps_tiny.npz"))
+    meta = json.loads(str(z["meta"]))
+    a = synth.ARCHS[meta["arch"]]
+    sd = {k: torch.from_numpy(v) for k, v in synth.vit_state_dict(meta["arch"], meta["seed"]).items()}
+    ep = synth.make_episode(frames=meta["frames"], res=a["res"], seed=meta["seed"], episode=meta["episode"])
+    frames = torch.from_numpy(ep["support_set"][:meta["n"]]).cuda()
+    from clip_fsar_amd.engine import HipViT
+    vit = HipViT(a, sd, precision=precision)
+    assert vit.prune_last
+    pruned = vit.forward(frames).clone()
+    full = vit.forward(frames, taps={}).clone()
+    assert maxdiff(pruned, full) < tol * max(1.0, float(full.abs().max()))
+    if precision == "fp32":
+        assert maxdiff(pruned.cpu(), z["out"]) < 2e-4
+
+
 @pytest.mark.parametrize("name", SMALL_CASES)
 def test_small_cases_fp32_vs_reference_golden(name):
     g = load_golden(name)

@@ -177,6 +177,21 @@ def test_vit_attention(hip, ntok, dtype):
     assert maxdiff(out.float().cpu(), ref) < tol
 
 
+@pytest.mark.parametrize("ntok", [5, 17, 197, 257])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_vit_attention_cls(hip, ntok, dtype):
+    """cfsar_vit_attention_cls == row 0 of every frame of the full attention (few_shot.py:623 for the one query the last block needs)."""
+    F_, heads = 5, 3
+    D = heads * 64
+    td = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dtype]
+    qkv = (_rand(F_ * ntok, 3 * D, seed=25) * 1.5).to(td)
+    ref = _ref_attention(qkv, F_, ntok, D, heads).reshape(F_, ntok, D)[:, 0, :]
+    out = torch.full((F_, D), float("nan"), device="cuda", dtype=td)
+    hip.vit_attention_cls(qkv.cuda(), out, F_, ntok, D, heads)
+    tol = {"f32": 2e-5, "bf16": 1.5e-2, "f16": 2e-3}[dtype]                # fp32 arithmetic on the stored operands; output rounded to td
+    assert maxdiff(out.float().cpu(), ref) < tol
+
+
 def test_class_text_logits(hip):
     nv, T, E, ncls = 10, 8, 512, 64
     feats, text, scale = _rand(nv, T, E, seed=16), _rand(ncls, E, seed=17), torch.tensor([1.7])
