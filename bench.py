@@ -456,13 +456,14 @@ def run(args):
         eps_per_s = episodes / elapsed
         tflop_per_ep = GFLOP_PER_FRAME * frames_per_ep / 1e3            # the reference path's algorithmic work
         # executed work: the last ViT block is computed for the class-token rows only (engine.py: prune_last; few_shot.py:683 reads
-        # nothing else of it) -- (N - 1) (18 D^2 + 4 N D) FLOPs per frame fewer; every end-to-end fraction below is priced on THIS figure
+        # nothing else of it; q, attention, out_proj and the MLP of the other N - 1 rows) -- (N - 1) (20 D^2 + 4 N D) FLOPs per frame fewer; every
+        # end-to-end fraction below is priced on THIS figure
         gflop_exec = GFLOP_PER_FRAME
         pruned = False
         if not dry and ARCH.startswith("ViT") and getattr(eng.vit, "prune_last", False):
             a_ = synth.ARCHS[ARCH]
             n_, d_ = (a_["res"] // a_["patch"]) ** 2 + 1, a_["width"]
-            gflop_exec = GFLOP_PER_FRAME - (n_ - 1) * (18.0 * d_ * d_ + 4.0 * n_ * d_) / 1e9
+            gflop_exec = GFLOP_PER_FRAME - (n_ - 1) * (20.0 * d_ * d_ + 4.0 * n_ * d_) / 1e9
             pruned = True
         tflop_exec = gflop_exec * frames_per_ep / 1e3
         out = {

@@ -609,8 +609,9 @@ __global__ __launch_bounds__(256) void vit_attn_f32_kernel(const float* __restri
 // per-wave LDS row, all arithmetic in fp32.  Reads K and V once (2/3 of the qkv matrix): memory bound.
 // ------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void vit_attn_cls_kernel(const T* __restrict__ qkv, T* __restrict__ out, int ntok, int D, int heads,
-                                                           int nitems, float scale) {
+__global__ __launch_bounds__(256) void vit_attn_cls_kernel(const T* __restrict__ qp, long long ldq, const T* __restrict__ kp,
+                                                           const T* __restrict__ vp, int ldkv, T* __restrict__ out, int ntok, int D,
+                                                           int heads, int nitems, float scale) {
     constexpr int EPL = 16 / (int)sizeof(T);                      // elements per lane (16 bytes)
     constexpr int LPR = 64 / EPL;                                  // lanes per 64-element row: 8 (2-byte types) or 16 (fp32)
     constexpr int RPI = 64 / LPR;                                  // key rows per wave-instruction
@@ -620,12 +621,13 @@ __global__ __launch_bounds__(256) void vit_attn_cls_kernel(const T* __restrict__
     const int item = blockIdx.x * 4 + wave;
     if (item >= nitems) return;
     const int f = item / heads, h = item - f * heads;
-    const size_t ld = (size_t)3 * D;
-    const T* base = qkv + (size_t)f * ntok * ld + h * 64;
+    const size_t ld = (size_t)ldkv;
+    const T* kbase = kp + (size_t)f * ntok * ld + h * 64;
+    const T* vbase = vp + (size_t)f * ntok * ld + h * 64;
     const int r = lane / LPR, c = lane % LPR;
     float q[EPL];
     {
-        const tvec qv = *reinterpret_cast<const tvec*>(base + c * EPL);
+        const tvec qv = *reinterpret_cast<const tvec*>(qp + (size_t)f * ldq + h * 64 + c * EPL);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) q[e] = (float)qv[e] * scale;
     }
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(256) void vit_attn_cls_kernel(const T* __restrict__
     for (int it = 0; it < nit; ++it) {
         const int k = it * RPI + r;
         const int kk = k < ntok ? k : ntok - 1;
-        const tvec kv = *reinterpret_cast<const tvec*>(base + (size_t)kk * ld + D + c * EPL);
+        const tvec kv = *reinterpret_cast<const tvec*>(kbase + (size_t)kk * ld + c * EPL);
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) d = fmaf(q[e], (float)kv[e], d);
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(256) void vit_attn_cls_kernel(const T* __restrict__
         const int k = it * RPI + r;
         const bool ok = k < ntok;
         const int kk = ok ? k : ntok - 1;
-        const tvec vv = *reinterpret_cast<const tvec*>(base + (size_t)kk * ld + 2 * D + c * EPL);
+        const tvec vv = *reinterpret_cast<const tvec*>(vbase + (size_t)kk * ld + c * EPL);
         const float pk = ok ? p[kk] : 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pk, (float)vv[e], acc[e]);
@@ -812,21 +814,29 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
     return cfsar_fail("cfsar_vit_attention: bad dtype %d", dtype);
 }
 
-// The class-token form: out[f, :] = attention output of query row 0 of frame f (see vit_attn_cls_kernel).  qkv [F*ntok, 3*D] as for
-// cfsar_vit_attention; out [F, D]; dtype bf16 | fp16 | f32; ntok <= 320.
-extern "C" int cfsar_vit_attention_cls(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads, cfsar_stream_t stream) {
-    CFSAR_REQUIRE(qkv && out, "cfsar_vit_attention_cls: null pointer");
-    CFSAR_REQUIRE(F > 0 && ntok > 0 && ntok <= 320 && heads > 0 && D == heads * 64,
-                  "cfsar_vit_attention_cls: need D == heads*64, ntok <= 320 (D=%d heads=%d ntok=%d)", D, heads, ntok);
+// The class-token form: out[f, :] = softmax(q_f K_f^T / 8) V_f per head for ONE query per frame (see vit_attn_cls_kernel).  q: row f at q + f * ldq
+// (elements); k / v: token t of frame f at k / v + (f * ntok + t) * ldkv; head h at columns 64 h of each.  With the packed qkv matrix of
+// cfsar_vit_attention: q = qkv, ldq = ntok * 3 D, k = qkv + D, v = qkv + 2 D, ldkv = 3 D.  out [F, D]; dtype bf16 | fp16 | f32; ntok <= 320.
+extern "C" int cfsar_vit_attention_cls(const void* q, long long ldq, const void* k, const void* v, int ldkv, void* out, int dtype, int F,
+                                       int ntok, int D, int heads, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(q && k && v && out, "cfsar_vit_attention_cls: null pointer");
+    CFSAR_REQUIRE(F > 0 && ntok > 0 && ntok <= 320 && heads > 0 && D == heads * 64 && ldq >= D && ldkv >= D,
+                  "cfsar_vit_attention_cls: need D == heads*64, ntok <= 320, ldq / ldkv >= D (D=%d heads=%d ntok=%d)", D, heads, ntok);
+    const int esz = dtype == CFSAR_F32 ? 4 : 2;
+    CFSAR_REQUIRE((ldq * esz) % 16 == 0 && (ldkv * esz) % 16 == 0 && ((size_t)q % 16 | (size_t)k % 16 | (size_t)v % 16 | (size_t)out % 16) == 0,
+                  "cfsar_vit_attention_cls: rows must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nitems = F * heads;
     const dim3 grid((unsigned)((nitems + 3) / 4)), block(256);
     if (dtype == CFSAR_BF16)
-        hipLaunchKernelGGL(vit_attn_cls_kernel<__bf16>, grid, block, 0, s, static_cast<const __bf16*>(qkv), static_cast<__bf16*>(out), ntok, D, heads, nitems, 0.125f);
+        hipLaunchKernelGGL(vit_attn_cls_kernel<__bf16>, grid, block, 0, s, static_cast<const __bf16*>(q), ldq, static_cast<const __bf16*>(k),
+                           static_cast<const __bf16*>(v), ldkv, static_cast<__bf16*>(out), ntok, D, heads, nitems, 0.125f);
     else if (dtype == CFSAR_F16)
-        hipLaunchKernelGGL(vit_attn_cls_kernel<_Float16>, grid, block, 0, s, static_cast<const _Float16*>(qkv), static_cast<_Float16*>(out), ntok, D, heads, nitems, 0.125f);
+        hipLaunchKernelGGL(vit_attn_cls_kernel<_Float16>, grid, block, 0, s, static_cast<const _Float16*>(q), ldq, static_cast<const _Float16*>(k),
+                           static_cast<const _Float16*>(v), ldkv, static_cast<_Float16*>(out), ntok, D, heads, nitems, 0.125f);
     else if (dtype == CFSAR_F32)
-        hipLaunchKernelGGL(vit_attn_cls_kernel<float>, grid, block, 0, s, static_cast<const float*>(qkv), static_cast<float*>(out), ntok, D, heads, nitems, 0.125f);
+        hipLaunchKernelGGL(vit_attn_cls_kernel<float>, grid, block, 0, s, static_cast<const float*>(q), ldq, static_cast<const float*>(k),
+                           static_cast<const float*>(v), ldkv, static_cast<float*>(out), ntok, D, heads, nitems, 0.125f);
     else
         return cfsar_fail("cfsar_vit_attention_cls: bad dtype %d", dtype);
     return cfsar_check_launch("cfsar_vit_attention_cls");

@@ -210,9 +210,14 @@ class HipViT:
                 if prune and i == self.L - 1:
                     # last block: K / V from every token, everything behind the attention for the class-token rows only
                     xc, oc, uc, partc, rstatc = ws["xc"][:F_], ws["oc"][:F_], ws["uc"][:F_], ws["partc"][:F_], ws["rstatc"][:F_]
-                    hip.gemm_lnfold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], rstat, M=M)
-                    hip.vit_attention_cls(qkv, oc, F_, N, D, self.H)
+                    # ... and of q only the class-token rows: K | V for all M rows (N = 2 D: two thirds of the QKV GEMM), q for F rows
+                    kv = qkv.view(-1)[:M * 2 * D].view(M, 2 * D)
+                    hip.gemm_lnfold(x, b["wg_qkv"][D:], kv, b["c_qkv"][D:], b["d_qkv"][D:], rstat, M=M)
                     xc.copy_(x[:M].view(F_, N, D)[:, 0, :])                           # class-token rows of the stream
+                    rstatc.copy_(rstat[:M].view(F_, N, 4)[:, 0, :])
+                    qc = ws["hc"][:F_]
+                    hip.gemm_lnfold(xc, b["wg_qkv"][:D], qc, b["c_qkv"][:D], b["d_qkv"][:D], rstatc, M=F_)
+                    hip.vit_attention_cls(None, oc, F_, N, D, self.H, q=qc, kv=kv)
                     hip.gemm_residual_stats(oc, b["w_out"], xc, b["b_out"], partc, M=F_)
                     hip.ln_stats_finalize(partc, rstatc, F_, S, D)
                     hip.gemm_lnfold(xc, b["wg_fc"], uc, b["c_fc"], b["d_fc"], rstatc, act=hip.ACT_QUICKGELU, M=F_)

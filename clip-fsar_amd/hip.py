@@ -46,7 +46,7 @@ SIGNATURES = {
     "cfsar_attnpool_attend": [_c_p, _c_p, _c_p] + [_c_int] * 4 + [ctypes.c_float, _c_p],
     "cfsar_stem_conv3x3_s2": [_c_p] * 4 + [_c_int] * 6 + [_c_p],
     "cfsar_vit_attention": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
-    "cfsar_vit_attention_cls": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_vit_attention_cls": [_c_p, _c_i64, _c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_class_text_logits": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_build_sequences": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p],
     "cfsar_seq_attention": [_c_p, _c_p] + [_c_int] * 6 + [_c_f, _c_int, _c_p],
@@ -257,12 +257,25 @@ def vit_attention(qkv, out, F_, ntok, D, heads):
                                      heads, _stream()), "cfsar_vit_attention")
 
 
-def vit_attention_cls(qkv, out, F_, ntok, D, heads):
-    """Attention output of query row 0 (the class token) of every frame: out [F, D] (include/clipfsar_hip.h: cfsar_vit_attention_cls)."""
-    if qkv.dtype != out.dtype:
-        raise RuntimeError("vit_attention_cls: qkv/out dtype mismatch")
-    _check(lib().cfsar_vit_attention_cls(_dev(qkv, None, "qkv"), _dev(out, None, "out"), _code(qkv.dtype), F_, ntok, D,
-                                         heads, _stream()), "cfsar_vit_attention_cls")
+def vit_attention_cls(qkv, out, F_, ntok, D, heads, q=None, kv=None):
+    """Attention output of ONE query row per frame (the class token in the last ViT block): out [F, D] (include/clipfsar_hip.h:
+    cfsar_vit_attention_cls).  Either the packed qkv matrix [F*ntok, 3D] (query = row 0 of every frame), or q [F, D] + kv [F*ntok, 2D]
+    (k | v)."""
+    if q is None:
+        if qkv.dtype != out.dtype:
+            raise RuntimeError("vit_attention_cls: qkv/out dtype mismatch")
+        base, es = qkv.data_ptr(), qkv.element_size()
+        _dev(qkv, None, "qkv")
+        qp, ldq, kp, vp, ldkv, dt = base, ntok * 3 * D, base + D * es, base + 2 * D * es, 3 * D, qkv.dtype
+    else:
+        if not (q.dtype == kv.dtype == out.dtype):
+            raise RuntimeError("vit_attention_cls: q / kv / out dtype mismatch")
+        _dev(q, None, "q")
+        _dev(kv, None, "kv")
+        es = kv.element_size()
+        qp, ldq, kp, vp, ldkv, dt = q.data_ptr(), q.shape[1], kv.data_ptr(), kv.data_ptr() + D * es, 2 * D, kv.dtype
+    _check(lib().cfsar_vit_attention_cls(ctypes.c_void_p(qp), ldq, ctypes.c_void_p(kp), ctypes.c_void_p(vp), ldkv, _dev(out, None, "out"),
+                                         _code(dt), F_, ntok, D, heads, _stream()), "cfsar_vit_attention_cls")
 
 
 # ----------------------------------------------------------------------------------------------- few-shot tail ops

@@ -138,9 +138,12 @@ int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F, int ntok, 
                         cfsar_stream_t stream);
 
 /* The class-token form of the same attention: VisionTransformer.forward keeps only x[:, 0] after the LAST block
- * (few_shot.py:683), so that block needs the attention output of query row 0 of every frame alone.  qkv as above;
- * out [F, D] (row f = frame f).  dtype bf16 | fp16 | f32; ntok <= 320. */
-int cfsar_vit_attention_cls(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads, cfsar_stream_t stream);
+ * (few_shot.py:683), so that block needs the attention output of ONE query row per frame.  q: row f at q + f*ldq (elements);
+ * k / v: token t of frame f at k / v + (f*ntok + t)*ldkv, head h at columns 64h.  With the packed matrix of
+ * cfsar_vit_attention: q = qkv, ldq = ntok*3D, k = qkv + D, v = qkv + 2D, ldkv = 3D.  out [F, D] (row f = frame f).
+ * dtype bf16 | fp16 | f32; ntok <= 320; rows 16-byte aligned. */
+int cfsar_vit_attention_cls(const void* q, long long ldq, const void* k, const void* v, int ldkv, void* out, int dtype, int F,
+                            int ntok, int D, int heads, cfsar_stream_t stream);
 
 /* ---- A15b aux class logits: cos_sim(mean_T(feats), text_train) * scale  (few_shot.py:2937-2939, cos_sim :1115-1124).
  * feats [n_videos, T, E] f32, text [n_cls, E] f32, scale [1] f32 (device), out [n_videos, n_cls] f32. */
