@@ -641,6 +641,14 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         }
     }
     __syncthreads();
+#ifdef CFSAR_DEV
+    if (p.dbg & 32768) {                          // A/B: static priority for the younger half of the workgroup (cdna guide T5, static form)
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
+    if (p.dbg & 65536) {                          // A/B: ... for the older half
+        if (wave < 4) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     int sb = 0;                                   // stage that holds K tile 0 of the current output tile
     char* slab = smem + EPI_OFF + wave * EPI_SLAB;
 #ifdef CFSAR_DEV
