@@ -13,21 +13,22 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SMALL_CASES = ["t_5w1s_T8", "t_5w5s_T8_mb", "t_5w5s_q2_T8", "t_5w3s_T16_mb_d2", "t_5w2s_T4_sd", "t197_5w1s_T2",
                "t257_5w1s_T2", "rn_t_5w2s_T4"]
 
-# max |logits - reference| measured per golden case (MI355X, round 3, tools/parity_report.py -> profiles/r03_parity_table.md).  The 16-bit
+# max |logits - reference| measured per golden case (MI355X, round 3, tools/parity_report.py -> profiles/r03_parity_table.md; the larger of
+# the mid-round and the end-of-round table: the attention and last-block changes moved single cases by up to 25 % either way).  The 16-bit
 # modes' regression bounds are 2 x these (a bound 10 x the measured value lets a 10 x regression through); fp32 and the
 # full-size fp16 cases are held to the north-star 1e-3.
 MEASURED_DLOGITS = {
-    "t_5w1s_T8": {"bf16": 0.01661, "fp16": 0.003053},
-    "t_5w5s_T8_mb": {"bf16": 0.01428, "fp16": 0.003311},
-    "t_5w5s_q2_T8": {"bf16": 0.0154, "fp16": 0.003375},
-    "t_5w3s_T16_mb_d2": {"bf16": 0.02273, "fp16": 0.004392},
-    "t_5w2s_T4_sd": {"bf16": 0.004592, "fp16": 0.001235},
+    "t_5w1s_T8": {"bf16": 0.01661, "fp16": 0.003851},
+    "t_5w5s_T8_mb": {"bf16": 0.01457, "fp16": 0.003619},
+    "t_5w5s_q2_T8": {"bf16": 0.0154, "fp16": 0.003699},
+    "t_5w3s_T16_mb_d2": {"bf16": 0.023, "fp16": 0.005109},
+    "t_5w2s_T4_sd": {"bf16": 0.004592, "fp16": 0.001315},
     "t197_5w1s_T2": {"bf16": 0.008524, "fp16": 0.001421},
-    "t257_5w1s_T2": {"bf16": 0.003391, "fp16": 0.000374},
+    "t257_5w1s_T2": {"bf16": 0.003434, "fp16": 0.000643},
     "rn_t_5w2s_T4": {"bf16": 0.002072, "fp16": None},
-    "cfg2_B16_5w1s_T8": {"bf16": 0.003045, "fp16": 0.0007601},
-    "cfg3_B16_5w5s_T8_mb": {"bf16": 0.003766, "fp16": 0.0007486},
-    "cfg4_L14_5w1s_T16": {"bf16": 0.004307, "fp16": 0.001474},
+    "cfg2_B16_5w1s_T8": {"bf16": 0.003286, "fp16": 0.0007601},
+    "cfg3_B16_5w5s_T8_mb": {"bf16": 0.003766, "fp16": 0.0008583},
+    "cfg4_L14_5w1s_T16": {"bf16": 0.005474, "fp16": 0.001487},
     "rn50_5w1s_T2": {"bf16": 0.005736, "fp16": None},
 }
 
