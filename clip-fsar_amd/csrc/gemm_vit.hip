@@ -43,6 +43,12 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
+// residual rows of an output tile's first pass fetched before its last K step on the LDS-DMA paths (A/B: -DCFSAR_PRE_OPATH1_ONLY)
+#ifdef CFSAR_PRE_OPATH1_ONLY
+constexpr int kPreMinOpath = 1, kPreMaxOpath = 1;
+#else
+constexpr int kPreMinOpath = 1, kPreMaxOpath = 2;
+#endif
 #ifndef CFSAR_EPI_PIPE
 #define CFSAR_EPI_PIPE 0      // 1 = software-pipelined epilogue stores (measured neutral to negative: profiles/r03_gemm_anatomy.md)
 #endif
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         u32x4 rv0[4] = {};
         // (LDS-DMA instance only: in the register-staged one 16 more live registers across the last K step cost 22-30 spills and 10 %)
         auto residual_prefetch = [&]() __attribute__((always_inline)) {     // rows rr + 8 it of the wave's first 32-row pass
-            if constexpr (HAS_RES && OPATH == 1) {
+            if constexpr (HAS_RES && (OPATH >= kPreMinOpath && OPATH <= kPreMaxOpath)) {
                 const int mb_ = m0 + wm * 128, nb_ = n0 + wn * 64;
                 const int ncl_ = nb_ + 64 <= p.N ? nb_ : p.N - 64;
                 const int rr_ = lane >> 3, Q_ = lane & 7;
@@ -732,8 +738,8 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
 #endif
         {
             const int mb = m0 + wm * 128, nb = n0 + wn * 64;
-            if (mb + 128 <= p.M && nb + 64 <= p.N) epilogue_rows<TO, ACT, HAS_RES, STORE, true, LNFOLD, HAS_RES && OPATH == 1, HB>(acc, p, mb, nb, lane, slab, rscale, rv0);
-            else epilogue_rows<TO, ACT, HAS_RES, STORE, false, LNFOLD, HAS_RES && OPATH == 1, HB>(acc, p, mb, nb, lane, slab, rscale, rv0);
+            if (mb + 128 <= p.M && nb + 64 <= p.N) epilogue_rows<TO, ACT, HAS_RES, STORE, true, LNFOLD, HAS_RES && (OPATH >= kPreMinOpath && OPATH <= kPreMaxOpath), HB>(acc, p, mb, nb, lane, slab, rscale, rv0);
+            else epilogue_rows<TO, ACT, HAS_RES, STORE, false, LNFOLD, HAS_RES && (OPATH >= kPreMinOpath && OPATH <= kPreMaxOpath), HB>(acc, p, mb, nb, lane, slab, rscale, rv0);
         }
         CFSAR_TRACE(2);
 #ifdef CFSAR_DEV

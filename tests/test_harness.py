@@ -365,7 +365,9 @@ def test_test_epoch_with_pinned_host_inputs_keeps_up_with_resident_inputs():
         torch.cuda.synchronize()
         return time.perf_counter() - t0, res
     timed(_Steps(resident))                         # warm-up: engine build, workspaces
-    t_res, r_res = timed(_Steps(resident))
-    t_host, r_host = timed(_Steps(host))
+    timed(_Steps(host))                             # ... and the prefetcher's device buffers
+    runs_res = [timed(_Steps(resident)) for _ in range(3)]
+    runs_host = [timed(_Steps(host)) for _ in range(3)]
+    (t_res, r_res), (t_host, r_host) = min(runs_res, key=lambda r: r[0]), min(runs_host, key=lambda r: r[0])   # best of 3 each
     assert r_host["episodes"] == B * steps and abs(r_host["top1_acc"] - r_res["top1_acc"]) < 1e-6
     assert t_res / t_host >= 0.95, "host-input harness %.1f episodes/s vs resident %.1f" % (B * steps / t_host, B * steps / t_res)
