@@ -101,6 +101,11 @@ __device__ __forceinline__ void glds16_asm_pol(const char* src, unsigned lds_add
 // instructions (clip-fsar_amd/build.py SOURCE_FLAGS; 0 of 1 500 stress launches against 44 of 150, same speed).  An earlier workaround
 // (pinning the transcendental operands with empty asm statements) is no longer needed and was removed.  Guards:
 // tests/test_gpu_kernels.py::test_gemm_lnfold_* and ::test_vit_gemms_are_bit_stable_under_a_second_stream, tools/stream_stress.py.
+#ifdef CFSAR_GELU_UNFUSED                      // A/B builds: row scale as its own multiply in front of quick_gelu4
+constexpr bool kGeluRowFused = false;
+#else
+constexpr bool kGeluRowFused = true;
+#endif
 __device__ __forceinline__ void quick_gelu4(float (&v)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -235,16 +240,35 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
     // mi - 1 BETWEEN the convert groups of pass mi; measured neutral (QKV, c_fc) to negative (residual instances): what the stores
     // cost is not issue time inside the epilogue but memory-system interference with every workgroup's operand loads during the K
     // loops that follow (profiles/r03_gemm_anatomy.md: workgroups that skip their stores slow down exactly like those that store).
+    float gelu_k[4] = {0.f, 0.f, 0.f, 0.f}, gelu_sd[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (ROWSCALE && ACT == CFSAR_ACT_QUICKGELU) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            gelu_k[mi] = -1.702f * 1.4426950408889634f * rscale[mi];
+            gelu_sd[mi] = __builtin_amdgcn_rcpf(rscale[mi]);
+        }
+    }
     auto convert_group = [&](int mi, int q) __attribute__((always_inline)) {
         const int ni = q >> 2, g = q & 3;
         TO4 o;
         float v[4];
+        if constexpr (kGeluRowFused && ROWSCALE && ACT == CFSAR_ACT_QUICKGELU) {
+            // a / std * sigmoid(1.702 a / std) = a / (std + std * 2^(a * k)), k = -1.702 log2(e) / std: the row scale rides inside the
+            // sigmoid's denominator (one fma) instead of costing a multiply per element: 3 VALU + 2 transcendental instructions
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = acc[mi][ni][4 * g + j];
-            if constexpr (ROWSCALE) v[j] *= rscale[mi];
+            for (int j = 0; j < 4; ++j) {
+                const float a = acc[mi][ni][4 * g + j];
+                const float e = __builtin_amdgcn_exp2f(a * gelu_k[mi]);
+                v[j] = a * __builtin_amdgcn_rcpf(__builtin_fmaf(e, gelu_sd[mi], gelu_sd[mi]));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc[mi][ni][4 * g + j];
+                if constexpr (ROWSCALE) v[j] *= rscale[mi];
+            }
+            if constexpr (ACT == CFSAR_ACT_QUICKGELU) quick_gelu4(v);
         }
-        if constexpr (ACT == CFSAR_ACT_QUICKGELU) quick_gelu4(v);
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (TO)v[j];
         const int slot = (2 * (ni * 4 + g) + hi) ^ wsw;
