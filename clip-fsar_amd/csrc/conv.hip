@@ -2,6 +2,8 @@
 // Activations are NHWC ([F*H*W, C] row-major) so 1x1 convolutions are plain GEMM rows and 3x3 convolutions become a
 // GEMM after a tap-major gather (column = (ky*3+kx)*C + c).  BatchNorm (eval) is folded into the conv weights / bias on
 // the host, ReLU and the identity add are GEMM epilogues (cfsar_gemm_ex); what remains here is memory-bound.
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -311,4 +313,241 @@ extern "C" int cfsar_stem_conv3x3_s2(const float* frames, const float* w, const 
     if (out_dtype == CFSAR_BF16) return launch_stem<__bf16>(frames, w, bias, out, F, H, W, Cout, relu, s);
     if (out_dtype == CFSAR_F32) return launch_stem<float>(frames, w, bias, out, F, H, W, Cout, relu, s);
     return cfsar_fail("cfsar_stem_conv3x3_s2: bad out_dtype %d", out_dtype);
+}
+
+// ============================================================================================================
+// Direct 3x3 / pad 1 / stride 1 convolution for NARROW channel counts (Cin, Cout in {32, 64}: the RN50 stem convs 2 / 3 and the
+// conv2 of layer1, few_shot.py:549-554, 196-197), bf16 NHWC in, bf16 NHWC out, bias (+ ReLU) fused.
+//
+// The implicit-GEMM path (gemm.hip, p3 CONV NARROW) gathers every input pixel NINE times from L2 into the operand tile; with 64-128
+// bytes per pixel these convs are bound by that gather (1.1 ms per launch at 16 episodes against 0.2-0.6 ms of HBM time).  Here:
+//   * the NHWC tensor is ONE linear stream of pixels; a persistent workgroup (4 waves, one per SIMD) walks a contiguous range of
+//     128-pixel tiles and keeps a RING of 1 024 pixels of that stream in LDS, filled by LDS-DMA in 128-pixel chunks SIX chunks
+//     ahead: every pixel is fetched once per workgroup (plus the halo at the two ends of its range);
+//   * a tap is an LDS read at (pixel + dy W + dx) mod 1 024 -- the MFMA "B" fragment of 32 consecutive pixels x 8 channels is one
+//     ds_read_b128 (128-byte rows, chunk ^ ((row >> 1) & 7); for Cin = 32 two pixels share a row and the mask is 3: both layouts
+//     are bank-conflict free for every tap offset), lanes whose tap falls outside the image read a zero row instead;
+//   * the WEIGHTS live in registers for the whole launch (9 taps x Cin/16 x Cout/32 fragments = 72 ... 288 VGPRs / AGPRs: one wave
+//     per SIMD owns 512 registers), so the inner loop is one ds_read_b128 per Cout/32 MFMAs and nothing else;
+//   * epilogue: bias is the accumulators' initial value; ReLU, bf16 pack, transpose through a 2-4 KiB wave-private slab, 16-byte
+//     stores of whole pixel rows (the wave's 32 pixels are 2-4 KiB of contiguous output).
+// ============================================================================================================
+namespace {
+
+__device__ __forceinline__ void dc_glds16(const char* src, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_addr)
+        : "memory");
+}
+
+template <typename F, int... Is>
+__device__ __forceinline__ void dc_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void dc_static_for(F&& f) {
+    dc_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+struct DirectConvArgs {
+    const char* in;
+    const char* w;
+    char* out;
+    const float* bias;
+    int M, H, W;            // pixels in the stream, image height / width
+    unsigned invW, invH;    // floor(2^32 / W) + 1, floor(2^32 / H) + 1: exact quotients for operands < 2^25
+    int ldw;                // weight row pitch in elements (round_up(9 Cin, 64))
+    int relu;
+    int ntiles;
+};
+
+constexpr int DC_TILE = 128;        // pixels per tile = per DMA chunk
+constexpr int DC_RING = 1024;       // pixels in the LDS ring = 8 chunks
+constexpr int DC_NCH = 8;
+
+template <int N> __device__ __forceinline__ void dc_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(DirectConvArgs p) {
+    constexpr int PXB = CIN * 2;                  // bytes per pixel
+    constexpr int RPC = PXB;                      // 128-byte LDS rows per 128-pixel chunk
+    constexpr int DPW = RPC / 32;                 // LDS-DMA instructions per wave and chunk (1 KiB each)
+    constexpr int RING_BYTES = DC_RING * PXB;
+    constexpr int KC = CIN / 16, NI = COUT / 32;
+    constexpr int SWM = CIN == 64 ? 7 : 3;
+    constexpr int ZOFF = RING_BYTES;              // 128 bytes of zeros
+    constexpr int SLAB0 = RING_BYTES + 128;
+    constexpr int SLAB = 32 * COUT * 2;
+    constexpr int NSLOT = COUT / 4;               // 8-byte slots per slab row
+    constexpr int LPR = COUT / 8;                 // lanes per output row (16 bytes each)
+    constexpr int RPI = 64 / LPR;                 // rows per store instruction
+    constexpr int NS = 32 / RPI;                  // store instructions per tile and wave
+    constexpr int NACC = NI == 1 ? 2 : NI;        // one output column tile: two accumulators break the MFMA dependence chain
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, hi = lane >> 5;
+
+    const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t0 = (int)blockIdx.x * per;
+    const int t1 = t0 + per < p.ntiles ? t0 + per : p.ntiles;
+    if (t0 >= t1) return;
+
+    if (tid < 32) *reinterpret_cast<unsigned*>(smem + ZOFF + tid * 4) = 0u;
+
+    // weights -> registers: fragment (tap, kc, ni) = W[32 ni + lr][tap Cin + 16 kc + 8 hi .. + 8]
+    uint4 wr[9][KC][NI];
+    dc_static_for<9>([&](auto T) {
+        dc_static_for<KC>([&](auto K) {
+            dc_static_for<NI>([&](auto N) {
+                wr[T.value][K.value][N.value] = *reinterpret_cast<const uint4*>(
+                    p.w + ((size_t)(32 * N.value + lr) * p.ldw + T.value * CIN + 16 * K.value + 8 * hi) * 2);
+            });
+        });
+    });
+    // bias in the accumulator layout: element 4 g + j of column tile ni is output channel 32 ni + 8 g + 4 hi + j
+    float br[NI][16];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) br[ni][e] = p.bias ? p.bias[32 * ni + 8 * (e >> 2) + 4 * hi + (e & 3)] : 0.0f;
+
+    // LDS-DMA: instruction j = wave + 4 i of a chunk fills its rows 8 j .. 8 j + 7; lane (rr, pos) brings the 16-byte piece that
+    // belongs at position pos of row 8 j + rr, i.e. chunk pos ^ swizzle(row) of that row of the stream
+    const long long nrows = (long long)p.M * PXB / 128;
+    int srow[DPW], soff[DPW];
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+        const int rowin = 8 * (wave + 4 * i) + (lane >> 3);
+        srow[i] = rowin;
+        soff[i] = ((lane & 7) ^ ((rowin >> 1) & SWM)) << 4;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(c & (DC_NCH - 1)) * (RPC * 128) + (unsigned)wave * 1024u);
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            long long g = (long long)c * RPC + srow[i];
+            g = g < 0 ? 0 : (g >= nrows ? nrows - 1 : g);
+            dc_glds16(p.in + g * 128 + soff[i], base + i * 4096);
+        }
+    };
+    for (int c = t0 - 1; c <= t0 + DC_NCH - 3; ++c) issue(c);
+
+    const int ck0 = hi << 4;
+    char* slab = smem + SLAB0 + wave * SLAB;
+    const int rsub = lane / LPR, Q = lane % LPR;
+
+    for (int t = t0; t < t1; ++t) {
+        // chunk t + 1 has landed: behind it in the queue are chunks t + 2 ... t + 5 and the stores of up to five tiles
+        if (t - t0 < 5) dc_wait_vm<4 * DPW>();
+        else dc_wait_vm<4 * DPW + 5 * NS>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // every wave is done with tile t - 1: chunk t - 2 is dead
+        issue(t + DC_NCH - 2);
+
+        const int pix = t * DC_TILE + wave * 32 + lr;
+        const int pc = pix < p.M ? pix : p.M - 1;
+        const int rowi = (int)__umulhi((unsigned)pc, p.invW);
+        const int x = pc - rowi * p.W;
+        const int y = rowi - (int)__umulhi((unsigned)rowi, p.invH) * p.H;
+        int abase[9], aswz[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const bool ok = (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
+            const int slot = (pc + dy * p.W + dx) & (DC_RING - 1);
+            const int lrow = CIN == 64 ? slot : slot >> 1;
+            const int chb = CIN == 64 ? 0 : (slot & 1) * 4;
+            abase[tap] = ok ? lrow * 128 : ZOFF;
+            aswz[tap] = ok ? ((chb ^ ((lrow >> 1) & SWM)) << 4) : 0;
+        }
+        f32x16 acc[NACC];
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][e] = (a < NI) ? br[a < NI ? a : 0][e] : 0.0f;
+
+        dc_static_for<9>([&](auto T) {
+            dc_static_for<KC>([&](auto K) {
+                const uint4 af = *reinterpret_cast<const uint4*>(smem + abase[T.value] + (aswz[T.value] ^ ((2 * K.value) << 4) ^ ck0));
+                dc_static_for<NI>([&](auto N) {
+                    constexpr int a = NI == 1 ? ((T.value * KC + K.value) & 1) : N.value;
+                    acc[a] = cfsar_mfma_32x32x16<__bf16>(wr[T.value][K.value][N.value], af, acc[a]);
+                });
+            });
+        });
+        if constexpr (NI == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][e] += acc[1][e];
+        }
+
+        // epilogue: [ReLU] -> bf16 -> slab (8-byte slot (2 (4 ni + g) + hi) ^ (lr & (NSLOT - 1)) of row lr) -> 16-byte row-contiguous stores
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[ni][4 * g + j];
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    o[j] = (__bf16)v;
+                }
+                const int sl = (2 * (4 * ni + g) + hi) ^ (lr & (NSLOT - 1));
+                *reinterpret_cast<bf16x4*>(slab + lr * (COUT * 2) + sl * 8) = o;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private slab: in-order DS + this wait
+#pragma unroll
+        for (int it = 0; it < NS; ++it) {
+            const int row = it * RPI + rsub;
+            const int f = row & (NSLOT - 1);
+            uint4 d = *reinterpret_cast<const uint4*>(slab + row * (COUT * 2) + ((Q ^ (f >> 1)) << 4));
+            if (f & 1) d = uint4{d.z, d.w, d.x, d.y};
+            const int opix = t * DC_TILE + wave * 32 + row;
+            if (opix < p.M) *reinterpret_cast<uint4*>(p.out + (size_t)opix * (COUT * 2) + Q * 16) = d;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no LDS-DMA may outlive the workgroup
+}
+
+template <int CIN, int COUT>
+int launch_direct_conv(const DirectConvArgs& a, hipStream_t s) {
+    constexpr int LDS = DC_RING * CIN * 2 + 128 + 4 * 32 * COUT * 2;
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&conv3x3_direct_kernel<CIN, COUT>), LDS, "cfsar_conv3x3_nhwc(direct)")) return rc;
+    const int cus = cfsar_num_cus();
+    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    hipLaunchKernelGGL((conv3x3_direct_kernel<CIN, COUT>), dim3(grid), dim3(256), LDS, s, a);
+    return cfsar_check_launch("cfsar_conv3x3_nhwc(direct)");
+}
+
+}  // namespace
+
+// Called by cfsar_conv3x3_nhwc (gemm.hip) for the shapes this kernel covers; returns -2 when it does not apply.
+int cfsar_conv3x3_direct(const void* in, const void* W, void* out, const float* bias, int F, int H, int Wd, int C, int Cout, int ldw,
+                         int ldo, int relu, hipStream_t s) {
+    const long long M = (long long)F * H * Wd;
+    if (!((C == 32 || C == 64) && (Cout == 32 || Cout == 64) && !(C == 64 && Cout == 32))) return -2;
+    if (ldo != Cout || Wd + 1 > DC_TILE || Wd < 2 || H < 2 || M >= (1ll << 25) || (M * C * 2) % 128 != 0 || M < DC_TILE) return -2;
+    DirectConvArgs a;
+    a.in = static_cast<const char*>(in);
+    a.w = static_cast<const char*>(W);
+    a.out = static_cast<char*>(out);
+    a.bias = bias;
+    a.M = (int)M; a.H = H; a.W = Wd;
+    a.invW = (unsigned)((1ull << 32) / (unsigned)Wd) + 1u;
+    a.invH = (unsigned)((1ull << 32) / (unsigned)H) + 1u;
+    a.ldw = ldw;
+    a.relu = relu;
+    a.ntiles = (int)((M + DC_TILE - 1) / DC_TILE);
+    if (C == 32 && Cout == 32) return launch_direct_conv<32, 32>(a, s);
+    if (C == 32 && Cout == 64) return launch_direct_conv<32, 64>(a, s);
+    return launch_direct_conv<64, 64>(a, s);
 }

@@ -1530,6 +1530,12 @@ extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* 
                          row_off, res_mod, res_off, CFSAR_F32, 0, stream);
 }
 
+#ifdef CFSAR_DEV
+static int g_no_direct_conv = 0;        // dev A/B: cfsar_debug_set_direct_conv(0) routes the narrow convs through the implicit GEMM again
+extern "C" void cfsar_debug_set_direct_conv(int on) { g_no_direct_conv = !on; }
+#else
+constexpr int g_no_direct_conv = 0;
+#endif
 // Implicit-GEMM 3x3 convolution (pad 1, stride 1) on NHWC bf16 activations: out[f,y,x,:] = [relu](W . patch(f,y,x) + bias
 // (+ residual)); W is [Cout, ldw] tap-major ((ky*3+kx)*C + c), zero-padded to ldw = round_up(9*C, 64).  See the header.
 extern "C" int cfsar_conv3x3_nhwc(const void* in, const void* W, void* out, const float* bias, const void* residual, int F,
@@ -1566,6 +1572,11 @@ extern "C" int cfsar_conv3x3_nhwc(const void* in, const void* W, void* out, cons
     while ((1 << a.conv_lgC) < C) ++a.conv_lgC;
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int conv_variant = 0;     // 3 / 4: force the 256x128 / 256x64 tile (A/B history: tools/rn_gemm_ab.py)
+    // Cin, Cout in {32, 64}: the direct kernel (conv.hip: the input ring in LDS, weights in registers) instead of the 9-fold gather
+    if (out_dtype == CFSAR_BF16 && !residual && conv_variant == 0 && !g_no_direct_conv) {
+        const int rc = cfsar_conv3x3_direct(in, W, out, bias, F, H, Wd, C, Cout, ldw, ldo, relu, s);
+        if (rc != -2) return rc;
+    }
     if (out_dtype == CFSAR_BF16 && (conv_variant == 4 || (conv_variant == 0 && Cout <= 64))) {     // 256x64 tile
         a.tiles_n = (Cout + 63) / 64;
         return residual ? launch_p3_inst<__bf16, __bf16, CFSAR_ACT_NONE, true, false, true, true>(a, s)

@@ -240,15 +240,16 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
     // mi - 1 BETWEEN the convert groups of pass mi; measured neutral (QKV, c_fc) to negative (residual instances): what the stores
     // cost is not issue time inside the epilogue but memory-system interference with every workgroup's operand loads during the K
     // loops that follow (profiles/r03_gemm_anatomy.md: workgroups that skip their stores slow down exactly like those that store).
-    float gelu_k[4] = {0.f, 0.f, 0.f, 0.f}, gelu_sd[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (ROWSCALE && ACT == CFSAR_ACT_QUICKGELU) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            gelu_k[mi] = -1.702f * 1.4426950408889634f * rscale[mi];
-            gelu_sd[mi] = __builtin_amdgcn_rcpf(rscale[mi]);
+    // per 32-row pass: k = -1.702 log2(e) / std and std of the pass's row (two registers live at a time)
+    auto gelu_consts = [&](int mi, float& gk, float& gsd) __attribute__((always_inline)) {
+        if constexpr (kGeluRowFused && ROWSCALE && ACT == CFSAR_ACT_QUICKGELU) {
+            float rs = rscale[mi];
+            asm volatile("" : "+v"(rs));            // computed HERE, not hoisted into the K loop's last steps (24 spilled registers)
+            gk = -1.702f * 1.4426950408889634f * rs;
+            gsd = __builtin_amdgcn_rcpf(rs);
         }
-    }
-    auto convert_group = [&](int mi, int q) __attribute__((always_inline)) {
+    };
+    auto convert_group = [&](int mi, int q, float gk, float gsd) __attribute__((always_inline)) {
         const int ni = q >> 2, g = q & 3;
         TO4 o;
         float v[4];
@@ -258,8 +259,8 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float a = acc[mi][ni][4 * g + j];
-                const float e = __builtin_amdgcn_exp2f(a * gelu_k[mi]);
-                v[j] = a * __builtin_amdgcn_rcpf(__builtin_fmaf(e, gelu_sd[mi], gelu_sd[mi]));
+                const float e = __builtin_amdgcn_exp2f(a * gk);
+                v[j] = a * __builtin_amdgcn_rcpf(__builtin_fmaf(e, gsd, gsd));
             }
         } else {
 #pragma unroll
@@ -332,9 +333,11 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
             for (int it = 0; it < 4; ++it) rv[it] = rvn[it];
         }
         if (mi < 3) load_res(mi + 1);
+        float gk = 0.f, gsd = 0.f;
+        gelu_consts(mi, gk, gsd);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            convert_group(mi, q);
+            convert_group(mi, q, gk, gsd);
             if (mi > 0 && (q & 1)) {
                 finish(mi - 1, q >> 1, dprev[q >> 1], rvprev[q >> 1]);
             }
@@ -357,8 +360,10 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
             if constexpr (HAS_RES) rv[it] = rvn[it];
         }
         if (mi < 3) load_res(mi + 1);
+        float gk = 0.f, gsd = 0.f;
+        gelu_consts(mi, gk, gsd);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) convert_group(mi, q);
+        for (int q = 0; q < 8; ++q) convert_group(mi, q, gk, gsd);
         u32x4 d[4];
         read_back(d);
 #pragma unroll

@@ -124,6 +124,7 @@ def test_hot_kernels_use_no_scratch():
         "gemm_kernel_p10IDF16bLi0ELb0ELb0ELb0E": 0, "gemm_kernel_p10IfLi0ELb1ELb0ELb0E": 0,
         "gemm_kernel_p3IDF16bDF16bLi0ELb0ELb0ELb1ELb0E": 0, "gemm_kernel_p3IDF16bDF16bLi0ELb0ELb0ELb1ELb1E": 0,   # RN50 implicit convs
         "stem_conv1_kernel": 0,
+        "conv3x3_direct_kernelILi32ELi32E": 0, "conv3x3_direct_kernelILi32ELi64E": 0, "conv3x3_direct_kernelILi64ELi64E": 0,   # weights in registers
         "cos_otam_kernel": 0,                              # OTAM DP rows in registers (T = 8 / 16) or LDS (run-time T)
         "skinny_gemm_f32_kernel": 0,
     }

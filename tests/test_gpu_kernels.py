@@ -441,6 +441,34 @@ def test_conv3x3_implicit_gemm(hip, C, H, W_, Co, res):
     assert maxdiff(out32.cpu(), ref2) < 2e-3 * max(1.0, float(ref2.abs().max()))
 
 
+@pytest.mark.parametrize("C,Co,Fn,H,W_", [(32, 32, 24, 112, 112), (32, 64, 7, 112, 112), (64, 64, 90, 56, 56), (32, 64, 3, 9, 127),
+                                         (64, 64, 2, 33, 5), (32, 32, 2, 8, 8)])
+def test_conv3x3_direct_kernel(hip, C, Co, Fn, H, W_):
+    """The direct kernel behind cfsar_conv3x3_nhwc for Cin, Cout in {32, 64} (csrc/conv.hip: LDS pixel ring + weights in registers) ==
+    relu(nn.Conv2d(3, padding=1) + bias) on bf16-rounded operands: many tiles per workgroup (the ring wraps several times), the
+    widest image the halo allows (W = 127), images narrower than the halo, a ragged last tile, frame borders inside a tile."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(Fn, C, H, W_, generator=g)).to(torch.bfloat16).cuda()
+    w = (torch.randn(Co, C, 3, 3, generator=g) * (9 * C) ** -0.5).to(torch.bfloat16).cuda()
+    bias = torch.randn(Co, generator=g).cuda()
+    kpad = -(-9 * C // 64) * 64
+    wt = torch.zeros(Co, kpad, dtype=torch.bfloat16, device="cuda")
+    wt[:, :9 * C] = w.permute(0, 2, 3, 1).reshape(Co, 9 * C)
+    xd = x.permute(0, 2, 3, 1).contiguous()
+    ref = torch.relu(F.conv2d(x.float(), w.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co) + bias)
+    out = torch.full((Fn * H * W_, Co), float("nan"), device="cuda", dtype=torch.bfloat16)
+    hip.conv3x3(xd, wt, out, Fn, H, W_, C, bias=bias, relu=True)
+    torch.cuda.synchronize()
+    d = (out.float() - ref).abs()
+    assert not torch.isnan(out.float()).any()
+    assert float(d.max()) < 2e-2 * max(1.0, float(ref.abs().max())), (float(d.max()), int(d.argmax()) // Co)
+    out2 = torch.full_like(out, float("nan"))                    # no ReLU, no bias
+    hip.conv3x3(xd, wt, out2, Fn, H, W_, C)
+    ref2 = F.conv2d(x.float(), w.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    assert float((out2.float() - ref2).abs().max()) < 2e-2 * max(1.0, float(ref2.abs().max()))
+
+
 @pytest.mark.parametrize("T,heads,hd", [(50, 32, 64), (5, 4, 8), (82, 2, 128)])
 def test_attnpool_attend_single_query(hip, T, heads, hd):
     """cfsar_attnpool_attend == row 0 of softmax(scale q k^T) v per head (the only row AttentionPool2d returns,
