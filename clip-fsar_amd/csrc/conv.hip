@@ -366,7 +366,15 @@ struct DirectConvArgs {
     int ldw;                // weight row pitch in elements (round_up(9 Cin, 64))
     int relu;
     int ntiles;
+#ifdef CFSAR_DEV
+    int dbg;                // ablation bits (tools/rn_conv_ab.py): 1 no stores, 2 tap addresses of the first tile only, 4 no MFMAs, 8 no barrier
+#endif
 };
+#ifdef CFSAR_DEV
+#define DCDBG(p) ((p).dbg)
+#else
+#define DCDBG(p) 0
+#endif
 
 constexpr int DC_TILE = 128;        // pixels per tile = per DMA chunk
 constexpr int DC_RING = 1024;       // pixels in the LDS ring = 8 chunks
@@ -375,24 +383,26 @@ constexpr int DC_NCH = 8;
 template <int N> __device__ __forceinline__ void dc_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv3x3_direct_kernel(DirectConvArgs p) {
+__global__ __launch_bounds__(256, CIN == 32 ? 2 : 1) void conv3x3_direct_kernel(DirectConvArgs p) {
     constexpr int PXB = CIN * 2;                  // bytes per pixel
     constexpr int RPC = PXB;                      // 128-byte LDS rows per 128-pixel chunk
     constexpr int DPW = RPC / 32;                 // LDS-DMA instructions per wave and chunk (1 KiB each)
     constexpr int RING_BYTES = DC_RING * PXB;
-    constexpr int KC = CIN / 16, NI = COUT / 32;
+    constexpr int KC = CIN / 16;
+    constexpr int WCO = COUT / 32;                // waves across the output channels (32 each)
+    constexpr int WPX = 4 / WCO;                  // waves across the tile's pixels
+    constexpr int MI = 4 / WPX;                   // 32-pixel MFMA tiles per wave
+    constexpr int NSTEP = 9 * KC;
     constexpr int SWM = CIN == 64 ? 7 : 3;
     constexpr int ZOFF = RING_BYTES;              // 128 bytes of zeros
     constexpr int SLAB0 = RING_BYTES + 128;
-    constexpr int SLAB = 32 * COUT * 2;
-    constexpr int NSLOT = COUT / 4;               // 8-byte slots per slab row
-    constexpr int LPR = COUT / 8;                 // lanes per output row (16 bytes each)
-    constexpr int RPI = 64 / LPR;                 // rows per store instruction
-    constexpr int NS = 32 / RPI;                  // store instructions per tile and wave
-    constexpr int NACC = NI == 1 ? 2 : NI;        // one output column tile: two accumulators break the MFMA dependence chain
+    constexpr int SLAB = 32 * 32 * 2;             // 32 pixels x 32 channels
+    constexpr int NS = 2 * MI;                    // store instructions per tile and wave (16 rows x 64 bytes each)
+    constexpr int NACC = MI == 1 ? 2 : MI;        // one pixel tile: two accumulators break the MFMA dependence chain
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave % WCO, pg = wave / WCO;
     const int lr = lane & 31, hi = lane >> 5;
 
     const int per = (p.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -402,22 +412,16 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(DirectConvArgs p) {
 
     if (tid < 32) *reinterpret_cast<unsigned*>(smem + ZOFF + tid * 4) = 0u;
 
-    // weights -> registers: fragment (tap, kc, ni) = W[32 ni + lr][tap Cin + 16 kc + 8 hi .. + 8]
-    uint4 wr[9][KC][NI];
-    dc_static_for<9>([&](auto T) {
-        dc_static_for<KC>([&](auto K) {
-            dc_static_for<NI>([&](auto N) {
-                wr[T.value][K.value][N.value] = *reinterpret_cast<const uint4*>(
-                    p.w + ((size_t)(32 * N.value + lr) * p.ldw + T.value * CIN + 16 * K.value + 8 * hi) * 2);
-            });
-        });
+    // weights -> registers: fragment (tap, kc) = W[32 cg + lr][tap Cin + 16 kc + 8 hi .. + 8]
+    uint4 wr[NSTEP];
+    dc_static_for<NSTEP>([&](auto S) {
+        constexpr int tap = S.value / KC, kc = S.value % KC;
+        wr[S.value] = *reinterpret_cast<const uint4*>(p.w + ((size_t)(32 * cg + lr) * p.ldw + tap * CIN + 16 * kc + 8 * hi) * 2);
     });
-    // bias in the accumulator layout: element 4 g + j of column tile ni is output channel 32 ni + 8 g + 4 hi + j
-    float br[NI][16];
+    // bias in the accumulator layout: element 4 g + j is output channel 32 cg + 8 g + 4 hi + j
+    float br[16];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) br[ni][e] = p.bias ? p.bias[32 * ni + 8 * (e >> 2) + 4 * hi + (e & 3)] : 0.0f;
+    for (int e = 0; e < 16; ++e) br[e] = p.bias ? p.bias[32 * cg + 8 * (e >> 2) + 4 * hi + (e & 3)] : 0.0f;
 
     // LDS-DMA: instruction j = wave + 4 i of a chunk fills its rows 8 j .. 8 j + 7; lane (rr, pos) brings the 16-byte piece that
     // belongs at position pos of row 8 j + rr, i.e. chunk pos ^ swizzle(row) of that row of the stream
@@ -443,76 +447,114 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(DirectConvArgs p) {
 
     const int ck0 = hi << 4;
     char* slab = smem + SLAB0 + wave * SLAB;
-    const int rsub = lane / LPR, Q = lane % LPR;
+    const int rsub = lane >> 2, Q = lane & 3;     // read-back: 4 lanes per 64-byte row, 16 rows per instruction
+
+    // Tap addresses.  A tile later the same lane's pixel sits 128 pixels further in the ring: the row address moves by 128 PXB bytes
+    // (mod ring) and the swizzle term (row >> 1) & SWM (and, for Cin = 32, which half of the row) does NOT change -- rows move by
+    // multiples of 16.  So per tile and tap: one add + and, and one select against the zero row for taps outside the image (the
+    // zero row is 128 bytes: any swizzle term stays inside it).
+    int rbase[MI][9], aswz[MI][9];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int pix = t0 * DC_TILE + (pg * MI + mi) * 32 + lr;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int byte = ((pix + dy * p.W + dx) & (DC_RING - 1)) * PXB;      // this pixel's bytes in the ring
+            const int lrow = byte >> 7;
+            rbase[mi][tap] = lrow << 7;
+            aswz[mi][tap] = (byte & 64) ^ (((lrow >> 1) & SWM) << 4);           // Cin = 32: odd pixels are chunks 4-7 of their row
+        }
+    }
 
     for (int t = t0; t < t1; ++t) {
+        int abase[MI][9];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int pix = t * DC_TILE + (pg * MI + mi) * 32 + lr;
+            const int pc = pix < p.M ? pix : p.M - 1;
+            const int rowi = (int)__umulhi((unsigned)pc, p.invW);
+            const int x = pc - rowi * p.W;
+            const int y = rowi - (int)__umulhi((unsigned)rowi, p.invH) * p.H;
+            const bool yok[3] = {y >= 1, true, y + 1 < p.H}, xok[3] = {x >= 1, true, x + 1 < p.W};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                abase[mi][tap] = (yok[tap / 3] && xok[tap % 3]) ? rbase[mi][tap] : ZOFF;
+                rbase[mi][tap] = (rbase[mi][tap] + DC_TILE * PXB) & (RING_BYTES - 1);
+            }
+        }
         // chunk t + 1 has landed: behind it in the queue are chunks t + 2 ... t + 5 and the stores of up to five tiles
         if (t - t0 < 5) dc_wait_vm<4 * DPW>();
         else dc_wait_vm<4 * DPW + 5 * NS>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();             // every wave is done with tile t - 1: chunk t - 2 is dead
+        if (!(DCDBG(p) & 8)) __builtin_amdgcn_s_barrier();             // every wave is done with tile t - 1: chunk t - 2 is dead
         issue(t + DC_NCH - 2);
 
-        const int pix = t * DC_TILE + wave * 32 + lr;
-        const int pc = pix < p.M ? pix : p.M - 1;
-        const int rowi = (int)__umulhi((unsigned)pc, p.invW);
-        const int x = pc - rowi * p.W;
-        const int y = rowi - (int)__umulhi((unsigned)rowi, p.invH) * p.H;
-        int abase[9], aswz[9];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const bool ok = (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
-            const int slot = (pc + dy * p.W + dx) & (DC_RING - 1);
-            const int lrow = CIN == 64 ? slot : slot >> 1;
-            const int chb = CIN == 64 ? 0 : (slot & 1) * 4;
-            abase[tap] = ok ? lrow * 128 : ZOFF;
-            aswz[tap] = ok ? ((chb ^ ((lrow >> 1) & SWM)) << 4) : 0;
-        }
         f32x16 acc[NACC];
 #pragma unroll
         for (int a = 0; a < NACC; ++a)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][e] = (a < NI) ? br[a < NI ? a : 0][e] : 0.0f;
+            for (int e = 0; e < 16; ++e) acc[a][e] = (a < MI) ? br[e] : 0.0f;
 
-        dc_static_for<9>([&](auto T) {
-            dc_static_for<KC>([&](auto K) {
-                const uint4 af = *reinterpret_cast<const uint4*>(smem + abase[T.value] + (aswz[T.value] ^ ((2 * K.value) << 4) ^ ck0));
-                dc_static_for<NI>([&](auto N) {
-                    constexpr int a = NI == 1 ? ((T.value * KC + K.value) & 1) : N.value;
-                    acc[a] = cfsar_mfma_32x32x16<__bf16>(wr[T.value][K.value][N.value], af, acc[a]);
-                });
-            });
+        // K loop: 9 taps x Cin/16 steps; the fragments of step s + 1 are read while the MFMAs of step s run
+        constexpr int PD = MI == 2 ? 3 : 6;       // steps of read-ahead: ~200 cycles of MFMA work cover the LDS latency
+        uint4 af[PD + 1][MI];
+        auto read_step = [&](auto S, uint4 (&dst)[MI]) __attribute__((always_inline)) {
+            constexpr int tap = S.value / KC, kc = S.value % KC;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                dst[mi] = *reinterpret_cast<const uint4*>(smem + abase[mi][tap] + (aswz[mi][tap] ^ ((2 * kc) << 4) ^ ck0));
+        };
+        dc_static_for<PD>([&](auto S) { read_step(S, af[S.value]); });
+        if (!(DCDBG(p) & 4))
+        dc_static_for<NSTEP>([&](auto S) {
+            constexpr int s = S.value;
+            if constexpr (s + PD < NSTEP) read_step(std::integral_constant<int, s + PD>{}, af[(s + PD) % (PD + 1)]);
+            __builtin_amdgcn_sched_barrier(0);    // keep the reads of step s + PD AHEAD of these MFMAs (the scheduler otherwise serialises
+#pragma unroll                                    // read -> wait -> MFMA with one fragment register)
+            for (int mi = 0; mi < MI; ++mi) {
+                const int a = MI == 1 ? (s & 1) : mi;
+                acc[a] = cfsar_mfma_32x32x16<__bf16>(wr[s], af[s % (PD + 1)][mi], acc[a]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (NI == 1) {
+        if constexpr (MI == 1) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[0][e] += acc[1][e];
         }
 
-        // epilogue: [ReLU] -> bf16 -> slab (8-byte slot (2 (4 ni + g) + hi) ^ (lr & (NSLOT - 1)) of row lr) -> 16-byte row-contiguous stores
+        // epilogue per 32-pixel tile: [ReLU] -> bf16 -> slab (8-byte slot (2 g + hi) ^ (lr & 7) of row lr) -> 16-byte stores, 4 lanes
+        // per pixel (its 64 bytes of this wave's 32 channels)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = acc[ni][4 * g + j];
+                    float v = acc[mi][4 * g + j];
                     if (p.relu) v = fmaxf(v, 0.0f);
                     o[j] = (__bf16)v;
                 }
-                const int sl = (2 * (4 * ni + g) + hi) ^ (lr & (NSLOT - 1));
-                *reinterpret_cast<bf16x4*>(slab + lr * (COUT * 2) + sl * 8) = o;
+                *reinterpret_cast<bf16x4*>(slab + lr * 64 + (((2 * g + hi) ^ (lr & 7)) << 3)) = o;
             }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private slab: in-order DS + this wait
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private slab: in-order DS + this wait
 #pragma unroll
-        for (int it = 0; it < NS; ++it) {
-            const int row = it * RPI + rsub;
-            const int f = row & (NSLOT - 1);
-            uint4 d = *reinterpret_cast<const uint4*>(slab + row * (COUT * 2) + ((Q ^ (f >> 1)) << 4));
-            if (f & 1) d = uint4{d.z, d.w, d.x, d.y};
-            const int opix = t * DC_TILE + wave * 32 + row;
-            if (opix < p.M) *reinterpret_cast<uint4*>(p.out + (size_t)opix * (COUT * 2) + Q * 16) = d;
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 16 + rsub;
+                const int f = row & 7;
+                uint4 d = *reinterpret_cast<const uint4*>(slab + row * 64 + ((Q ^ (f >> 1)) << 4));
+                if (f & 1) d = uint4{d.z, d.w, d.x, d.y};
+                const int opix = t * DC_TILE + (pg * MI + mi) * 32 + row;
+                uint4* dst = reinterpret_cast<uint4*>(p.out + (size_t)opix * (COUT * 2) + cg * 64 + Q * 16);
+                if (opix < p.M && !(DCDBG(p) & 1)) {
+                    if (DCDBG(p) & 16) {
+                        typedef unsigned dc_u32x4 __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(dc_u32x4{d.x, d.y, d.z, d.w}, reinterpret_cast<dc_u32x4*>(dst));
+                    }
+                    else *dst = d;
+                }
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no LDS-DMA may outlive the workgroup
@@ -520,16 +562,19 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(DirectConvArgs p) {
 
 template <int CIN, int COUT>
 int launch_direct_conv(const DirectConvArgs& a, hipStream_t s) {
-    constexpr int LDS = DC_RING * CIN * 2 + 128 + 4 * 32 * COUT * 2;
+    constexpr int LDS = DC_RING * CIN * 2 + 128 + 4 * 2048;
     if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&conv3x3_direct_kernel<CIN, COUT>), LDS, "cfsar_conv3x3_nhwc(direct)")) return rc;
-    const int cus = cfsar_num_cus();
-    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    const int wgs = cfsar_num_cus() * (CIN == 32 ? 2 : 1);        // Cin = 32: 72 KiB of LDS, <= 256 registers: two workgroups per CU
+    const int grid = a.ntiles < wgs ? a.ntiles : wgs;
     hipLaunchKernelGGL((conv3x3_direct_kernel<CIN, COUT>), dim3(grid), dim3(256), LDS, s, a);
     return cfsar_check_launch("cfsar_conv3x3_nhwc(direct)");
 }
 
 }  // namespace
 
+#ifdef CFSAR_DEV
+int g_direct_conv_dbg = 0;
+#endif
 // Called by cfsar_conv3x3_nhwc (gemm.hip) for the shapes this kernel covers; returns -2 when it does not apply.
 int cfsar_conv3x3_direct(const void* in, const void* W, void* out, const float* bias, int F, int H, int Wd, int C, int Cout, int ldw,
                          int ldo, int relu, hipStream_t s) {
@@ -547,6 +592,9 @@ int cfsar_conv3x3_direct(const void* in, const void* W, void* out, const float* 
     a.ldw = ldw;
     a.relu = relu;
     a.ntiles = (int)((M + DC_TILE - 1) / DC_TILE);
+#ifdef CFSAR_DEV
+    a.dbg = g_direct_conv_dbg;
+#endif
     if (C == 32 && Cout == 32) return launch_direct_conv<32, 32>(a, s);
     if (C == 32 && Cout == 64) return launch_direct_conv<32, 64>(a, s);
     return launch_direct_conv<64, 64>(a, s);

@@ -1532,7 +1532,8 @@ extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* 
 
 #ifdef CFSAR_DEV
 static int g_no_direct_conv = 0;        // dev A/B: cfsar_debug_set_direct_conv(0) routes the narrow convs through the implicit GEMM again
-extern "C" void cfsar_debug_set_direct_conv(int on) { g_no_direct_conv = !on; }
+extern int g_direct_conv_dbg;          // conv.hip
+extern "C" void cfsar_debug_set_direct_conv(int on) { g_no_direct_conv = !(on & 1); g_direct_conv_dbg = on >> 8; }
 #else
 constexpr int g_no_direct_conv = 0;
 #endif

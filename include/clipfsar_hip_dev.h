@@ -29,7 +29,8 @@ void cfsar_debug_set_vit_dbg(int dbg);
 void cfsar_debug_set_vit_trace(void* trace, int stagger_unit);
 /* workgroup shape of the bf16 attention kernel at 197 tokens (csrc/attention.hip); 0 = product */
 void cfsar_debug_set_attn_variant(int v);
-/* 0: cfsar_conv3x3_nhwc routes Cin, Cout in {32, 64} through the implicit GEMM again instead of the direct kernel (csrc/conv.hip) */
+/* bit 0 clear: cfsar_conv3x3_nhwc routes Cin, Cout in {32, 64} through the implicit GEMM again instead of the direct kernel
+ * (csrc/conv.hip); bits 8+: ablation bits of the direct kernel (1 no stores, 2 first tile's tap addresses, 4 no MFMAs, 8 no barrier) */
 void cfsar_debug_set_direct_conv(int on);
 
 #if defined(__GNUC__) || defined(__clang__)

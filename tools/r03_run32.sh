@@ -1,0 +1,2 @@
+timeout 900 python -m pytest tests/test_gpu_kernels.py -q -x -k "conv3x3" 2>&1 | tail -3
+timeout 600 python tools/rn_conv_ab.py 16 2>&1 | grep -v amdgpu

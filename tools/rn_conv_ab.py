@@ -32,4 +32,10 @@ for tag, C, Co, H in (("stem conv2", 32, 32, 112), ("stem conv3", 32, 64, 112), 
     gb = M * (C + Co) * 2 / 1e9
     fl = 2.0 * M * 9 * C * Co
     td, ti = min(res[1]), min(res[0])
+    abl = {}
+    for name, bits in (("no stores", 1), ("nt stores", 16), ("no MFMA", 4), ("no barrier", 8), ("no MFMA, no stores", 5), ("only DMA + barrier", 7)):
+        L.cfsar_debug_set_direct_conv(1 | (bits << 8))
+        abl[name] = bench(lambda: hip.conv3x3(x, w, out, Fn, H, H, C, bias=b, relu=True), rounds=3)
+    L.cfsar_debug_set_direct_conv(1)
+    print("   ablations (us): " + ", ".join("%s %.0f" % kv for kv in abl.items()))
     print("%-13s direct %7.1f us (%.2f TB/s, %4.0f TFLOP/s) | implicit GEMM %7.1f us | x%.2f" % (tag, td, gb / td * 1e3, fl / td / 1e6, ti, ti / td))
