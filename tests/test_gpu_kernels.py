@@ -352,6 +352,10 @@ def test_avgpool_and_attnpool_tokens(hip, dtype):
     oo = torch.empty(2, 3, 4, 8, device="cuda", dtype=td)
     hip.avgpool2x2(xo.cuda(), oo, 2, 7, 9, 8)
     assert maxdiff(oo.float().cpu(), xo.float()[:, :6, :8].reshape(2, 3, 2, 4, 2, 8).mean((2, 4))) < (1e-6 if dtype == "f32" else 1e-2)
+    xs = _rand(2, 6, 4, 12, seed=18).to(td)                 # C % 8 != 0: the scalar kernel
+    os_ = torch.empty(2, 3, 2, 12, device="cuda", dtype=td)
+    hip.avgpool2x2(xs.cuda(), os_, 2, 6, 4, 12)
+    assert maxdiff(os_.float().cpu(), xs.float().reshape(2, 3, 2, 2, 2, 12).mean((2, 4))) < (1e-6 if dtype == "f32" else 1e-2)
     # AttentionPool2d tokens (few_shot.py:446-448): [mean ; x] + pos
     HW = 49
     t = _rand(Fn, HW, C, seed=9).to(td)
