@@ -348,17 +348,25 @@ extern "C" int cfsar_stem_conv3x3_s2(const float* frames, const float* w, const 
 // conv2 of layer1, few_shot.py:549-554, 196-197), bf16 NHWC in, bf16 NHWC out, bias (+ ReLU) fused.
 //
 // The implicit-GEMM path (gemm.hip, p3 CONV NARROW) gathers every input pixel NINE times from L2 into the operand tile; with 64-128
-// bytes per pixel these convs are bound by that gather (1.1 ms per launch at 16 episodes against 0.2-0.6 ms of HBM time).  Here:
-//   * the NHWC tensor is ONE linear stream of pixels; a persistent workgroup (4 waves, one per SIMD) walks a contiguous range of
-//     128-pixel tiles and keeps a RING of 1 024 pixels of that stream in LDS, filled by LDS-DMA in 128-pixel chunks SIX chunks
-//     ahead: every pixel is fetched once per workgroup (plus the halo at the two ends of its range);
-//   * a tap is an LDS read at (pixel + dy W + dx) mod 1 024 -- the MFMA "B" fragment of 32 consecutive pixels x 8 channels is one
+// bytes per pixel these convs are bound by that gather (1.7 / 1.7 / 0.6 ms per launch at 16 episodes against 0.2-0.6 ms of HBM
+// time).  Here:
+//   * the NHWC tensor is ONE linear stream of pixels; a persistent workgroup (4 waves; two workgroups per CU) walks a contiguous
+//     range of tiles (128 pixels for Cin = 32, 64 for Cin = 64: 8 KiB of the stream) and keeps a RING of 8 tiles' worth of the
+//     stream in LDS (64 KiB), filled by LDS-DMA one chunk per tile, SIX chunks ahead: every pixel is fetched once per workgroup
+//     (plus the halo at the two ends of its range);
+//   * a tap is an LDS read at (pixel + dy W + dx) mod ring -- the MFMA "B" fragment of 32 consecutive pixels x 8 channels is one
 //     ds_read_b128 (128-byte rows, chunk ^ ((row >> 1) & 7); for Cin = 32 two pixels share a row and the mask is 3: both layouts
-//     are bank-conflict free for every tap offset), lanes whose tap falls outside the image read a zero row instead;
-//   * the WEIGHTS live in registers for the whole launch (9 taps x Cin/16 x Cout/32 fragments = 72 ... 288 VGPRs / AGPRs: one wave
-//     per SIMD owns 512 registers), so the inner loop is one ds_read_b128 per Cout/32 MFMAs and nothing else;
-//   * epilogue: bias is the accumulators' initial value; ReLU, bf16 pack, transpose through a 2-4 KiB wave-private slab, 16-byte
-//     stores of whole pixel rows (the wave's 32 pixels are 2-4 KiB of contiguous output).
+//     are bank-conflict free for every tap offset, checked by brute force over the ds_read_b128 lane groups), lanes whose tap falls
+//     outside the image read a 128-byte zero row instead.  The address of a tap advances by a constant per tile and its swizzle
+//     term never changes (rows move by multiples of 16): one add + and + select per tap and tile;
+//   * the WEIGHTS live in registers for the whole launch: a wave owns 32 output channels (9 taps x Cin/16 fragments = 72 / 144
+//     VGPRs) and 32 or 64 of the tile's pixels, so the inner loop is one ds_read_b128 per MFMA and nothing else; the fragments
+//     are read 3-6 steps ahead, pinned by scheduling barriers (left alone the compiler serialises read -> wait -> MFMA through
+//     one fragment register);
+//   * epilogue: bias is the accumulators' initial value; ReLU, bf16 pack, transpose through a 2 KiB wave-private slab, 16-byte
+//     stores (4 lanes per pixel: its 64 bytes of this wave's 32 channels).
+// Measured at 16 episodes (1 280 frames; tools/rn_conv_ab.py): stem conv2 1 701 -> 447 us (4.6 TB/s of in + out), stem conv3
+// 1 723 -> 774 us (4.0 TB/s), layer1 conv2 597 -> 315 us (940 TFLOP/s).
 // ============================================================================================================
 namespace {
 
@@ -404,22 +412,24 @@ struct DirectConvArgs {
 #define DCDBG(p) 0
 #endif
 
-constexpr int DC_TILE = 128;        // pixels per tile = per DMA chunk
-constexpr int DC_RING = 1024;       // pixels in the LDS ring = 8 chunks
-constexpr int DC_NCH = 8;
+// pixels per tile = per DMA chunk: 8 KiB of the stream either way (128 pixels of 64 bytes, 64 pixels of 128 bytes), so that the ring
+// is 64 KiB for both channel counts and two workgroups share a CU
+template <int CIN> struct DcGeom { static constexpr int TILE = CIN == 64 ? 64 : 128; };
+constexpr int DC_NCH = 8;           // chunks in the LDS ring
 
 template <int N> __device__ __forceinline__ void dc_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256, CIN == 32 ? 2 : 1) void conv3x3_direct_kernel(DirectConvArgs p) {
+__global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(DirectConvArgs p) {
+    constexpr int DC_TILE = DcGeom<CIN>::TILE, DC_RING = DC_NCH * DC_TILE;
     constexpr int PXB = CIN * 2;                  // bytes per pixel
-    constexpr int RPC = PXB;                      // 128-byte LDS rows per 128-pixel chunk
+    constexpr int RPC = DC_TILE * PXB / 128;      // 128-byte LDS rows per chunk (64)
     constexpr int DPW = RPC / 32;                 // LDS-DMA instructions per wave and chunk (1 KiB each)
     constexpr int RING_BYTES = DC_RING * PXB;
     constexpr int KC = CIN / 16;
     constexpr int WCO = COUT / 32;                // waves across the output channels (32 each)
     constexpr int WPX = 4 / WCO;                  // waves across the tile's pixels
-    constexpr int MI = 4 / WPX;                   // 32-pixel MFMA tiles per wave
+    constexpr int MI = DC_TILE / (32 * WPX);      // 32-pixel MFMA tiles per wave
     constexpr int NSTEP = 9 * KC;
     constexpr int SWM = CIN == 64 ? 7 : 3;
     constexpr int ZOFF = RING_BYTES;              // 128 bytes of zeros
@@ -525,7 +535,7 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 1) void conv3x3_direct_kernel(
             for (int e = 0; e < 16; ++e) acc[a][e] = (a < MI) ? br[e] : 0.0f;
 
         // K loop: 9 taps x Cin/16 steps; the fragments of step s + 1 are read while the MFMAs of step s run
-        constexpr int PD = MI == 2 ? 3 : 6;       // steps of read-ahead: ~200 cycles of MFMA work cover the LDS latency
+        constexpr int PD = MI == 2 ? 3 : (CIN == 64 ? 4 : 6);   // steps of read-ahead (~130-200 cycles of MFMA work; Cin = 64: 144 weight registers leave room for 4)
         uint4 af[PD + 1][MI];
         auto read_step = [&](auto S, uint4 (&dst)[MI]) __attribute__((always_inline)) {
             constexpr int tap = S.value / KC, kc = S.value % KC;
@@ -590,9 +600,9 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 1) void conv3x3_direct_kernel(
 
 template <int CIN, int COUT>
 int launch_direct_conv(const DirectConvArgs& a, hipStream_t s) {
-    constexpr int LDS = DC_RING * CIN * 2 + 128 + 4 * 2048;
+    constexpr int LDS = DC_NCH * DcGeom<CIN>::TILE * CIN * 2 + 128 + 4 * 2048;
     if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&conv3x3_direct_kernel<CIN, COUT>), LDS, "cfsar_conv3x3_nhwc(direct)")) return rc;
-    const int wgs = cfsar_num_cus() * (CIN == 32 ? 2 : 1);        // Cin = 32: 72 KiB of LDS, <= 256 registers: two workgroups per CU
+    const int wgs = cfsar_num_cus() * 2;        // 72 KiB of LDS, <= 256 registers: two workgroups per CU
     const int grid = a.ntiles < wgs ? a.ntiles : wgs;
     hipLaunchKernelGGL((conv3x3_direct_kernel<CIN, COUT>), dim3(grid), dim3(256), LDS, s, a);
     return cfsar_check_launch("cfsar_conv3x3_nhwc(direct)");
@@ -608,7 +618,8 @@ int cfsar_conv3x3_direct(const void* in, const void* W, void* out, const float* 
                          int ldo, int relu, hipStream_t s) {
     const long long M = (long long)F * H * Wd;
     if (!((C == 32 || C == 64) && (Cout == 32 || Cout == 64) && !(C == 64 && Cout == 32))) return -2;
-    if (ldo != Cout || Wd + 1 > DC_TILE || Wd < 2 || H < 2 || M >= (1ll << 25) || (M * C * 2) % 128 != 0 || M < DC_TILE) return -2;
+    const int tile = C == 64 ? DcGeom<64>::TILE : DcGeom<32>::TILE;
+    if (ldo != Cout || Wd + 1 > tile || Wd < 2 || H < 2 || M >= (1ll << 25) || (M * C * 2) % 128 != 0 || M < tile) return -2;
     DirectConvArgs a;
     a.in = static_cast<const char*>(in);
     a.w = static_cast<const char*>(W);
@@ -619,7 +630,7 @@ int cfsar_conv3x3_direct(const void* in, const void* W, void* out, const float* 
     a.invH = (unsigned)((1ull << 32) / (unsigned)H) + 1u;
     a.ldw = ldw;
     a.relu = relu;
-    a.ntiles = (int)((M + DC_TILE - 1) / DC_TILE);
+    a.ntiles = (int)((M + tile - 1) / tile);
 #ifdef CFSAR_DEV
     a.dbg = g_direct_conv_dbg;
 #endif

@@ -446,7 +446,7 @@ def test_conv3x3_implicit_gemm(hip, C, H, W_, Co, res):
 
 
 @pytest.mark.parametrize("C,Co,Fn,H,W_", [(32, 32, 24, 112, 112), (32, 64, 7, 112, 112), (64, 64, 90, 56, 56), (32, 64, 3, 9, 127),
-                                         (64, 64, 2, 33, 5), (32, 32, 2, 8, 8)])
+                                         (64, 64, 2, 33, 5), (32, 32, 2, 8, 8), (64, 64, 3, 6, 63)])
 def test_conv3x3_direct_kernel(hip, C, Co, Fn, H, W_):
     """The direct kernel behind cfsar_conv3x3_nhwc for Cin, Cout in {32, 64} (csrc/conv.hip: LDS pixel ring + weights in registers) ==
     relu(nn.Conv2d(3, padding=1) + bias) on bf16-rounded operands: many tiles per workgroup (the ring wraps several times), the
