@@ -15,7 +15,8 @@ struct VitGemmArgs {          // kernel argument block
     int M, N, K;
     int lda, ldw, ldo, ldr;
     int act;
-    int tiles_n, ntiles;      // 256 x 256 output tiles
+    int tiles_n, ntiles;      // 64 miw x 256 output tiles
+    int miw;                  // 4 = 256-row tiles, 3 = 192-row tiles (small M: fewer wasted rounds of the persistent grid)
     int group, colfast;       // tile walk inside an XCD's range (see tile_of)
     // head-blocked layouts (tokens per frame T >= 128; 0 = row-major).  hb_tokens / hb_heads: the LN-folded QKV instance writes
     // out[((f H + h) T + t) * 192 + 64 which + c] for row m = f T + t, column n = 64 (which H + h) + c (which = q / k / v), i.e. 75 KB

@@ -180,8 +180,8 @@ __device__ __forceinline__ void tile_of(int lin, int tiles_m, int tiles_n, int g
 // before the activation.  STATS (residual producer): per row, the sum and the sum of squares of the 64 STORED (rounded) values of
 // this wave are written to stats_out[row][slot = column / 64] -- the LayerNorm statistics of the next LN-folded GEMM come from
 // these partials (cfsar_ln_stats_finalize), so the residual stream is never re-read for them.
-template <typename TO, int ACT, bool HAS_RES, int STORE, bool FULL, bool ROWSCALE = false, bool PRE = false, bool HB = false>
-__device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemmArgs& p, int mb, int nb, int lane, char* slab,
+template <typename TO, int ACT, bool HAS_RES, int STORE, bool FULL, bool ROWSCALE = false, bool PRE = false, bool HB = false, int NMI = 4>
+__device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGemmArgs& p, int mb, int nb, int lane, char* slab,
                                               const float (&rscale)[4], const u32x4 (&rv0)[4]) {
     typedef typename Vec2B<TO>::v4 TO4;
     typedef typename Vec2B<TO>::v8 TO8;
@@ -326,13 +326,13 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
 #if CFSAR_EPI_PIPE
     u32x4 dprev[4], rvprev[4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < NMI; ++mi) {
         u32x4 rv[4];
         if constexpr (HAS_RES) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) rv[it] = rvn[it];
         }
-        if (mi < 3) load_res(mi + 1);
+        if (mi < NMI - 1) load_res(mi + 1);
         float gk = 0.f, gsd = 0.f;
         gelu_consts(mi, gk, gsd);
 #pragma unroll
@@ -350,16 +350,16 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
         }
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) finish(3, it, dprev[it], rvprev[it]);
+    for (int it = 0; it < 4; ++it) finish(NMI - 1, it, dprev[it], rvprev[it]);
 #else
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < NMI; ++mi) {
         u32x4 rv[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             if constexpr (HAS_RES) rv[it] = rvn[it];
         }
-        if (mi < 3) load_res(mi + 1);
+        if (mi < NMI - 1) load_res(mi + 1);
         float gk = 0.f, gsd = 0.f;
         gelu_consts(mi, gk, gsd);
 #pragma unroll
@@ -383,9 +383,16 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[4][2], const VitGemm
 //         start at d_n * std_m - mean_m c_n, produced by ONE extra MFMA per 32x32 tile (a rank-2 outer product, operands split
 //         into fp16 hi + lo parts: ~22 bits), and the epilogue multiplies the row by 1 / std_m.
 // SHORTK: K = 128 (two K tiles; the LDS-DMA path only): the first step is also the second-to-last one.
-template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE, bool SHORTK = false>
+// MIW: 32-row MFMA tiles per wave = output tile of 64 MIW rows: 4 (256 x 256, the batch-scale form) or 3 (192 x 256: at one or two episodes
+// per call a GEMM is 2.2 rounds of 256-row tiles on 256 CUs that cost 3; 192-row tiles make it 2.9 rounds of 0.75: -25 %)
+template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE, bool SHORTK = false, int MIW = 4>
 __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     static_assert(!SHORTK || OPATH == 1, "K = 128 runs on the LDS-DMA path");
+    static_assert(MIW == 4 || (MIW == 3 && !SHORTK), "tile height 256 or 192");
+    constexpr int TMv = 64 * MIW;                 // output tile rows
+    constexpr int WR = 32 * MIW;                  // rows of one wave
+    constexpr int NM = 2 * MIW;                   // MFMAs per sub-step
+    constexpr int NL = MIW + 2;                   // fragment loads per sub-step
     constexpr bool HAS_RES = MODE == 1;
     constexpr bool LNFOLD = MODE == 2 || MODE == 4;       // 4 = LN-folded with head-blocked output (the QKV GEMM)
     constexpr bool HB = MODE == 4;
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
         int tm, tn;
         tile_of(lin, tiles_m, p.tiles_n, p.group, p.colfast, tm, tn);
-        m0 = tm * TM;
+        m0 = tm * TMv;
         n0 = tn * TN;
 #ifdef CFSAR_DEV
         if (p.dbg & 8) { m0 = 0; n0 = 0; }     // ablation: every workgroup reads tile (0, 0) (cache-hot operands)
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     // per-lane source offsets of the 4 + 4 staging pieces (8 rows x 128 B each; wave w owns pieces {w, w+8, w+16, w+24})
     auto offsets = [&](int m0, int n0, unsigned (&ox)[4], unsigned (&ow)[4]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {                       // X: pieces 0 .. MIW - 1 are used
             const int row = (i * 8 + wave) * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ swz(row);
             int gm = m0 + row;
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     int rdX[4], rdW[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int rx = wm * 128 + i * 32 + lr;
+        const int rx = wm * WR + i * 32 + lr;                                  // i >= MIW: unused
         rdX[i] = rx * ROWB + ((hi ^ swz(rx)) << 4);                        // sub-step ss: ^ (ss << 5)
     }
 #pragma unroll
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     if (b >= nt) return;
     int m0 = 0, n0 = 0;                    // origin of the current output tile
     const unsigned akstride = p.ha_tokens > 0 ? (unsigned)p.ha_tokens * 128u : (unsigned)ROWB;     // bytes between K tiles of A
-    f32x16 acc[4][2];
+    f32x16 acc[MIW][2];
     // Bias / LayerNorm terms are added by ONE extra MFMA per 32x32 tile AFTER the last K step (a rank-1 / rank-2 outer product, see
     // tail_fold below); the accumulators start at zero (the first sub-step's MFMAs take the inline constant 0 as C).  What a lane
     // needs for it is tiny -- the bias (or c / d) of ITS two columns 32 ni + lr and, LN-folded, (mean | std) and 1 / std of ITS four
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     // epilogue's stores any more (in-order memory returns: a load behind 16 stores waits for all of them; round 2 loaded 8 x 16 B of
     // bias or 4 x 16 B of statistics per lane there and initialised 128 accumulators from them).
     constexpr int NTL = LNFOLD ? 10 : 2;
-    float tl[NTL];                       // [0..1] bias | c (hi == 0) / d (hi == 1) of column 32 ni + lr; LNFOLD: [2..5] mean | std, [6..9] 1 / std
+    float tl[NTL] = {};                  // [0..1] bias | c (hi == 0) / d (hi == 1) of column 32 ni + lr; LNFOLD: [2..5] mean | std, [6..9] 1 / std
     float rscale[4] = {1.f, 1.f, 1.f, 1.f};
     auto asm_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
         float v;
@@ -473,8 +480,8 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         for (int ni = 0; ni < 2; ++ni) tl[ni] = asm_load(cd + nb_ + ni * 32 + lr);
         if constexpr (LNFOLD) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                int m = m0_ + wm * 128 + mi * 32 + lr;
+            for (int mi = 0; mi < MIW; ++mi) {
+                int m = m0_ + wm * WR + mi * 32 + lr;
                 m = m < p.M ? m : p.M - 1;
                 tl[2 + mi] = asm_load(p.rowstats + (size_t)m * 4 + hi);
                 tl[6 + mi] = asm_load(p.rowstats + (size_t)m * 4 + 2);
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             const TI one = (TI)(hi ? 0.f : 1.f);
             const TI8 ones = TI8{one, one, one, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     if constexpr (std::is_same<TI, _Float16>::value) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[ni], ones, acc[mi][ni], 0, 0, 0);
@@ -522,14 +529,14 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                 cw[ni] = f16x8{h, h, l, 0, 0, 0, 0, 0};
             }
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
+            for (int mi = 0; mi < MIW; ++mi) {
                 const float nm = hi ? tl[2 + mi] : -tl[2 + mi];
                 const _Float16 h = (_Float16)nm, l = (_Float16)(nm - (float)h);
                 mx[mi] = f16x8{h, l, h, 0, 0, 0, 0, 0};
                 rscale[mi] = tl[6 + mi];
             }
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cw[ni], mx[mi], acc[mi][ni], 0, 0, 0);
@@ -573,14 +580,14 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         constexpr int j = decltype(J)::value;
         const char* base = smem + stage * STAGE;
         const int x2 = ss << 5;
-        constexpr int isx[6] = {1, 0, 1, 1, 1, 0};
-        constexpr int idx[6] = {0, 0, 1, 2, 3, 1};
+        constexpr int isx[6] = {1, 0, 1, 1, MIW == 4 ? 1 : 0, 0};       // MIW = 3: x0 w0 x1 x2 w1
+        constexpr int idx[6] = {0, 0, 1, 2, MIW == 4 ? 3 : 1, 1};
         if constexpr (isx[j] != 0) xf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdX[idx[j]] ^ x2));
         else wf[idx[j]] = *reinterpret_cast<const uint4*>(base + (rdW[idx[j]] ^ x2));
     };
     auto mfma_one = [&](auto J, uint4 (&xf)[4], uint4 (&wf)[2], auto ZERO) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
-        constexpr int ni = j >> 2, mi = j & 3;
+        constexpr int ni = j / MIW, mi = j % MIW;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const f32x16 c = decltype(ZERO)::value ? zero : acc[mi][ni];          // first sub-step of an output tile: C = 0 (inline constant)
         if constexpr (std::is_same<TI, _Float16>::value)
@@ -598,34 +605,35 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     auto step = [&](int cur, int nxt, const unsigned (&ox)[4], const unsigned (&ow)[4], int ksrc, auto LOAD, auto WRITE, auto SYNC, auto FRAGS, auto ZERO, auto TAIL) __attribute__((always_inline)) {
         constexpr bool load = decltype(LOAD)::value, write = decltype(WRITE)::value, sync = decltype(SYNC)::value,
                        frags = decltype(FRAGS)::value, tail = decltype(TAIL)::value;
-        static_for<8>([&](auto J) {                                     // sub-step 0
+        static_for<NM>([&](auto J) {                                    // sub-step 0
             constexpr int j = decltype(J)::value;
             mfma_one(J, xfA, wfA, ZERO);
-            if constexpr (j < 6) load_one(cur, 1, J, xfB, wfB);
-            if constexpr (j >= 4) {
-                if constexpr (OPATH == 0) { if constexpr (write) swriteX(nxt, std::integral_constant<int, j - 4>{}); }
-                else if constexpr (OPATH == 1) { if constexpr (load) dmaX(ox, ksrc, nxt, std::integral_constant<int, j - 4>{}); }
+            if constexpr (j < NL) load_one(cur, 1, J, xfB, wfB);
+            if constexpr (j >= NM - MIW) {                              // the MIW pieces of X
+                if constexpr (OPATH == 0) { if constexpr (write) swriteX(nxt, std::integral_constant<int, j - (NM - MIW)>{}); }
+                else if constexpr (OPATH == 1) { if constexpr (load) dmaX(ox, ksrc, nxt, std::integral_constant<int, j - (NM - MIW)>{}); }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        static_for<8>([&](auto J) {                                     // sub-step 1
+        static_for<NM>([&](auto J) {                                    // sub-step 1
             constexpr int j = decltype(J)::value;
             mfma_one(J, xfB, wfB, F_{});
-            if constexpr (j < 6) load_one(cur, 2, J, xfA, wfA);
-            if constexpr (j >= 4) {
-                if constexpr (OPATH == 0) { if constexpr (load) gloadX(ox, ksrc, std::integral_constant<int, j - 4>{}); }
-                else if constexpr (OPATH == 1) { if constexpr (load) dmaW(ow, ksrc, nxt, std::integral_constant<int, j - 4>{}); }
+            if constexpr (j < NL) load_one(cur, 2, J, xfA, wfA);
+            if constexpr (OPATH == 0) {
+                if constexpr (j >= NM - MIW && load) gloadX(ox, ksrc, std::integral_constant<int, j - (NM - MIW)>{});
+            } else if constexpr (OPATH == 1) {
+                if constexpr (j >= NM - 4 && load) dmaW(ow, ksrc, nxt, std::integral_constant<int, j - (NM - 4)>{});
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        static_for<8>([&](auto J) {                                     // sub-step 2
+        static_for<NM>([&](auto J) {                                    // sub-step 2
             constexpr int j = decltype(J)::value;
             mfma_one(J, xfA, wfA, F_{});
-            if constexpr (j < 6) load_one(cur, 3, J, xfB, wfB);
-            if constexpr (j >= 4 && OPATH == 0 && write) swriteW(nxt, std::integral_constant<int, j - 4>{});
+            if constexpr (j < NL) load_one(cur, 3, J, xfB, wfB);
+            if constexpr (j >= NM - 4 && OPATH == 0 && write) swriteW(nxt, std::integral_constant<int, j - (NM - 4)>{});
             __builtin_amdgcn_sched_barrier(0);
         });
-        static_for<8>([&](auto J) {                                     // sub-step 3
+        static_for<NM>([&](auto J) {                                    // sub-step 3
             constexpr int j = decltype(J)::value;
             mfma_one(J, xfB, wfB, F_{});
             if constexpr (j < 2) {
@@ -633,17 +641,26 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                     gloadW(ow, ksrc, std::integral_constant<int, 2 * j>{});
                     gloadW(ow, ksrc, std::integral_constant<int, 2 * j + 1>{});
                 }
-            } else if constexpr (frags) load_one(nxt, 0, std::integral_constant<int, j - 2>{}, xfA, wfA);
+            } else if constexpr (frags) {
+                load_one(nxt, 0, std::integral_constant<int, j - 2>{}, xfA, wfA);
+                if constexpr (j == NM - 1 && NL > NM - 2) load_one(nxt, 0, std::integral_constant<int, NL - 1>{}, xfA, wfA);   // MIW = 3: 5 loads, 4 slots
+            }
             // OPATH 2: every wave has issued its last fragment reads of stage `cur` before the barrier of this sub-step -> the
             // stage is free: K tile `ksrc` (two ahead) starts its flight NOW and has a whole K step to land (OPATH 1 issues the
             // same pieces 1.5 - 2.5 sub-steps later, into the other stage)
             if constexpr (tail && j == 2) tail_loads(m0, n0);          // this tile's bias / statistics: covered by the NEXT step's wait
-            if constexpr (OPATH == 2 && load && j >= 2) {
+            if constexpr (OPATH == 2 && load && j >= 2 && MIW == 4) {
                 if constexpr (j < 6) dmaX(ox, ksrc, cur, std::integral_constant<int, j - 2>{});
                 else {
                     dmaW(ow, ksrc, cur, std::integral_constant<int, 2 * (j - 6)>{});
                     dmaW(ow, ksrc, cur, std::integral_constant<int, 2 * (j - 6) + 1>{});
                 }
+            }
+            if constexpr (OPATH == 2 && load && j >= 2 && MIW == 3) {   // 3 + 4 pieces over the slots j = 2 .. 5: X0 X1 | X2 W0 | W1 W2 | W3
+                if constexpr (j == 2) { dmaX(ox, ksrc, cur, std::integral_constant<int, 0>{}); dmaX(ox, ksrc, cur, std::integral_constant<int, 1>{}); }
+                if constexpr (j == 3) { dmaX(ox, ksrc, cur, std::integral_constant<int, 2>{}); dmaW(ow, ksrc, cur, std::integral_constant<int, 0>{}); }
+                if constexpr (j == 4) { dmaW(ow, ksrc, cur, std::integral_constant<int, 1>{}); dmaW(ow, ksrc, cur, std::integral_constant<int, 2>{}); }
+                if constexpr (j == 5) { dmaW(ow, ksrc, cur, std::integral_constant<int, 3>{}); }
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (j == 1 && sync) {
@@ -658,19 +675,19 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     offsets(m0, n0, offX, offW);
     // ---- pipeline fill for the first output tile of this workgroup
     if constexpr (OPATH == 0) {
-        static_for<4>([&](auto J) { gloadX(offX, 0, J); });
+        static_for<MIW>([&](auto J) { gloadX(offX, 0, J); });
         static_for<4>([&](auto J) { gloadW(offW, 0, J); });
-        static_for<4>([&](auto J) { swriteX(0, J); });
+        static_for<MIW>([&](auto J) { swriteX(0, J); });
         static_for<4>([&](auto J) { swriteW(0, J); });
-        static_for<4>([&](auto J) { gloadX(offX, 1, J); });
+        static_for<MIW>([&](auto J) { gloadX(offX, 1, J); });
         static_for<4>([&](auto J) { gloadW(offW, 1, J); });
     } else {
-        static_for<4>([&](auto J) { dmaX(offX, 0, 0, J); });
+        static_for<MIW>([&](auto J) { dmaX(offX, 0, 0, J); });
         static_for<4>([&](auto J) { dmaW(offW, 0, 0, J); });
         if constexpr (OPATH == 2) {                       // K tile 1 is in flight before the first step as well
-            static_for<4>([&](auto J) { dmaX(offX, 1, 1, J); });
+            static_for<MIW>([&](auto J) { dmaX(offX, 1, 1, J); });
             static_for<4>([&](auto J) { dmaW(offW, 1, 1, J); });
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(MIW + 4) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -702,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         const bool has_next = bn < nt;
         int m0n = m0, n0n = n0;
         if (has_next) origin(bn, m0n, n0n);
-        static_for<6>([&](auto J) { load_one(sb, 0, J, xfA, wfA); });
+        static_for<NL>([&](auto J) { load_one(sb, 0, J, xfA, wfA); });
         CFSAR_TRACE(0);
         int kt = 0;
         // The tail steps ALWAYS prefetch (one straight-line MFMA stream: a fork on has_next would merge two 128-register
@@ -712,7 +729,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         // (LDS-DMA instance only: in the register-staged one 16 more live registers across the last K step cost 22-30 spills and 10 %)
         auto residual_prefetch = [&]() __attribute__((always_inline)) {     // rows rr + 8 it of the wave's first 32-row pass
             if constexpr (HAS_RES && (OPATH >= kPreMinOpath && OPATH <= kPreMaxOpath)) {
-                const int mb_ = m0 + wm * 128, nb_ = n0 + wn * 64;
+                const int mb_ = m0 + wm * WR, nb_ = n0 + wn * 64;
                 const int ncl_ = nb_ + 64 <= p.N ? nb_ : p.N - 64;
                 const int rr_ = lane >> 3, Q_ = lane & 7;
 #pragma unroll
@@ -732,7 +749,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, T_{}, T_{}, T_{}, F_{}, T_{});      // loads K tile 0 of the next tile
             ++kt;
             step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 1, T_{}, T_{}, T_{}, F_{}, F_{}, F_{});      // writes it, loads K tile 1
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // the tail operands (older than the 8 loads of K tile 1) have landed
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(MIW + 4) : "memory");     // the tail operands (older than the loads of K tile 1) have landed
         } else if constexpr (OPATH == 1 && SHORTK) {
             step(sb & 1, (sb + 1) & 1, offX, offW, 1, T_{}, F_{}, T_{}, T_{}, T_{}, T_{});
             kt = 1;
@@ -762,13 +779,13 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         CFSAR_TRACE(1);
 #ifdef CFSAR_DEV
         if (p.dbg & 4) {                                                // ablation: no epilogue (keep the accumulators live)
-            if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[3][1][2] + acc[2][0][1];
+            if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[1][1][3] + acc[MIW - 1][1][2] + acc[2][0][1];
         } else
 #endif
         {
-            const int mb = m0 + wm * 128, nb = n0 + wn * 64;
-            if (mb + 128 <= p.M && nb + 64 <= p.N) epilogue_rows<TO, ACT, HAS_RES, STORE, true, LNFOLD, HAS_RES && (OPATH >= kPreMinOpath && OPATH <= kPreMaxOpath), HB>(acc, p, mb, nb, lane, slab, rscale, rv0);
-            else epilogue_rows<TO, ACT, HAS_RES, STORE, false, LNFOLD, HAS_RES && (OPATH >= kPreMinOpath && OPATH <= kPreMaxOpath), HB>(acc, p, mb, nb, lane, slab, rscale, rv0);
+            const int mb = m0 + wm * WR, nb = n0 + wn * 64;
+            if (mb + WR <= p.M && nb + 64 <= p.N) epilogue_rows<TO, ACT, HAS_RES, STORE, true, LNFOLD, HAS_RES && (OPATH >= kPreMinOpath && OPATH <= kPreMaxOpath), HB, MIW>(acc, p, mb, nb, lane, slab, rscale, rv0);
+            else epilogue_rows<TO, ACT, HAS_RES, STORE, false, LNFOLD, HAS_RES && (OPATH >= kPreMinOpath && OPATH <= kPreMaxOpath), HB, MIW>(acc, p, mb, nb, lane, slab, rscale, rv0);
         }
         CFSAR_TRACE(2);
 #ifdef CFSAR_DEV
@@ -790,9 +807,15 @@ int persistent_grid() {
     return n >= 8 ? n : 8;
 }
 
-template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE, bool SHORTK>
+// the 192-row form exists for the product policy's instances only (compile time): LN-folded on the early-DMA path with write-through
+// stores, residual on the early-DMA and the register-staged path with plain stores
+constexpr bool vit_has_192(int mode, int opath, int store) {
+    return (mode == 1 && store == 0 && (opath == 0 || opath == 2)) || ((mode == 2 || mode == 4) && opath == 2 && store == 2);
+}
+
+template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE, bool SHORTK, int MIW = 4>
 int launch_inst2(const VitGemmArgs& a, hipStream_t s) {
-    auto* fn = &vit_gemm_kernel<TI, TO, ACT, MODE, OPATH, STORE, SHORTK>;
+    auto* fn = &vit_gemm_kernel<TI, TO, ACT, MODE, OPATH, STORE, SHORTK, MIW>;
     if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(fn), LDS_BYTES, "cfsar_gemm(vit)")) return rc;
     const int grid = a.ntiles < persistent_grid() ? ((a.ntiles + 7) & ~7) : persistent_grid();
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), LDS_BYTES, s, a);
@@ -802,6 +825,9 @@ int launch_inst2(const VitGemmArgs& a, hipStream_t s) {
 template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE>
 int launch_inst(const VitGemmArgs& a, hipStream_t s) {
     if (a.K == 128) return launch_inst2<TI, TO, ACT, MODE, 1, STORE, true>(a, s);       // two K tiles: its own instance
+    if constexpr (vit_has_192(MODE, OPATH, STORE)) {
+        if (a.miw == 3) return launch_inst2<TI, TO, ACT, MODE, OPATH, STORE, false, 3>(a, s);
+    }
     return launch_inst2<TI, TO, ACT, MODE, OPATH, STORE, false>(a, s);
 }
 
@@ -864,7 +890,23 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     a.lda = c.lda; a.ldw = c.ldw; a.ldo = c.ldo; a.ldr = c.ldr;
     a.act = c.act;
     a.tiles_n = (c.N + TN - 1) / TN;
-    a.ntiles = ((c.M + TM - 1) / TM) * a.tiles_n;
+    // Tile height: 192 rows when that saves a tenth of the rounds-x-rows the persistent grid walks (one or two episodes per call:
+    // 62 bands x 9 columns of 256-row tiles are 2.2 rounds on 256 CUs and cost 3; 83 x 9 of 192 rows cost 3 x 0.75)
+    a.miw = 4;
+    {
+        const int mode_ = lnfold ? 2 : (f16res ? 1 : 0);
+        if (c.K != 128 && vit_has_192(mode_, c.opath, c.store)) {
+            const long long G = persistent_grid();
+            const long long t256 = (long long)((c.M + 255) / 256) * a.tiles_n, t192 = (long long)((c.M + 191) / 192) * a.tiles_n;
+            const long long r256 = ((t256 + G - 1) / G) * 256, r192 = ((t192 + G - 1) / G) * 192;
+            if (r192 * 10 <= r256 * 9) a.miw = 3;
+#ifdef CFSAR_DEV
+            if (c.dbg & (1 << 17)) a.miw = 3;          // forced (tests / A/B)
+            if (c.dbg & (1 << 18)) a.miw = 4;
+#endif
+        }
+    }
+    a.ntiles = ((c.M + 64 * a.miw - 1) / (64 * a.miw)) * a.tiles_n;
     a.group = c.group > 0 ? c.group : 8;
     a.colfast = c.colfast;
     a.hb_tokens = c.hb_tokens; a.hb_heads = c.hb_heads; a.ha_tokens = c.ha_tokens;
@@ -983,6 +1025,9 @@ static int gemm_residual_stats_impl(const void* A, const void* W, void* x, const
     c.out_dtype = CFSAR_F16; c.in_dtype = in_dtype; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
     c.opath = vit_policy_opath(K); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;
     c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = ha_tokens;
+#ifdef CFSAR_DEV
+    c.dbg = g_force_dbg & ((1 << 17) | (1 << 18));       // tile-height overrides only
+#endif
     const int rc = cfsar_gemm_vit_try(c, static_cast<hipStream_t>(stream));
     return rc == -2 ? cfsar_fail("cfsar_gemm_residual_stats: operands too large for 32-bit offsets") : rc;
 }

@@ -531,10 +531,12 @@ class ClipFsarEngine:
         # hidden [F * tokens, 4 D] in 2 bytes (ViT-B/16: 3 548 frames fit; the engine keeps one frame of margin: 3 547); larger episode batches run the tower in chunks
         limit = getattr(self.vit, "max_frames_32bit", None)
         self.max_frames = min(max_frames, limit) if limit else max_frames
-        # Small batches (one or two episodes): the support and the query frames go through the tower as two concurrent forwards
-        # on two HIP streams.  A single 80-frame GEMM is 2.2 rounds of 256x256 tiles on 256 CUs (a third round that is 18 %
-        # full); with two independent kernel chains the tail of one chain's kernel is filled by the other chain's next kernel.
+        # Two episodes per call (81-160 frames): the support and the query frames go through the tower as two concurrent forwards on
+        # two HIP streams -- with two independent kernel chains the tail of one chain's kernel is filled by the other chain's next
+        # kernel (311 vs 304 episodes/s).  One episode (80 frames) runs as ONE chain since the ViT GEMM has its 192-row tile form
+        # (csrc/gemm_vit.hip, MIW = 3: 2.9 rounds of 192-row tiles instead of 2.2 rounds of 256-row ones that cost 3): 272 vs 269.
         self.dual_frames = 160 if os.environ.get("CFSAR_DUAL_STREAM", "1") != "0" else 0
+        self.dual_min_frames = int(os.environ.get("CFSAR_DUAL_MIN_FRAMES", "81"))
         self._side = None
 
     def forward(self, support_set, target_set, support_labels, real_support_labels, way, T, merge_before=False,
@@ -551,7 +553,7 @@ class ClipFsarEngine:
         feats = torch.empty(B, S + Q, T, E, device=self.dev, dtype=torch.float32)
         chunk = max(1, self.max_frames // per_ep)
         feats2d = feats.reshape(B * per_ep, E)
-        dual = (taps is None and B * per_ep <= self.dual_frames and B <= chunk and self.dev.type == "cuda" and
+        dual = (taps is None and self.dual_min_frames <= B * per_ep <= self.dual_frames and B <= chunk and self.dev.type == "cuda" and
                 not isinstance(self.vit, HipResNet))
         if dual:
             if self._side is None:

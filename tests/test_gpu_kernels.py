@@ -547,7 +547,7 @@ def test_fp16_residual_stream_ops(hip):
 
 # ------------------------------------------------------------------------------------------------ LayerNorm folded into the GEMMs
 @pytest.mark.parametrize("M,N,K,act", [(777, 384, 128, "none"), (900, 320, 192, "none"), (5000, 2304, 768, "none"), (44000, 3072, 768, "gelu"),
-                                       (300, 512, 1024, "gelu"), (20500, 768, 256, "none")])
+                                       (300, 512, 1024, "gelu"), (20500, 768, 256, "none"), (15760, 2304, 768, "none"), (31520, 3072, 768, "gelu")])
 def test_gemm_lnfold_matches_layernorm_then_gemm(hip, M, N, K, act):
     _check_lnfold(hip, M, N, K, act)
 
@@ -589,17 +589,18 @@ def _check_lnfold(hip, M, N, K, act, od=torch.bfloat16):
     assert maxdiff(out.float(), ref2) < (6e-3 if od == torch.bfloat16 else 1.5e-3) * scale, (M, N, K, act)    # output rounding (2^-9 / 2^-12) dominates
 
 
-@pytest.mark.parametrize("M,N,K", [(777, 128, 128), (1300, 192, 192), (5000, 768, 768), (44000, 768, 3072), (20500, 1024, 256)])
+@pytest.mark.parametrize("M,N,K", [(777, 128, 128), (1300, 192, 192), (5000, 768, 768), (44000, 768, 3072), (20500, 1024, 256),
+                                   (15760, 768, 3072), (15760, 768, 768), (70000, 768, 768)])    # 15 760 rows (one episode): 192-row tiles, several per workgroup
 def test_gemm_residual_stats_and_finalize(hip, M, N, K):
     _check_residual_stats(hip, M, N, K)
 
 
-@pytest.mark.parametrize("M,N,K", [(777, 128, 128), (5000, 768, 768), (30000, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(777, 128, 128), (5000, 768, 768), (30000, 768, 3072), (15760, 768, 3072)])
 def test_gemm_residual_stats_fp16_operands(hip, M, N, K):
     _check_residual_stats(hip, M, N, K, td=torch.float16)
 
 
-@pytest.mark.parametrize("M,N,K,act", [(777, 384, 128, "none"), (5000, 2304, 768, "none"), (30000, 3072, 768, "gelu")])
+@pytest.mark.parametrize("M,N,K,act", [(777, 384, 128, "none"), (5000, 2304, 768, "none"), (30000, 3072, 768, "gelu"), (15760, 2304, 768, "none")])
 def test_gemm_lnfold_fp16_output(hip, M, N, K, act):
     _check_lnfold(hip, M, N, K, act, od=torch.float16)
 
