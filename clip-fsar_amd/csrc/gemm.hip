@@ -1465,6 +1465,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
         VitGemmCall c;
         c.A = A; c.W = W; c.out = out; c.bias = bias; c.res = residual;
         c.rowstats = nullptr; c.cvec = nullptr; c.stats_out = nullptr;
+        c.part = nullptr; c.part_slots = 0; c.part_eps = 0.f;
         c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = ldr;
         c.in_dtype = in_dtype; c.out_dtype = out_dtype; c.res_dtype = res_dtype; c.act = act; c.relu = relu;
         c.opath = cfsar_vit_policy_opath(K);

@@ -10,6 +10,11 @@ struct VitGemmArgs {          // kernel argument block
     const void* res;          // fp16 residual [M, ldr] or NULL
     const float* rowstats;    // LN-folded mode: [M, 4] = (mean, std, 1 / std, -) per row of A, else NULL
     const float* cvec;        // LN-folded mode: c_n = sum_k W'_nk, [N]
+    // LN-folded mode, optional: the statistics come straight from the producer GEMM's partials [M, part_slots, 2] (sum, sum of squares per
+    // 64 columns) and are finalized inside this kernel (no cfsar_ln_stats_finalize launch); rowstats is NULL then.  part_slots in {12, 16}.
+    const float* part;
+    int part_slots;
+    float part_invD, part_eps;
     float* stats_out;         // residual mode, optional: [M, stats_slots, 2] partial (sum, sum of squares) of the stored rows
     int stats_slots;          // N / 64
     int M, N, K;
@@ -40,6 +45,9 @@ struct VitGemmCall {          // host-side request
     const float* rowstats;
     const float* cvec;
     float* stats_out;
+    const float* part;        // see VitGemmArgs (NULL: rowstats)
+    int part_slots;
+    float part_eps;
     int M, N, K, lda, ldw, ldo, ldr;
     int in_dtype, out_dtype, res_dtype, act, relu;      // in_dtype: A / W (bf16, or fp16 in the fp16 numerics mode and LN-folded)
     int opath, store;         // operand path (0 register-staged, 1 LDS-DMA), store policy (0 default, 1 nt, 2 sc1; dev builds)

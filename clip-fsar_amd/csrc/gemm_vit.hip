@@ -464,6 +464,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     // rows 32 mi + lr -- and is fetched by compiler-invisible loads during the second-to-last K step: nothing is loaded after the
     // epilogue's stores any more (in-order memory returns: a load behind 16 stores waits for all of them; round 2 loaded 8 x 16 B of
     // bias or 4 x 16 B of statistics per lane there and initialised 128 accumulators from them).
+    constexpr bool kFuseStatsDecl = LNFOLD && OPATH == 2 && MIW == 3;     // see kFuseStats below
     constexpr int NTL = LNFOLD ? 10 : 2;
     float tl[NTL] = {};                  // [0..1] bias | c (hi == 0) / d (hi == 1) of column 32 ni + lr; LNFOLD: [2..5] mean | std, [6..9] 1 / std
     float rscale[4] = {1.f, 1.f, 1.f, 1.f};
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) tl[ni] = asm_load(cd + nb_ + ni * 32 + lr);
         if constexpr (LNFOLD) {
+            if (!(kFuseStatsDecl && p.part != nullptr))
 #pragma unroll
             for (int mi = 0; mi < MIW; ++mi) {
                 int m = m0_ + wm * WR + mi * 32 + lr;
@@ -542,6 +544,61 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cw[ni], mx[mi], acc[mi][ni], 0, 0, 0);
         }
     };
+    // ---- statistics finalized in here (p.part != NULL; LN-folded early-DMA instances, K >= 512): during K step mi the lane fetches its half
+    // (hi) of row 32 mi + lr's partials -- part_slots / 4 loads of 16 bytes, compiler-invisible like tail_loads, covered by the next
+    // step's vmcnt(0) -- and during step mi + 1 sums them, adds the partner lane's half and leaves (mean | std, 1 / std) in tl[] exactly as
+    // tail_loads would have loaded them from cfsar_ln_stats_finalize's output.
+    // 192-row instances only: in the 256-row ones the 8 + 16 extra live registers cost 75-98 spills (and the finalize launch is 0.4 % of a
+    // 16-episode step; it is 8 % of a one-episode step, which is where the 192-row tiles run)
+    constexpr bool kFuseStats = LNFOLD && OPATH == 2 && MIW == 3;
+    const bool fuse_stats = kFuseStats && p.part != nullptr;                  // kernel-uniform
+    // Arithmetic = cfsar_ln_stats_finalize's, bit for bit (ln_stats_finalize8_kernel: pair sums s_q = slot 2q + slot 2q + 1, then
+    // ((s0 + s1) + (s2 + s3)) + ((s6 + s7) + (s4 + s5))): the lanes with hi == 0 take slots 0-7, those with hi == 1 slots 8-15 (8-11 and
+    // zeros for 12 slots) -- an episode's logits do not depend on which instance served it (tests: batch-size invariance).
+    u32x4 sp[4] = {};
+    auto stat_loads = [&](auto MI_) __attribute__((always_inline)) {
+        constexpr int mi = decltype(MI_)::value;
+        int m = m0 + wm * WR + mi * 32 + lr;
+        m = m < p.M ? m : p.M - 1;
+        const char* src = reinterpret_cast<const char*>(p.part) + ((size_t)m * p.part_slots + (hi ? 8 : 0)) * 8;
+        sp[2] = u32x4{0u, 0u, 0u, 0u};
+        sp[3] = u32x4{0u, 0u, 0u, 0u};
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sp[0]) : "v"(src) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(sp[1]) : "v"(src) : "memory");
+        if (p.part_slots == 16 || hi == 0) {
+            asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "+v"(sp[2]) : "v"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "+v"(sp[3]) : "v"(src) : "memory");
+        }
+    };
+    auto stat_consume = [&](auto MI_) __attribute__((always_inline)) {
+        constexpr int mi = decltype(MI_)::value;
+        asm volatile("" : "+v"(sp[0]), "+v"(sp[1]), "+v"(sp[2]), "+v"(sp[3]));      // defined from here on (the wait of this step covered them)
+        auto f = [](unsigned u) { return __builtin_bit_cast(float, u); };
+        float s = ((f(sp[0][0]) + f(sp[0][2])) + (f(sp[1][0]) + f(sp[1][2]))) + ((f(sp[2][0]) + f(sp[2][2])) + (f(sp[3][0]) + f(sp[3][2])));
+        float sq = ((f(sp[0][1]) + f(sp[0][3])) + (f(sp[1][1]) + f(sp[1][3]))) + ((f(sp[2][1]) + f(sp[2][3])) + (f(sp[3][1]) + f(sp[3][3])));
+        const int partner = (lane ^ 32) << 2;
+        s += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(partner, __builtin_bit_cast(int, s)));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(partner, __builtin_bit_cast(int, sq)));
+        const float invD = p.part_invD, eps = p.part_eps;
+        const float mean = s * invD;
+        const float var = fmaxf(sq * invD - mean * mean, 0.f);
+        const float sd = sqrtf(var + eps);
+        tl[2 + mi] = hi ? sd : mean;
+        tl[6 + mi] = 1.0f / sd;
+    };
+    // K step `kstat` of an output tile: consume row tile kstat - 1, fetch row tile kstat (uniform branches, no MFMA inside)
+    auto stats_at = [&](int kstat) __attribute__((always_inline)) {
+        if constexpr (kFuseStats) {
+            if (fuse_stats && kstat >= 0 && kstat <= MIW) {
+                static_for<MIW>([&](auto MI_) {
+                    if (kstat == decltype(MI_)::value + 1) stat_consume(MI_);
+                });
+                static_for<MIW>([&](auto MI_) {
+                    if (kstat == decltype(MI_)::value) stat_loads(MI_);
+                });
+            }
+        }
+    };
     u32x4 GX[4], GW[4];
     uint4 xfA[4], wfA[2], xfB[4], wfB[2];
     auto gloadX = [&](const unsigned (&ox)[4], int kt, auto J) __attribute__((always_inline)) {
@@ -602,7 +659,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     //   SYNC : barrier after MFMA 1 of sub-step 3 (the following K tile is complete in LDS for every wave)
     //   FRAGS: prefetch the first fragments of the following K tile after the barrier (off at an output-tile boundary: the
     //          epilogue runs in between)
-    auto step = [&](int cur, int nxt, const unsigned (&ox)[4], const unsigned (&ow)[4], int ksrc, auto LOAD, auto WRITE, auto SYNC, auto FRAGS, auto ZERO, auto TAIL) __attribute__((always_inline)) {
+    auto step = [&](int cur, int nxt, const unsigned (&ox)[4], const unsigned (&ow)[4], int ksrc, auto LOAD, auto WRITE, auto SYNC, auto FRAGS, auto ZERO, auto TAIL, int kstat = -1) __attribute__((always_inline)) {
         constexpr bool load = decltype(LOAD)::value, write = decltype(WRITE)::value, sync = decltype(SYNC)::value,
                        frags = decltype(FRAGS)::value, tail = decltype(TAIL)::value;
         static_for<NM>([&](auto J) {                                    // sub-step 0
@@ -649,6 +706,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             // stage is free: K tile `ksrc` (two ahead) starts its flight NOW and has a whole K step to land (OPATH 1 issues the
             // same pieces 1.5 - 2.5 sub-steps later, into the other stage)
             if constexpr (tail && j == 2) tail_loads(m0, n0);          // this tile's bias / statistics: covered by the NEXT step's wait
+            if constexpr (kFuseStats && j == 2) stats_at(kstat);       // behind this step's wait and barrier
             if constexpr (OPATH == 2 && load && j >= 2 && MIW == 4) {
                 if constexpr (j < 6) dmaX(ox, ksrc, cur, std::integral_constant<int, j - 2>{});
                 else {
@@ -766,8 +824,8 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, F_{}, F_{}, F_{});      // K tile 0 of the next tile
         } else {
             // step kt waits for K tile kt + 1 (issued by step kt - 1) and issues K tile kt + 2 into its own stage after its barrier
-            step(sb & 1, (sb + 1) & 1, offX, offW, 2, T_{}, F_{}, T_{}, T_{}, T_{}, F_{});
-            for (kt = 1; kt < nk - 2; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 2, T_{}, F_{}, T_{}, T_{}, F_{}, F_{});
+            step(sb & 1, (sb + 1) & 1, offX, offW, 2, T_{}, F_{}, T_{}, T_{}, T_{}, F_{}, 0);
+            for (kt = 1; kt < nk - 2; ++kt) step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, kt + 2, T_{}, F_{}, T_{}, T_{}, F_{}, F_{}, kt);
             offsets(m0n, n0n, offX, offW);
             step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, T_{}, F_{}, T_{}, T_{}, F_{}, T_{});      // K tile 0 of the next tile
             ++kt;
@@ -811,6 +869,21 @@ int persistent_grid() {
 // stores, residual on the early-DMA and the register-staged path with plain stores
 constexpr bool vit_has_192(int mode, int opath, int store) {
     return (mode == 1 && store == 0 && (opath == 0 || opath == 2)) || ((mode == 2 || mode == 4) && opath == 2 && store == 2);
+}
+
+int persistent_grid();
+int vit_pick_miw(int M, int tiles_n, int mode, int opath, int store, int K, int dbg) {
+    if (K == 128 || !vit_has_192(mode, opath, store)) return 4;
+    const long long G = persistent_grid();
+    const long long t256 = (long long)((M + 255) / 256) * tiles_n, t192 = (long long)((M + 191) / 192) * tiles_n;
+    const long long r256 = ((t256 + G - 1) / G) * 256, r192 = ((t192 + G - 1) / G) * 192;
+    int miw = r192 * 10 <= r256 * 9 ? 3 : 4;
+#ifdef CFSAR_DEV
+    if (dbg & (1 << 17)) miw = 3;          // forced (tests / A/B)
+    if (dbg & (1 << 18)) miw = 4;
+#endif
+    (void)dbg;
+    return miw;
 }
 
 template <typename TI, typename TO, int ACT, int MODE, int OPATH, int STORE, bool SHORTK, int MIW = 4>
@@ -864,7 +937,7 @@ static long long* g_trace = nullptr;
 #endif
 // Returns -2 when the call is outside this kernel's contract (the caller falls back to the generic kernels of gemm.hip).
 int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
-    const bool lnfold = c.rowstats != nullptr;
+    const bool lnfold = c.rowstats != nullptr || c.part != nullptr;
     const bool f16io = lnfold ? c.out_dtype == CFSAR_F16 : c.in_dtype == CFSAR_F16;     // the fp16 numerics mode (see launch_path)
     const bool f16res = !lnfold && c.out_dtype == CFSAR_F16 && c.res && c.res_dtype == CFSAR_F16 && c.act == CFSAR_ACT_NONE;
     const bool bf16plain = (c.out_dtype == CFSAR_BF16 || (lnfold && c.out_dtype == CFSAR_F16)) && !c.res &&
@@ -883,6 +956,9 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     a.bias = c.bias;
     a.res = c.res;
     a.rowstats = c.rowstats;
+    a.part = c.part; a.part_slots = c.part_slots; a.part_invD = 1.0f / (float)c.K; a.part_eps = c.part_eps;
+    if (c.part && !(c.opath == 2 && c.K >= 512 && (c.part_slots == 12 || c.part_slots == 16) && c.part_slots * 64 == c.K))
+        return cfsar_fail("cfsar_gemm_lnfold_partials: needs K = 64 slots in {768, 1024} (K=%d, slots=%d)", c.K, c.part_slots);
     a.cvec = c.cvec;
     a.stats_out = c.stats_out;
     a.stats_slots = c.N / 64;
@@ -892,20 +968,8 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     a.tiles_n = (c.N + TN - 1) / TN;
     // Tile height: 192 rows when that saves a tenth of the rounds-x-rows the persistent grid walks (one or two episodes per call:
     // 62 bands x 9 columns of 256-row tiles are 2.2 rounds on 256 CUs and cost 3; 83 x 9 of 192 rows cost 3 x 0.75)
-    a.miw = 4;
-    {
-        const int mode_ = lnfold ? 2 : (f16res ? 1 : 0);
-        if (c.K != 128 && vit_has_192(mode_, c.opath, c.store)) {
-            const long long G = persistent_grid();
-            const long long t256 = (long long)((c.M + 255) / 256) * a.tiles_n, t192 = (long long)((c.M + 191) / 192) * a.tiles_n;
-            const long long r256 = ((t256 + G - 1) / G) * 256, r192 = ((t192 + G - 1) / G) * 192;
-            if (r192 * 10 <= r256 * 9) a.miw = 3;
-#ifdef CFSAR_DEV
-            if (c.dbg & (1 << 17)) a.miw = 3;          // forced (tests / A/B)
-            if (c.dbg & (1 << 18)) a.miw = 4;
-#endif
-        }
-    }
+    a.miw = vit_pick_miw(c.M, a.tiles_n, lnfold ? 2 : (f16res ? 1 : 0), c.opath, c.store, c.K, c.dbg);
+    if (c.part && a.miw != 3) return cfsar_fail("cfsar_gemm_lnfold_partials: internal: fused statistics need the 192-row instance");
     a.ntiles = ((c.M + 64 * a.miw - 1) / (64 * a.miw)) * a.tiles_n;
     a.group = c.group > 0 ? c.group : 8;
     a.colfast = c.colfast;
@@ -976,14 +1040,15 @@ extern "C" void cfsar_debug_set_vit_trace(void* trace, int stagger_unit) { g_tra
 // out = act(LayerNorm(x; gamma, beta) W^T + bias) with the LayerNorm folded into the GEMM (MODE 2 above).  See the header.
 static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
                             const float* rowstats, int M, int N, int K, int lda, int ldw, int ldo, int act, int out_dtype, int hb_tokens,
-                            int hb_heads, cfsar_stream_t stream) {
+                            int hb_heads, cfsar_stream_t stream, const float* partial = nullptr, int slots = 0, float eps = 0.f) {
     CFSAR_REQUIRE(out_dtype == CFSAR_BF16 || out_dtype == CFSAR_F16, "cfsar_gemm_lnfold: out_dtype must be bf16 or fp16, got %d", out_dtype);
-    CFSAR_REQUIRE(x && Wg && out && cvec && dvec && rowstats, "cfsar_gemm_lnfold: null pointer");
+    CFSAR_REQUIRE(x && Wg && out && cvec && dvec && (rowstats || partial), "cfsar_gemm_lnfold: null pointer");
     CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_lnfold: bad shape M=%d N=%d K=%d (K %% 64, N %% 64, K >= 128)", M, N, K);
     CFSAR_REQUIRE(lda >= K && ldw >= K && ldo >= N && lda % 8 == 0 && ldw % 8 == 0 && ldo % 8 == 0, "cfsar_gemm_lnfold: bad leading dimension");
     CFSAR_REQUIRE(act == CFSAR_ACT_NONE || act == CFSAR_ACT_QUICKGELU, "cfsar_gemm_lnfold: bad act %d", act);
     VitGemmCall c;
-    c.A = x; c.W = Wg; c.out = out; c.bias = dvec; c.res = nullptr; c.rowstats = rowstats; c.cvec = cvec; c.stats_out = nullptr;
+    c.A = x; c.W = Wg; c.out = out; c.bias = dvec; c.res = nullptr; c.rowstats = partial ? nullptr : rowstats; c.cvec = cvec; c.stats_out = nullptr;
+    c.part = partial; c.part_slots = slots; c.part_eps = eps;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = 0;
     c.out_dtype = out_dtype; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F32; c.act = act; c.relu = 0;
     c.opath = vit_policy_opath(K); c.store = vit_policy_store(2); c.group = 8; c.colfast = 0; c.dbg = 0;
@@ -1011,6 +1076,35 @@ extern "C" int cfsar_gemm_lnfold_heads(const void* x, const void* Wg, void* out,
     return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats, M, N, K, lda, ldw, N, CFSAR_ACT_NONE, CFSAR_BF16, tokens, heads, stream);
 }
 
+// cfsar_gemm_lnfold / cfsar_gemm_lnfold_heads (tokens > 0) with the row statistics taken straight from the producer's partials
+// (cfsar_gemm_residual_stats: [M, slots, 2]) and finalized inside the kernel: no cfsar_ln_stats_finalize launch in between.  K = 64 slots
+// in {768, 1024} (the ViT-B / ViT-L widths); other widths keep the two-launch form.  See the header.
+extern "C" int cfsar_gemm_lnfold_partials(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
+                                          const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda,
+                                          int ldw, int ldo, int act, int out_dtype, int tokens, int heads, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(partial != nullptr && rowstats_ws != nullptr, "cfsar_gemm_lnfold_partials: null partials / workspace");
+    CFSAR_REQUIRE(slots > 0 && slots * 64 == K, "cfsar_gemm_lnfold_partials: K=%d is not 64 x slots=%d", K, slots);
+    int dbg = 0;
+#ifdef CFSAR_DEV
+    dbg = g_force_dbg;
+#endif
+    // The 192-row instances (small M: one or two episodes per call) finalize the statistics themselves; at batch scale the 256-row
+    // instances have no registers to spare for it and the finalize launch is 0.4 % of the step: two launches from here.
+    const bool fused = vit_policy_opath(K) == 2 && (slots == 12 || slots == 16) && K >= 512 &&
+                       vit_pick_miw(M, (N + TN - 1) / TN, 2, 2, vit_policy_store(2), K, dbg) == 3;
+    if (!fused) {
+        if (int rc = cfsar_ln_stats_finalize(partial, rowstats_ws, M, slots, K, eps, stream)) return rc;
+        if (tokens > 0) return cfsar_gemm_lnfold_heads(x, Wg, out, cvec, dvec, rowstats_ws, M, N, K, lda, ldw, tokens, heads, stream);
+        return cfsar_gemm_lnfold(x, Wg, out, cvec, dvec, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, stream);
+    }
+    if (tokens > 0) {
+        CFSAR_REQUIRE(tokens >= 128 && heads > 0 && N == 192 * heads && M % tokens == 0 && act == CFSAR_ACT_NONE && out_dtype == CFSAR_BF16,
+                      "cfsar_gemm_lnfold_partials: head-blocked output needs tokens >= 128, N = 192 heads, M a multiple of tokens, act NONE, bf16");
+        return gemm_lnfold_impl(x, Wg, out, cvec, dvec, nullptr, M, N, K, lda, ldw, N, act, out_dtype, tokens, heads, stream, partial, slots, eps);
+    }
+    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, nullptr, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, partial, slots, eps);
+}
+
 // x = x + A W^T + bias (fp16 residual stream, in place) and, if stats_partial != NULL, the per-row partial LayerNorm
 // statistics of the NEW x: stats_partial[m][n / 64] = (sum, sum of squares) over columns [64 (n/64), +64).  See the header.
 static int gemm_residual_stats_impl(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M,
@@ -1021,6 +1115,7 @@ static int gemm_residual_stats_impl(const void* A, const void* W, void* x, const
     CFSAR_REQUIRE(lda >= K && ldw >= K && ldx >= N && lda % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, "cfsar_gemm_residual_stats: bad leading dimension");
     VitGemmCall c;
     c.A = A; c.W = W; c.out = x; c.bias = bias; c.res = x; c.rowstats = nullptr; c.cvec = nullptr; c.stats_out = stats_partial;
+    c.part = nullptr; c.part_slots = 0; c.part_eps = 0.f;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldx; c.ldr = ldx;
     c.out_dtype = CFSAR_F16; c.in_dtype = in_dtype; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
     c.opath = vit_policy_opath(K); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;

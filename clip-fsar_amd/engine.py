@@ -137,6 +137,8 @@ class HipViT:
         # (K and V still come from all tokens): -6.3 % of the tower's FLOPs (ViT-B/16, 12 layers), same class-token arithmetic.
         # CFSAR_FULL_LAST_BLOCK=1 computes the whole block like the reference's PyTorch code does (taps always do).
         self.prune_last = os.environ.get("CFSAR_FULL_LAST_BLOCK", "0") != "1"
+        # LN statistics finalized inside the consuming GEMM (ViT-B / ViT-L widths; CFSAR_FUSE_STATS=0: the separate finalize launches)
+        self.fuse_stats = bool(self.fold) and hip.lnfold_partials_ok(self.D, self.D // 64) and os.environ.get("CFSAR_FUSE_STATS", "1") != "0"
         self._slots = {}
         self.max_frames_32bit = (2 ** 32 - 1) // (self.ntok * 4 * self.D * 2) - 1
 
@@ -206,38 +208,59 @@ class HipViT:
             part, rstat, S = ws["part"], ws["rstat"], D // 64
             hip.row_stats(x, rstat, M, D)                                             # statistics of ln_pre's output
             prune = self.prune_last and taps is None and not self.head_blocked
+            # ViT-B / ViT-L widths: the LN-folded GEMMs finalize the producer's partial statistics themselves (cfsar_gemm_lnfold_partials):
+            # no kernel between out_proj and c_fc, c_proj and the next block's QKV (46 launches per tower call; 8 % of a one-episode step)
+            fuse = self.fuse_stats
+            in_part = False                                                           # statistics of x: finalized in rstat / raw in part
+
+            def fold(xx, wg, out, c, d, pt, rs, act=hip.ACT_NONE, rows=M, from_part=False, heads=False):
+                if from_part:
+                    hip.gemm_lnfold_partials(xx, wg, out, c, d, pt, S, rs, act=act, M=rows, tokens=N if heads else 0, heads=self.H if heads else 0)
+                elif heads:
+                    hip.gemm_lnfold_heads(xx, wg, out, c, d, rs, N, self.H, M=rows)
+                else:
+                    hip.gemm_lnfold(xx, wg, out, c, d, rs, act=act, M=rows)
+
             for i, b in enumerate(self.blocks):                                       # :679-681, LayerNorms folded away
                 if prune and i == self.L - 1:
                     # last block: K / V from every token, everything behind the attention for the class-token rows only
                     xc, oc, uc, partc, rstatc = ws["xc"][:F_], ws["oc"][:F_], ws["uc"][:F_], ws["partc"][:F_], ws["rstatc"][:F_]
                     # ... and of q only the class-token rows: K | V for all M rows (N = 2 D: two thirds of the QKV GEMM), q for F rows
                     kv = qkv.view(-1)[:M * 2 * D].view(M, 2 * D)
-                    hip.gemm_lnfold(x, b["wg_qkv"][D:], kv, b["c_qkv"][D:], b["d_qkv"][D:], rstat, M=M)
+                    fold(x, b["wg_qkv"][D:], kv, b["c_qkv"][D:], b["d_qkv"][D:], part, rstat, from_part=in_part)
                     xc.copy_(x[:M].view(F_, N, D)[:, 0, :])                           # class-token rows of the stream
-                    rstatc.copy_(rstat[:M].view(F_, N, 4)[:, 0, :])
+                    if in_part:
+                        partc.copy_(part[:M].view(F_, N, S, 2)[:, 0])
+                    else:
+                        rstatc.copy_(rstat[:M].view(F_, N, 4)[:, 0, :])
                     qc = ws["hc"][:F_]
-                    hip.gemm_lnfold(xc, b["wg_qkv"][:D], qc, b["c_qkv"][:D], b["d_qkv"][:D], rstatc, M=F_)
+                    fold(xc, b["wg_qkv"][:D], qc, b["c_qkv"][:D], b["d_qkv"][:D], partc, rstatc, rows=F_, from_part=in_part)
                     hip.vit_attention_cls(None, oc, F_, N, D, self.H, q=qc, kv=kv)
                     hip.gemm_residual_stats(oc, b["w_out"], xc, b["b_out"], partc, M=F_)
-                    hip.ln_stats_finalize(partc, rstatc, F_, S, D)
-                    hip.gemm_lnfold(xc, b["wg_fc"], uc, b["c_fc"], b["d_fc"], rstatc, act=hip.ACT_QUICKGELU, M=F_)
+                    if not fuse:
+                        hip.ln_stats_finalize(partc, rstatc, F_, S, D)
+                    fold(xc, b["wg_fc"], uc, b["c_fc"], b["d_fc"], partc, rstatc, act=hip.ACT_QUICKGELU, rows=F_, from_part=fuse)
                     hip.gemm_residual_stats(uc, b["w_pr"], xc, b["b_pr"], None, M=F_)
                     xc_final = xc
                     break
                 if self.head_blocked:
                     # qkv and the attention output in head-blocked layout: 75 KB contiguous per (frame, head) for the attention
                     # kernel (called as frames x heads one-head problems), K tile kt of out_proj = head kt
-                    hip.gemm_lnfold_heads(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], rstat, N, self.H, M=M)
+                    fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, heads=True)
                     hip.vit_attention(qkv, o, F_ * self.H, N, 64, 1)
                     hip.gemm_residual_stats_heads(o, b["w_out"], x, b["b_out"], N, part, M=M)
                 else:
-                    hip.gemm_lnfold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], rstat, M=M)
+                    fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part)
                     hip.vit_attention(qkv, o, F_, N, D, self.H)
                     hip.gemm_residual_stats(o, b["w_out"], x, b["b_out"], part, M=M)  # x += out_proj(attn); stats of the new x
-                hip.ln_stats_finalize(part, rstat, M, S, D)
-                hip.gemm_lnfold(x, b["wg_fc"], u, b["c_fc"], b["d_fc"], rstat, act=hip.ACT_QUICKGELU, M=M)
+                if not fuse:
+                    hip.ln_stats_finalize(part, rstat, M, S, D)
+                fold(x, b["wg_fc"], u, b["c_fc"], b["d_fc"], part, rstat, act=hip.ACT_QUICKGELU, from_part=fuse)
                 hip.gemm_residual_stats(u, b["w_pr"], x, b["b_pr"], part, M=M)        # x += c_proj(gelu(c_fc))
-                hip.ln_stats_finalize(part, rstat, M, S, D)
+                if fuse:
+                    in_part = True
+                else:
+                    hip.ln_stats_finalize(part, rstat, M, S, D)
                 if taps is not None:
                     taps["block%d" % i] = x[:M].clone()
         for i, b in enumerate(self.blocks if not self.fold else []):                  # :679-681

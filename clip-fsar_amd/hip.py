@@ -35,6 +35,7 @@ SIGNATURES = {
     "cfsar_gemm_lnfold": [_c_p] * 6 + [_c_int] * 8 + [_c_p],
     "cfsar_gemm_residual_stats": [_c_p] * 5 + [_c_int] * 7 + [_c_p],
     "cfsar_gemm_lnfold_heads": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
+    "cfsar_gemm_lnfold_partials": [_c_p] * 6 + [_c_int, ctypes.c_float, _c_p] + [_c_int] * 10 + [_c_p],
     "cfsar_gemm_residual_stats_heads": [_c_p] * 5 + [_c_int] * 6 + [_c_p],
     "cfsar_ln_stats_finalize": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p],
     "cfsar_row_stats": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p],
@@ -208,6 +209,25 @@ def gemm_lnfold(x, Wg, out, cvec, dvec, rowstats, act=ACT_NONE, M=None):
                                    _dev(cvec, torch.float32, "cvec"), _dev(dvec, torch.float32, "dvec"),
                                    _dev(rowstats, torch.float32, "rowstats"), M, Wg.shape[0], Wg.shape[1], x.shape[1],
                                    Wg.shape[1], out.shape[1], act, _code(out.dtype), _stream()), "cfsar_gemm_lnfold")
+
+
+def lnfold_partials_ok(K, slots):
+    """cfsar_gemm_lnfold_partials: K = 64 slots (fused in-kernel for the ViT-B / ViT-L widths at small M, two launches otherwise)."""
+    return slots > 0 and K == 64 * slots
+
+
+def gemm_lnfold_partials(x, Wg, out, cvec, dvec, partial, slots, rowstats_ws, act=ACT_NONE, M=None, tokens=0, heads=0, eps=1e-5):
+    """gemm_lnfold / gemm_lnfold_heads (tokens > 0) with the statistics finalized inside the GEMM from the producer's partials
+    [M, slots, 2] (include/clipfsar_hip.h: cfsar_gemm_lnfold_partials)."""
+    M = x.shape[0] if M is None else M
+    if out.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError("gemm_lnfold_partials: out must be bf16 or fp16, got %s" % out.dtype)
+    _check(lib().cfsar_gemm_lnfold_partials(_dev(x, torch.float16, "x"), _dev(Wg, torch.float16, "Wg"), _dev(out, None, "out"),
+                                            _dev(cvec, torch.float32, "cvec"), _dev(dvec, torch.float32, "dvec"),
+                                            _dev(partial, torch.float32, "partial"), slots, eps,
+                                            _dev(rowstats_ws, torch.float32, "rowstats_ws"), M, Wg.shape[0], Wg.shape[1], x.shape[1],
+                                            Wg.shape[1], out.shape[-1], act, _code(out.dtype), tokens, heads, _stream()),
+           "cfsar_gemm_lnfold_partials")
 
 
 def gemm_residual_stats(A, W, x, bias, stats_partial=None, M=None):

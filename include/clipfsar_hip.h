@@ -218,6 +218,17 @@ int cfsar_gemm_lnfold(const void* x, const void* Wg, void* out, const float* cve
 int cfsar_gemm_lnfold_heads(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec, const float* rowstats,
                             int M, int N, int K, int lda, int ldw, int tokens, int heads, cfsar_stream_t stream);
 
+/* cfsar_gemm_lnfold (tokens = 0) / cfsar_gemm_lnfold_heads (tokens > 0) with the row statistics taken STRAIGHT from the producer's
+ * partials -- partial [M, slots, 2] = (sum, sum of squares) per 64 columns, as written by cfsar_gemm_residual_stats -- and
+ * finalized inside the GEMM (mean, sqrt(biased variance + eps), reciprocal: the arithmetic of cfsar_ln_stats_finalize), so that no
+ * kernel runs between the producing and the consuming GEMM of a LayerNorm (few_shot.py:605-611 between :635 and :639, :640 and :626).
+ * The in-kernel form exists for K = 64 slots in {768, 1024} (ViT-B/16, ViT-L/14) on the 192-row-tile instances the launcher picks for
+ * small M (one or two episodes per call, where the finalize launches are 8 % of the step); in every other case this entry point runs
+ * cfsar_ln_stats_finalize into rowstats_ws [M, 4] and then the plain form itself -- same result, one call for the caller. */
+int cfsar_gemm_lnfold_partials(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec, const float* partial,
+                               int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda, int ldw, int ldo, int act,
+                               int out_dtype, int tokens, int heads, cfsar_stream_t stream);
+
 /* ---- A5/A6 residual update + the statistics of the next LayerNorm (few_shot.py:633-635 / :639-640 followed by :636 / :626).
  * x[m,n] = x[m,n] + sum_k A[m,k] W[n,k] + bias[n] in place on the fp16 residual stream (A, W of in_dtype: bf16 or fp16).  If stats_partial != NULL it
  * receives, per row m and 64-column slot s = n / 64, (sum, sum of squares) of the NEW (rounded) x[m, 64 s .. 64 s + 63]:

@@ -589,6 +589,34 @@ def _check_lnfold(hip, M, N, K, act, od=torch.bfloat16):
     assert maxdiff(out.float(), ref2) < (6e-3 if od == torch.bfloat16 else 1.5e-3) * scale, (M, N, K, act)    # output rounding (2^-9 / 2^-12) dominates
 
 
+@pytest.mark.parametrize("M,N,K,act,od", [(15760, 2304, 768, "none", torch.bfloat16), (7880, 3072, 768, "gelu", torch.bfloat16),
+                                          (40, 768, 768, "none", torch.bfloat16), (15760, 3072, 768, "gelu", torch.float16),
+                                          (12850, 3072, 1024, "none", torch.bfloat16), (44000, 2304, 768, "none", torch.bfloat16),
+                                          (900, 384, 256, "gelu", torch.bfloat16)])
+def test_gemm_lnfold_partials_matches_finalize_then_lnfold(hip, M, N, K, act, od):
+    """cfsar_gemm_lnfold_partials (statistics finalized inside the 192-row GEMM instances from the producer's partials; two launches
+    from inside the library at batch scale and for other widths) == cfsar_ln_stats_finalize + cfsar_gemm_lnfold on the same partials."""
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(M, K, generator=g) * (0.5 + 2.0 * torch.rand(M, 1, generator=g)) + torch.randn(M, 1, generator=g)).to(torch.float16).cuda()
+    S = K // 64
+    xs = x.float().reshape(M, S, 64)
+    part = torch.stack([xs.sum(2), (xs * xs).sum(2)], 2).contiguous()                   # what cfsar_gemm_residual_stats writes
+    Wg = _rand(N, K, seed=12, scale=K ** -0.5).to(torch.float16).cuda()
+    c, d = Wg.double().sum(1).float(), _rand(N, seed=13).cuda()
+    a = hip.ACT_QUICKGELU if act == "gelu" else hip.ACT_NONE
+    rstat = torch.empty(M, 4, device="cuda")
+    hip.ln_stats_finalize(part, rstat, M, S, K)
+    ref = torch.full((M, N), float("nan"), device="cuda", dtype=od)
+    hip.gemm_lnfold(x, Wg, ref, c, d, rstat, act=a)
+    ws = torch.full((M, 4), float("nan"), device="cuda")
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=od)
+    hip.gemm_lnfold_partials(x, Wg, out, c, d, part, S, ws, act=a)
+    assert not torch.isnan(out.float()).any()
+    # the in-kernel finalize repeats cfsar_ln_stats_finalize's arithmetic in its order: bit-identical outputs, so an episode's logits do
+    # not depend on which instance (192-row fused / 256-row two-launch) served it
+    assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
+
+
 @pytest.mark.parametrize("M,N,K", [(777, 128, 128), (1300, 192, 192), (5000, 768, 768), (44000, 768, 3072), (20500, 1024, 256),
                                    (15760, 768, 3072), (15760, 768, 768), (70000, 768, 768)])    # 15 760 rows (one episode): 192-row tiles, several per workgroup
 def test_gemm_residual_stats_and_finalize(hip, M, N, K):
