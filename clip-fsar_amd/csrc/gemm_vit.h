@@ -20,6 +20,7 @@ struct VitGemmArgs {          // kernel argument block
     int M, N, K;
     int lda, ldw, ldo, ldr;
     int act;
+    int relu;                 // bf16 residual instance only (RN50 conv3 + identity): ReLU applied last
     int tiles_n, ntiles;      // 64 miw x 256 output tiles
     int miw;                  // 4 = 256-row tiles, 3 = 192-row tiles (small M: fewer wasted rounds of the persistent grid)
     int group, colfast;       // tile walk inside an XCD's range (see tile_of)

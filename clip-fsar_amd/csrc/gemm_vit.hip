@@ -314,7 +314,11 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
             const TO8 a = __builtin_bit_cast(TO8, x), b = __builtin_bit_cast(TO8, r);
             TO8 sres;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sres[j] = (TO)((float)a[j] + (float)b[j]);
+            for (int j = 0; j < 8; ++j) {
+                float t = (float)a[j] + (float)b[j];
+                if (p.relu) t = fmaxf(t, 0.0f);                     // relu(bn3(conv3) + identity), few_shot.py:224-226
+                sres[j] = (TO)t;
+            }
             x = __builtin_bit_cast(u32x4, sres);
         }
 #ifdef CFSAR_DEV
@@ -908,6 +912,7 @@ int launch_inst(const VitGemmArgs& a, hipStream_t s) {
 // operands in mode 1, fp16 output in mode 2
 template <int OPATH, int STORE>
 int launch_path(const VitGemmArgs& a, int mode, bool f16io, hipStream_t s) {
+    if (mode == 5) return launch_inst<__bf16, __bf16, CFSAR_ACT_NONE, 1, OPATH, STORE>(a, s);     // bf16 residual (+ ReLU): RN50 conv3
     if (mode == 1) {
         if (f16io) return launch_inst<_Float16, _Float16, CFSAR_ACT_NONE, 1, OPATH, STORE>(a, s);
         return launch_inst<__bf16, _Float16, CFSAR_ACT_NONE, 1, OPATH, STORE>(a, s);
@@ -942,8 +947,12 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     const bool f16res = !lnfold && c.out_dtype == CFSAR_F16 && c.res && c.res_dtype == CFSAR_F16 && c.act == CFSAR_ACT_NONE;
     const bool bf16plain = (c.out_dtype == CFSAR_BF16 || (lnfold && c.out_dtype == CFSAR_F16)) && !c.res &&
                            (c.act == CFSAR_ACT_NONE || c.act == CFSAR_ACT_QUICKGELU);
+    // bf16 activations + bf16 residual (a separate buffer) [+ ReLU] -> bf16: the conv3 + identity of the RN50 bottlenecks (short K: what
+    // this kernel's tile-to-tile operand pipeline is for)
+    const bool bf16res = !lnfold && c.in_dtype == CFSAR_BF16 && c.out_dtype == CFSAR_BF16 && c.res && c.res_dtype == CFSAR_BF16 &&
+                         c.act == CFSAR_ACT_NONE && c.res != c.out;
     if (!lnfold && c.in_dtype == CFSAR_F16 && !f16res) return -2;
-    if (!(f16res || bf16plain) || !c.bias || c.relu) return -2;
+    if (!(f16res || bf16plain || bf16res) || !c.bias || (c.relu && !bf16res)) return -2;
     if (lnfold && (!bf16plain || !c.cvec)) return -2;
     if (c.stats_out && !f16res) return -2;
     if (c.K % 64 != 0 || c.K < 128 || c.N % 64 != 0 || c.ldo % 8 != 0 || (c.res && c.ldr % 8 != 0)) return -2;
@@ -965,10 +974,11 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     a.M = c.M; a.N = c.N; a.K = c.K;
     a.lda = c.lda; a.ldw = c.ldw; a.ldo = c.ldo; a.ldr = c.ldr;
     a.act = c.act;
+    a.relu = c.relu;
     a.tiles_n = (c.N + TN - 1) / TN;
     // Tile height: 192 rows when that saves a tenth of the rounds-x-rows the persistent grid walks (one or two episodes per call:
     // 62 bands x 9 columns of 256-row tiles are 2.2 rounds on 256 CUs and cost 3; 83 x 9 of 192 rows cost 3 x 0.75)
-    a.miw = vit_pick_miw(c.M, a.tiles_n, lnfold ? 2 : (f16res ? 1 : 0), c.opath, c.store, c.K, c.dbg);
+    a.miw = vit_pick_miw(c.M, a.tiles_n, lnfold ? 2 : ((f16res || bf16res) ? 1 : 0), c.opath, c.store, c.K, c.dbg);
     if (c.part && a.miw != 3) return cfsar_fail("cfsar_gemm_lnfold_partials: internal: fused statistics need the 192-row instance");
     a.ntiles = ((c.M + 64 * a.miw - 1) / (64 * a.miw)) * a.tiles_n;
     a.group = c.group > 0 ? c.group : 8;
@@ -984,7 +994,7 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     a.stagger_unit = g_stagger_unit;
     a.trace = g_trace;
 #endif
-    int mode = lnfold ? 2 : (f16res ? 1 : 0);
+    int mode = lnfold ? 2 : (f16res ? 1 : (bf16res ? 5 : 0));
 #ifdef CFSAR_DEV
     if (mode == 0 && c.act == CFSAR_ACT_NONE && (c.dbg & 64)) mode = 3;
 #endif

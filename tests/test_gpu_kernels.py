@@ -418,6 +418,26 @@ def test_gemm_forced_variants_dev(hip, variant):
         L.cfsar_debug_set_gemm_variant(0, 0)
 
 
+@pytest.mark.parametrize("M,N,K", [(125440, 1024, 256), (31360, 2048, 512), (140000, 512, 128), (70001, 1024, 320)])
+def test_rn50_conv3_residual_relu_on_the_persistent_kernel(hip, M, N, K):
+    """relu(A W^T + bias + identity) in bf16 at RN50 batch scale (>= 512 tiles: the persistent kernel of csrc/gemm_vit.hip, bf16-residual
+    instance; K = 128 its two-K-tile form) against the fp32 product of the bf16-rounded operands."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    r = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    hip.gemm(A, W, out, bias=bias, residual=r, relu=True)
+    ref = torch.relu(A.float() @ W.float().t() + bias + r.float())
+    assert not torch.isnan(out.float()).any()
+    assert float((out.float() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
+    out2 = torch.full_like(out, float("nan"))                  # no ReLU
+    hip.gemm(A, W, out2, bias=bias, residual=r)
+    ref2 = A.float() @ W.float().t() + bias + r.float()
+    assert float((out2.float() - ref2).abs().max()) < 2e-2 * max(1.0, float(ref2.abs().max()))
+
+
 @pytest.mark.parametrize("C,H,W_,Co,res", [(32, 12, 10, 64, False), (32, 11, 13, 32, True), (64, 9, 14, 64, False), (128, 7, 7, 128, True), (8, 5, 6, 260, True), (64, 10, 9, 256, False)])
 def test_conv3x3_implicit_gemm(hip, C, H, W_, Co, res):
     """cfsar_conv3x3_nhwc (patch gather inside the GEMM operand staging) == nn.Conv2d(3, padding=1) + bias (+ residual) +
