@@ -53,6 +53,7 @@ constexpr int kPreMinOpath = 1, kPreMaxOpath = 2;
 #define CFSAR_EPI_PIPE 0      // 1 = software-pipelined epilogue stores (measured neutral to negative: profiles/r03_gemm_anatomy.md)
 #endif
 
+constexpr int kActRelu = 100;                   // internal: plain instance with ReLU (RN50 1x1 convs: relu(bn(conv)), few_shot.py:222-223)
 constexpr int TM = 256, TN = 256;              // output tile
 constexpr int ROWB = 128;                      // bytes of K per row per K tile (64 bf16)
 constexpr int STAGE = (TM + TN) * ROWB;        // 64 KiB: X rows [0, 32 KiB), W rows [32 KiB, 64 KiB)
@@ -269,6 +270,10 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
                 if constexpr (ROWSCALE) v[j] *= rscale[mi];
             }
             if constexpr (ACT == CFSAR_ACT_QUICKGELU) quick_gelu4(v);
+            if constexpr (ACT == kActRelu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (TO)v[j];
@@ -931,6 +936,7 @@ int launch_path(const VitGemmArgs& a, int mode, bool f16io, hipStream_t s) {
     if (mode == 3) return launch_inst<_Float16, __bf16, CFSAR_ACT_NONE, 0, OPATH, STORE>(a, s);   // timing A/B: fp16 MFMA on a plain GEMM
 #endif
     if (a.act == CFSAR_ACT_QUICKGELU) return launch_inst<__bf16, __bf16, CFSAR_ACT_QUICKGELU, 0, OPATH, STORE>(a, s);
+    if (a.relu) return launch_inst<__bf16, __bf16, kActRelu, 0, OPATH, STORE>(a, s);
     return launch_inst<__bf16, __bf16, CFSAR_ACT_NONE, 0, OPATH, STORE>(a, s);
 }
 
@@ -952,7 +958,9 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     const bool bf16res = !lnfold && c.in_dtype == CFSAR_BF16 && c.out_dtype == CFSAR_BF16 && c.res && c.res_dtype == CFSAR_BF16 &&
                          c.act == CFSAR_ACT_NONE && c.res != c.out;
     if (!lnfold && c.in_dtype == CFSAR_F16 && !f16res) return -2;
-    if (!(f16res || bf16plain || bf16res) || !c.bias || (c.relu && !bf16res)) return -2;
+    // relu(A W^T + bias), N >= 256 (a 64- or 128-wide conv1 would waste most of the 256-wide tile: those stay on the 256 x 128 / x 64 kernels)
+    const bool plainrelu = bf16plain && !lnfold && c.relu && c.act == CFSAR_ACT_NONE && c.out_dtype == CFSAR_BF16 && c.N >= 256;
+    if (!(f16res || bf16plain || bf16res) || !c.bias || (c.relu && !(bf16res || plainrelu))) return -2;
     if (lnfold && (!bf16plain || !c.cvec)) return -2;
     if (c.stats_out && !f16res) return -2;
     if (c.K % 64 != 0 || c.K < 128 || c.N % 64 != 0 || c.ldo % 8 != 0 || (c.res && c.ldr % 8 != 0)) return -2;

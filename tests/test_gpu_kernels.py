@@ -432,6 +432,10 @@ def test_rn50_conv3_residual_relu_on_the_persistent_kernel(hip, M, N, K):
     ref = torch.relu(A.float() @ W.float().t() + bias + r.float())
     assert not torch.isnan(out.float()).any()
     assert float((out.float() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
+    out3 = torch.full_like(out, float("nan"))                  # relu(A W^T + bias): conv1 of the bottlenecks (plain instance with ReLU)
+    hip.gemm(A, W, out3, bias=bias, relu=True)
+    ref3 = torch.relu(A.float() @ W.float().t() + bias)
+    assert float((out3.float() - ref3).abs().max()) < 2e-2 * max(1.0, float(ref3.abs().max()))
     out2 = torch.full_like(out, float("nan"))                  # no ReLU
     hip.gemm(A, W, out2, bias=bias, residual=r)
     ref2 = A.float() @ W.float().t() + bias + r.float()
