@@ -63,7 +63,7 @@ PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md "Peak 
 
 
 class GemmTimer:
-    """Wraps the 16-bit MFMA GEMM entry points of clip_fsar_amd.hip (gemm, gemm_lnfold, gemm_residual_stats): brackets every
+    """Wraps the 16-bit MFMA GEMM entry points of clip_fsar_amd.hip (gemm, gemm_lnfold, gemm_lnfold_partials, gemm_residual_stats): brackets every
     launch with HIP events on the current stream (no host sync) and sums algorithmic FLOPs; durations are read after the
     timed region."""
 
@@ -94,7 +94,7 @@ class GemmTimer:
                 return r
             setattr(self.hip, name, timed)
         # engine.py binds `hip` as a module attribute, so patching the module functions is enough
-        for name in ("gemm", "gemm_lnfold", "gemm_residual_stats"):
+        for name in ("gemm", "gemm_lnfold", "gemm_lnfold_partials", "gemm_residual_stats"):     # _partials: + its finalize launch at batch scale
             wrap(name)
 
     def result(self):
