@@ -1272,7 +1272,7 @@ static int launch_p12_f16(const GemmArgs& a0, hipStream_t s) {
 }
 
 // ============================================================================================================
-// Skinny fp32 GEMM (M <= 256 rows): the temporal head of ONE episode is (S+Q)*T + S = 85 rows against 512...2048-wide weights,
+// Skinny fp32 GEMM (M <= 256 rows), first form (any K % 32 == 0; the second form below serves K % 128 == 0): the temporal head of ONE episode is (S+Q)*T + S = 85 rows against 512...2048-wide weights,
 // and the final ViT projection of one episode's support / query set is 40 rows.  An MFMA tiling gives such a problem 4-16
 // workgroups with a long serial K loop (66 us per launch); a thread-per-column FMA loop straight from global memory is bound
 // by the latency of its K / 4 dependent loads (60 us).  Here a workgroup owns 8 output columns for all rows and streams K in
@@ -1365,8 +1365,118 @@ static int launch_skinny_inst(const GemmArgs& a, hipStream_t s) {
     return cfsar_check_launch("cfsar_gemm(skinny f32)");
 }
 
+// ---- Skinny fp32 GEMM, second form (K % 128 == 0): register tiles + K split over the workgroup's four waves.
+// The form above gives every thread ONE output column: each thread re-reads the whole A chunk from LDS (2 MB of ds_read_b128 per
+// workgroup for 8 columns) and the launch is a chain of K / 64 barriers on N / 8 workgroups: 20 us at K = 512, 70 us at K = 2 048
+// (tools/skinny_time.py).  Here a workgroup owns an (8 TR) x 32 output tile, wave w the K range [w K / 4, (w + 1) K / 4) of it: a
+// lane accumulates TR x 4 outputs (one A fragment feeds 4 columns, one W fragment TR rows), streams its quarter of K through a
+// wave-private 3-stage LDS ring (LDS-DMA, 32-float chunks: no workgroup barrier inside the K loop), and the four partial tiles are
+// summed through LDS in wave order (deterministic).  Same epilogue.
+template <int TR>
+__global__ __launch_bounds__(256) void skinny2_gemm_f32_kernel(GemmArgs p) {
+    constexpr int AR = 8 * TR;                     // A rows of the tile
+    constexpr int ROWS = AR + 32;                  // + 32 W rows, 128 bytes (32 floats) each
+    constexpr int NI = ROWS / 8;                   // DMA instructions per chunk (8 rows each)
+    constexpr int STG = ROWS * 128;
+    extern __shared__ __attribute__((aligned(16))) char s2_smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tr = lane >> 3, tc = lane & 7;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * AR;
+    const int kq = p.K >> 2;                       // floats of K per wave
+    char* ring = s2_smem + wave * (3 * STG);
+    const char* src[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = i * 8 + (lane >> 3);
+        const int q = (lane & 7) ^ ((row >> 1) & 7);
+        const char* base;
+        if (row < AR) base = p.A + (size_t)(m0 + row < p.M ? m0 + row : p.M - 1) * p.lda * 4;
+        else base = p.W + (size_t)(n0 + row - AR < p.N ? n0 + row - AR : p.N - 1) * p.ldw * 4;
+        src[i] = base + (size_t)wave * kq * 4 + q * 16;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+    auto issue = [&](int chunk, int stage) __attribute__((always_inline)) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)stage * STG);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) glds16_asm(src[i] + (size_t)chunk * 128, dst + i * 1024);
+    };
+    const int nch = kq / 32;
+    issue(0, 0);
+    if (nch > 1) issue(1, 1);
+    float acc[TR][4];
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    // lane (tr, tc): rows tr + 8 i, columns tc + 8 j.  16-byte chunk s4 of LDS row r sits at position s4 ^ ((r >> 1) & 7).
+    int offA[TR], swA[TR], offW[4], swW[4];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) { const int r = tr + 8 * i; offA[i] = r * 128; swA[i] = (r >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int r = AR + tc + 8 * j; offW[j] = r * 128; swW[j] = (r >> 1) & 7; }
+    int stage = 0;
+    for (int c = 0; c < nch; ++c) {
+        if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");     // this wave's chunk c landed, c + 1 in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (c + 2 < nch) issue(c + 2, stage >= 1 ? stage - 1 : 2);       // the stage of chunk c - 1: its reads were consumed by the FMAs
+        const char* sb = ring + stage * STG;
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            float4 a4[TR], w4[4];
+#pragma unroll
+            for (int i = 0; i < TR; ++i) a4[i] = *reinterpret_cast<const float4*>(sb + offA[i] + ((s4 ^ swA[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w4[j] = *reinterpret_cast<const float4*>(sb + offW[j] + ((s4 ^ swW[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TR; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = fmaf(a4[i].x, w4[j].x, acc[i][j]);
+                    acc[i][j] = fmaf(a4[i].y, w4[j].y, acc[i][j]);
+                    acc[i][j] = fmaf(a4[i].z, w4[j].z, acc[i][j]);
+                    acc[i][j] = fmaf(a4[i].w, w4[j].w, acc[i][j]);
+                }
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    // partial tiles -> LDS (each wave into its own ring: no hazard with another wave's DMA), then every thread sums 4 waves in order
+    float* red = reinterpret_cast<float*>(ring);                          // [AR][32]
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[(tr + 8 * i) * 32 + tc + 8 * j] = acc[i][j];
+    __syncthreads();
+    for (int e = t; e < AR * 32; e += 256) {
+        const int r = e >> 5, cidx = e & 31;
+        const int m = m0 + r, n = n0 + cidx;
+        if (m >= p.M || n >= p.N) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += reinterpret_cast<const float*>(s2_smem + w * (3 * STG))[e];
+        int orow = m + p.row_off;
+        if (p.row_group > 0) orow += (m / p.row_group) * p.row_gap;
+        v = apply_act(v + (p.bias ? p.bias[n] : 0.f), p.act);
+        if (p.res) v += static_cast<const float*>(p.res)[(size_t)orow * p.ldr + n];
+        if (p.relu) v = fmaxf(v, 0.f);
+        reinterpret_cast<float*>(p.out)[(size_t)orow * p.ldo + n] = v;
+    }
+}
+
+template <int TR>
+static int launch_skinny2_inst(const GemmArgs& a, hipStream_t s) {
+    constexpr int lds = 4 * 3 * (8 * TR + 32) * 128;
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&skinny2_gemm_f32_kernel<TR>), lds, "cfsar_gemm(skinny2 f32)")) return rc;
+    hipLaunchKernelGGL((skinny2_gemm_f32_kernel<TR>), dim3((unsigned)((a.N + 31) / 32), (unsigned)((a.M + 8 * TR - 1) / (8 * TR))), dim3(256), lds, s, a);
+    return cfsar_check_launch("cfsar_gemm(skinny2 f32)");
+}
+
 // M <= 256, K % 32 == 0 (checked by the caller).  64-float chunks while three stages fit the LDS (M <= 128), else 32.
 static int launch_skinny_f32(const GemmArgs& a, hipStream_t s) {
+    if (a.K % 128 == 0 && !(GDBG(a) & 65536)) {    // register-tiled, K split over the waves; 16-row tiles while they stay within one round of workgroups
+        const long wg16 = (long)((a.M + 15) / 16) * ((a.N + 31) / 32);
+        return wg16 <= 256 ? launch_skinny2_inst<2>(a, s) : launch_skinny2_inst<4>(a, s);
+    }
     const int rpt = (a.M + 31) / 32;
     if (a.K % 64 == 0) {
         switch (rpt) {

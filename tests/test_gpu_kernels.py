@@ -65,11 +65,13 @@ def test_gemm_plain_and_epilogues(hip, M, N, K, dtype):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 8, 64), (40, 512, 768), (85, 1536, 512), (85, 512, 2048), (96, 2048, 512), (97, 100, 96),
-                                   (128, 516, 64), (170, 1536, 512), (192, 36, 160), (33, 24, 32)])
+                                   (128, 516, 64), (170, 1536, 512), (192, 36, 160), (33, 24, 32), (7, 36, 128), (192, 516, 256), (130, 2052, 384)])
 def test_gemm_skinny_f32(hip, M, N, K):
-    """The LDS-ring skinny fp32 kernel (M <= 192: temporal head / final projection of one or two episodes): every rows-per-
-    thread instance and both chunk widths (K % 64 == 0 with M <= 128, else 32-float chunks), N not a multiple of 8, one-chunk and
-    two-chunk K, all epilogues, and the output-row remap of the final projection (rows of a set scattered into [B, S+Q, T])."""
+    """The skinny fp32 kernels (M <= 192: temporal head / final projection of one or two episodes).  K % 128 == 0: register tiles with K
+    split over the workgroup's four waves (16- and 32-row tiles, one- and two-chunk quarters, N not a multiple of 32); otherwise the
+    LDS-ring form: every rows-per-thread instance and both chunk widths (K % 64 == 0 with M <= 128, else 32-float chunks), N not a
+    multiple of 8, one-chunk and two-chunk K.  All epilogues, and the output-row remap of the final projection (rows of a set scattered
+    into [B, S+Q, T])."""
     A = _rand(M, K, seed=31)
     W = _rand(N, K, seed=32, scale=K ** -0.5)
     bias, res = _rand(N, seed=33), _rand(M, N, seed=34)
