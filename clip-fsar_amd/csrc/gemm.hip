@@ -1567,6 +1567,12 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     if (in_dtype == CFSAR_F32 && out_dtype == CFSAR_F32 && res_dtype == CFSAR_F32 && res_mod == 0 && K % 32 == 0 &&
         lda % 4 == 0 && ldw % 4 == 0 && M <= 256 && (forced == 14 || (forced == 0 && M <= 192)))
         return launch_skinny_f32(a, s);
+    // fp32 up to a few thousand rows with K % 128 == 0 (the temporal head at batch scale: 16 episodes = 1 360 rows against 512 ... 2 048-wide
+    // weights) where the fp32-MFMA kernel gets fewer than 64 of its 128 x 128 tiles (N = 512): the register-tiled VALU kernel again, 43 x 16 workgroups
+    if (in_dtype == CFSAR_F32 && out_dtype == CFSAR_F32 && res_dtype == CFSAR_F32 && res_mod == 0 && K % 128 == 0 && lda % 4 == 0 &&
+        ldw % 4 == 0 && M <= 4096 && forced == 0 && (long)((M + 127) / 128) * ((N + 127) / 128) < 64)
+        return launch_skinny2_inst<4>(a, s);       // (same-process A/B at 1 360 rows, us: N = 512, K = 512: 26 vs 39; K = 2 048: 80 vs 134; 640 x 512 x 768: 24 vs 54;
+                                                   //  N >= 1 536 stays on the fp32-MFMA kernel: 41 vs 73-90; tools/skinny_ab.py)
     // The ViT-block GEMMs at batch scale (bias [+ QuickGELU] -> bf16, or bias + fp16 residual -> fp16; >= two 256x256 tiles per
     // CU): the persistent kernel of gemm_vit.hip whose operand pipeline runs through the epilogues.  Dev builds: variant
     // 20 + 4 * opath + store forces it on any shape; dbg bit 256 = column-fastest tile walk, bits 9-11 = band group (see below).
