@@ -61,8 +61,9 @@ def test_epoch(val_loader, model, val_meter, cur_epoch, cfg, writer=None):
         top5 = (1.0 - hit.any(1).float().reshape(B, Q).mean(1)) * 100.0
         stats.append(torch.stack([loss, top1, top5], dim=1))
         preds_all.append(idx[:, 0].reshape(B, Q))
-        real_all.append(task_dict["real_target_labels"].reshape(B, Q))
-        lab_all.append(labels.reshape(B, Q))
+        # copies, not views: the prefetcher's tensors are prefix views of two device buffers that later uploads overwrite
+        real_all.append(task_dict["real_target_labels"].reshape(B, Q).clone())
+        lab_all.append(labels.reshape(B, Q).clone())
         n_local += B
     total = min(int(cfg.TRAIN.NUM_TEST_TASKS), du.get_world_size() * max(n_local, 0) if du.get_world_size() > 1 else n_local)
     local = torch.cat(stats) if stats else torch.zeros(0, 3, device=dev)

@@ -44,6 +44,10 @@ class DevicePrefetcher:
                               for k, v in tens.items()):
             buf = {k: torch.empty(v.shape, dtype=v.dtype, device=self.device) for k, v in tens.items()}
             self._bufs[i] = buf
+            # the caching allocator may hand out a block whose previous owner still has kernels queued on the compute stream: the copy
+            # stream must not write it before they ran
+            self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._done[i] = None
         out = {}
         with torch.cuda.stream(self.copy_stream):
             if self._done[i] is not None:
