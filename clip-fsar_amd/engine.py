@@ -139,6 +139,10 @@ class HipViT:
         self.prune_last = os.environ.get("CFSAR_FULL_LAST_BLOCK", "0") != "1"
         # LN statistics finalized inside the consuming GEMM (ViT-B / ViT-L widths; CFSAR_FUSE_STATS=0: the separate finalize launches)
         self.fuse_stats = bool(self.fold) and hip.lnfold_partials_ok(self.D, self.D // 64) and os.environ.get("CFSAR_FUSE_STATS", "1") != "0"
+        # band-chunked layer schedule (developer switch; measured in profiles/r04_chunked_schedule.md): CFSAR_CHUNK_FRAMES=k,
+        # CFSAR_CHUNK_MODE = block | pairs | mlp
+        self.chunk_frames = int(os.environ.get("CFSAR_CHUNK_FRAMES", "0"))
+        self.chunk_mode = os.environ.get("CFSAR_CHUNK_MODE", "block")
         self._slots = {}
         self.max_frames_32bit = (2 ** 32 - 1) // (self.ntok * 4 * self.D * 2) - 1
 
@@ -249,6 +253,48 @@ class HipViT:
                     fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, heads=True)
                     hip.vit_attention(qkv, o, F_ * self.H, N, 64, 1)
                     hip.gemm_residual_stats_heads(o, b["w_out"], x, b["b_out"], N, part, M=M)
+                elif self.chunk_frames and fuse and F_ > self.chunk_frames:
+                    # band-chunked schedule: the block runs chunk by chunk of frames, the chunk's qkv / o / u live in
+                    # ONE reused buffer prefix so that they are consumed while cache-resident (see profiles/r04_chunked_schedule.md)
+                    cf, mode = self.chunk_frames, self.chunk_mode
+                    for f0 in range(0, F_, cf):
+                        f1 = min(F_, f0 + cf)
+                        r0, r1, nr = f0 * N, f1 * N, (f1 - f0) * N
+                        xs, ps, rs = x[r0:r1], part[r0:r1], rstat[r0:r1]
+                        if mode == "block":          # the whole block per chunk
+                            fold(xs, b["wg_qkv"], qkv[:nr], b["c_qkv"], b["d_qkv"], ps, rs, rows=nr, from_part=in_part)
+                            hip.vit_attention(qkv[:nr], o[:nr], f1 - f0, N, D, self.H)
+                            hip.gemm_residual_stats(o[:nr], b["w_out"], xs, b["b_out"], ps, M=nr)
+                            fold(xs, b["wg_fc"], u[:nr], b["c_fc"], b["d_fc"], ps, rs, act=hip.ACT_QUICKGELU, rows=nr, from_part=True)
+                            hip.gemm_residual_stats(u[:nr], b["w_pr"], xs, b["b_pr"], ps, M=nr)
+                    if mode == "pairs":              # QKV -> attention -> out_proj per chunk, then c_fc -> c_proj per chunk
+                        for f0 in range(0, F_, cf):
+                            f1 = min(F_, f0 + cf)
+                            r0, r1, nr = f0 * N, f1 * N, (f1 - f0) * N
+                            xs, ps, rs = x[r0:r1], part[r0:r1], rstat[r0:r1]
+                            fold(xs, b["wg_qkv"], qkv[:nr], b["c_qkv"], b["d_qkv"], ps, rs, rows=nr, from_part=in_part)
+                            hip.vit_attention(qkv[:nr], o[:nr], f1 - f0, N, D, self.H)
+                            hip.gemm_residual_stats(o[:nr], b["w_out"], xs, b["b_out"], ps, M=nr)
+                        for f0 in range(0, F_, cf):
+                            f1 = min(F_, f0 + cf)
+                            r0, r1, nr = f0 * N, f1 * N, (f1 - f0) * N
+                            xs, ps, rs = x[r0:r1], part[r0:r1], rstat[r0:r1]
+                            fold(xs, b["wg_fc"], u[:nr], b["c_fc"], b["d_fc"], ps, rs, act=hip.ACT_QUICKGELU, rows=nr, from_part=True)
+                            hip.gemm_residual_stats(u[:nr], b["w_pr"], xs, b["b_pr"], ps, M=nr)
+                    elif mode == "mlp":              # only c_fc -> c_proj per chunk
+                        fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part)
+                        hip.vit_attention(qkv, o, F_, N, D, self.H)
+                        hip.gemm_residual_stats(o, b["w_out"], x, b["b_out"], part, M=M)
+                        for f0 in range(0, F_, cf):
+                            f1 = min(F_, f0 + cf)
+                            r0, r1, nr = f0 * N, f1 * N, (f1 - f0) * N
+                            xs, ps, rs = x[r0:r1], part[r0:r1], rstat[r0:r1]
+                            fold(xs, b["wg_fc"], u[:nr], b["c_fc"], b["d_fc"], ps, rs, act=hip.ACT_QUICKGELU, rows=nr, from_part=True)
+                            hip.gemm_residual_stats(u[:nr], b["w_pr"], xs, b["b_pr"], ps, M=nr)
+                    in_part = True
+                    if taps is not None:
+                        taps["block%d" % i] = x[:M].clone()
+                    continue
                 else:
                     fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part)
                     hip.vit_attention(qkv, o, F_, N, D, self.H)

@@ -212,13 +212,28 @@ def context2_state_dict(dim: int, heads: int = 8, dim_head: int | None = None, m
     return sd
 
 
-def head_state_dict(arch: str, seed: int = 18, depth: int = 1, mlp_dim: int = 2048):
+def apply_outlier_channels(sd, prefix: str, channels, gain: float, shift: float):
+    """Trained-CLIP-like activation statistics on a random-init ViT: ``ln_pre`` (few_shot.py:677) gets weight x ``gain`` and
+    bias + ``shift`` on the given channels, so the residual stream carries a few channels with |x| ~ gain + shift (the "massive
+    activation" channels of trained ViTs) and a row mean away from zero through every block -- the regime where the LayerNorm-folded
+    GEMM's (x Wg - mean c) / std cancels large terms."""
+    w, b = sd[prefix + "ln_pre.weight"].copy(), sd[prefix + "ln_pre.bias"].copy()
+    for c in channels:
+        w[c] *= gain
+        b[c] += shift
+    sd[prefix + "ln_pre.weight"], sd[prefix + "ln_pre.bias"] = w.astype(np.float32), b.astype(np.float32)
+    return sd
+
+
+def head_state_dict(arch: str, seed: int = 18, depth: int = 1, mlp_dim: int = 2048, outliers=None):
     """Full ``CNN_OTAM_CLIPFSAR`` state dict (keys as in SURVEY.md section 5 minus the
-    ``head.`` prefix that BaseVideoModel adds)."""
+    ``head.`` prefix that BaseVideoModel adds).  ``outliers`` = dict(channels, gain, shift): see apply_outlier_channels."""
     E = ARCHS[arch]["embed"]
     sd = OrderedDict()
     sd["scale"] = np.ones((1,), np.float32)                      # few_shot.py:2733-2734
     sd.update(visual_state_dict(arch, seed, prefix="backbone."))
+    if outliers:
+        apply_outlier_channels(sd, "backbone.", outliers["channels"], float(outliers["gain"]), float(outliers["shift"]))
     sd.update(context2_state_dict(E, 8, E // 8, mlp_dim, depth, seed, prefix="context2."))
     return sd
 

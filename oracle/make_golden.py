@@ -40,6 +40,10 @@ HEAD_CASES = {
     "t_5w2s_T4_sd": dict(arch="ViT-test/16", way=5, shot=2, q=1, T=4, single_direct=True),
     "t197_5w1s_T2": dict(arch="ViT-test197/16", way=5, shot=1, q=1, T=2),
     "t257_5w1s_T2": dict(arch="ViT-test257/14", way=5, shot=1, q=1, T=2),
+    # trained-CLIP-like activation statistics: two ln_pre channels scaled so that |x| ~ 100 with a non-zero row mean;
+    # pins the cancellation behaviour of the LayerNorm-folded GEMMs before a real checkpoint does
+    "t_outlier_5w1s_T8": dict(arch="ViT-test/16", way=5, shot=1, q=1, T=8, outliers=dict(channels=[5, 77], gain=40.0, shift=60.0)),
+    "t197_outlier_5w1s_T2": dict(arch="ViT-test197/16", way=5, shot=1, q=1, T=2, outliers=dict(channels=[5, 77], gain=40.0, shift=60.0)),
     # N3: ModifiedResNet towers (small test tower; the real RN50 through the reference head's own "RN50" branch)
     "rn_t_5w2s_T4": dict(arch="RN-test", way=5, shot=2, q=1, T=4, lowfreq=2.0),
     "rn50_5w1s_T2": dict(arch="RN50", way=5, shot=1, q=1, T=2, large=True, lowfreq=2.0),
@@ -55,7 +59,7 @@ def run_head_case(name, p):
     arch = p["arch"]
     a = synth.ARCHS[arch]
     depth = p.get("depth", 1)
-    sd = synth.head_state_dict(arch, seed=SEED, depth=depth)
+    sd = synth.head_state_dict(arch, seed=SEED, depth=depth, outliers=p.get("outliers"))
     tt = synth.text_features(N_TRAIN, a["embed"], "train", SEED)
     te = synth.text_features(N_TEST, a["embed"], "test", SEED)
     cfg = rh.make_cfg(arch, way=p["way"], shot=p["shot"], frames=p["T"], n_train=N_TRAIN, n_test=N_TEST,

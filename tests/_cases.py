@@ -49,7 +49,8 @@ def case_inputs(meta, episode=None):
     """(arch dict, head state dict (torch cpu), text_train, text_test, episode dict (torch cpu))"""
     a = synth.ARCHS[meta["arch"]]
     depth = meta.get("depth", 1)
-    sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(meta["arch"], seed=meta["seed"], depth=depth).items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(meta["arch"], seed=meta["seed"], depth=depth,
+                                                                    outliers=meta.get("outliers")).items()}
     tt = torch.from_numpy(synth.text_features(meta["n_train"], a["embed"], "train", meta["seed"]))
     te = torch.from_numpy(synth.text_features(meta["n_test"], a["embed"], "test", meta["seed"]))
     ep = synth.make_episode(way=meta["way"], shot=meta["shot"], query_per_class=meta["q"], frames=meta["T"],

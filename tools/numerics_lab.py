@@ -9,9 +9,11 @@ Scheme grammar: comma-separated key=value over
   stream = f16 | f32 | hilo      residual stream storage (hilo: fp16 hi + fp16 lo, the consumer GEMMs read hi only)
   wres   = f16 | x               out_proj / c_proj weights (x = exact, i.e. a hi + lo split pair)
   wfold  = f16 | x               LN-folded QKV / c_fc weights
+  wqkv, wfc, wout, wpr           one GEMM's weights (override wfold / wres)
   act    = f16 | bf16 | x        patches, qkv, probabilities, attention output, MLP hidden
   u      = (as act)              MLP hidden only, overrides act
   o      = (as act)              attention output only
+  dr     = 0 | 1                 1: GEMM output rounded to fp16 before the residual add (the round-3 epilogue)
 """
 import math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,6 +37,11 @@ def make_tower(s):
     stream, wres, wfold = s.get("stream", "f16"), s.get("wres", "f16"), s.get("wfold", "f16")
     act = s.get("act", "f16")
     ku, ko, kq, kp = s.get("u", act), s.get("o", act), s.get("qkv", act), s.get("p", act)
+    wqkv, wfc, wout, wpr = s.get("wqkv", wfold), s.get("wfc", wfold), s.get("wout", wres), s.get("wpr", wres)
+    dr = s.get("dr", "0") == "1"       # round-3 kernels: the GEMM output is rounded to fp16 BEFORE the (packed fp16) residual add
+
+    def delta(t):
+        return t.half().float() if dr else t
 
     def store(x):            # what the residual stream keeps
         if stream == "f16":
@@ -68,7 +75,7 @@ def make_tower(s):
                 xi = feed(x)
                 gam, bet = g(b + "ln_1.weight"), g(b + "ln_1.bias")
                 mu, var = xi.mean(-1, keepdim=True), xi.var(-1, unbiased=False, keepdim=True)
-                Wg = rnd(g(b + "attn.in_proj_weight") * gam[None, :], wfold)
+                Wg = rnd(g(b + "attn.in_proj_weight") * gam[None, :], wqkv)
                 qkv = ((xi @ Wg.t() - mu * Wg.sum(1)) / torch.sqrt(var + 1e-5)) + (g(b + "attn.in_proj_weight") @ bet + g(b + "attn.in_proj_bias"))
                 qkv = rnd(qkv, kq)
                 q, k, v = qkv.split(D, -1)
@@ -78,14 +85,14 @@ def make_tower(s):
                 e = torch.exp(sc - sc.max(-1, keepdim=True).values)
                 o = (rnd(e, kp) @ v) / e.sum(-1, keepdim=True)
                 o = rnd(o.transpose(1, 2).reshape(F_, N, D), ko)
-                x = store(x + o @ rnd(g(b + "attn.out_proj.weight"), wres).t() + g(b + "attn.out_proj.bias"))
+                x = store(x + delta(o @ rnd(g(b + "attn.out_proj.weight"), wout).t() + g(b + "attn.out_proj.bias")))
                 xi = feed(x)
                 gam, bet = g(b + "ln_2.weight"), g(b + "ln_2.bias")
                 mu, var = xi.mean(-1, keepdim=True), xi.var(-1, unbiased=False, keepdim=True)
-                Wg = rnd(g(b + "mlp.c_fc.weight") * gam[None, :], wfold)
+                Wg = rnd(g(b + "mlp.c_fc.weight") * gam[None, :], wfc)
                 u = ((xi @ Wg.t() - mu * Wg.sum(1)) / torch.sqrt(var + 1e-5)) + (g(b + "mlp.c_fc.weight") @ bet + g(b + "mlp.c_fc.bias"))
                 u = rnd(orc.quick_gelu(u), ku)
-                x = store(x + u @ rnd(g(b + "mlp.c_proj.weight"), wres).t() + g(b + "mlp.c_proj.bias"))
+                x = store(x + delta(u @ rnd(g(b + "mlp.c_proj.weight"), wpr).t() + g(b + "mlp.c_proj.bias")))
             c = orc.layer_norm(x[:, 0, :], g("ln_post.weight"), g("ln_post.bias"))
             outs.append(c @ g("proj"))
         return torch.cat(outs, 0)
