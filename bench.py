@@ -83,7 +83,7 @@ class GemmTimer:
                     return orig(A, W, out, *a, **k)
                 M = k.get("M") or A.shape[0]
                 N = k.get("N") or W.shape[0]
-                K = k.get("K") or A.shape[1]
+                K = k.get("K") or A.shape[1]                     # of A: a split weight matrix is [N, 2K]
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 r = orig(A, W, out, *a, **k)
@@ -94,7 +94,9 @@ class GemmTimer:
                 return r
             setattr(self.hip, name, timed)
         # engine.py binds `hip` as a module attribute, so patching the module functions is enough
-        for name in ("gemm", "gemm_lnfold", "gemm_lnfold_partials", "gemm_residual_stats"):     # _partials: + its finalize launch at batch scale
+        # _partials: + its finalize launch at batch scale; _split / _wide: the fp16 numerics mode's forms (FLOPs stay the ALGORITHMIC
+        # 2 M N K of the reference op: a split-weight launch executes twice that on the matrix cores)
+        for name in ("gemm", "gemm_lnfold", "gemm_lnfold_partials", "gemm_residual_stats", "gemm_lnfold_split", "gemm_residual_wide"):
             wrap(name)
 
     def result(self):
@@ -102,19 +104,35 @@ class GemmTimer:
         return ms, self.flops, self.launches
 
 
+def csrc_fingerprint():
+    """sha256 (16 hex digits) over the GEMM sources: a PMC profile is only quoted for the kernels it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "clip-fsar_amd", "csrc")
+    for n in ("common.h", "gemm.hip", "gemm_vit.h", "gemm_vit.hip"):
+        with open(os.path.join(d, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(episodes_per_step):
-    """HBM bytes per bf16-GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
-    runs, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md; tools/collect_profiles.sh).  PMC collection
-    cannot run inside the timed bench, so the value is read from profiles/ and only reported when it was measured at the
-    same episodes-per-step; otherwise null."""
+    """(HBM bytes per 16-bit GEMM launch, provenance) from the newest committed rocprofv3 PMC profile (FETCH_SIZE and WRITE_SIZE in
+    separate runs, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md; tools/collect_profiles.sh).  PMC collection cannot run
+    inside the timed bench, so the value comes from profiles/ -- and is reported ONLY when the profile was taken at the same
+    episodes-per-step AND on the GEMM sources of this tree (`csrc_sha16` recorded by collect_profiles.sh == csrc_fingerprint()); else
+    null.  The provenance object names the file, its source fingerprint, commit and box either way."""
+    src = {"file": None, "csrc_sha16_profile": None, "csrc_sha16_tree": csrc_fingerprint(), "matches_tree": False}
     try:
-        path = next(p for p in (os.path.join(ROOT, "profiles", n) for n in ("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")) if os.path.exists(p))
+        names = sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_gemm_traffic\.json", n)), reverse=True)
+        path = os.path.join(ROOT, "profiles", names[0])
         d = json.load(open(path))["_all_bf16_gemm"]
-        if re.search(r"--episodes-per-step %d\b" % episodes_per_step, d["note"]):
-            return round(d["hbm_bytes_per_launch"])
+        src.update(file="profiles/" + names[0], csrc_sha16_profile=d.get("csrc_sha16"), commit=d.get("commit"), box=d.get("box"))
+        src["matches_tree"] = d.get("csrc_sha16") == src["csrc_sha16_tree"]
+        if src["matches_tree"] and re.search(r"--episodes-per-step %d\b" % episodes_per_step, d["note"]):
+            return round(d["hbm_bytes_per_launch"]), src
     except Exception:
         pass
-    return None
+    return None, src
 
 
 def _cpu_model():
@@ -393,10 +411,16 @@ def run(args):
     elapsed = time.perf_counter() - t0
     if timer is not None:
         timer.enabled = False
+    rank_elapsed = [elapsed]
+    collective = None
     if use_dist:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        tall = torch.zeros(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(tall, torch.tensor([elapsed], device=dev, dtype=torch.float64))      # outside the timed region
+        rank_elapsed = [float(v) for v in tall.tolist()]
+        elapsed = max(rank_elapsed)                                  # MAX over ranks
+        # what the timed all-gather really spanned: the gathered tensor holds world x steps x B accuracies
+        collective = {"backend": dist.get_backend(), "rccl_world_size": int(gathered.numel() // max(1, args.steps * B)),
+                      "gathered_elements": int(gathered.numel())}
 
     host_inputs = None
     if args.inputs == "host" and not dry:
@@ -484,6 +508,10 @@ def run(args):
                        "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                                    ("bench.py self-spawn" if world > 1 else "single process")},
             "top1_acc_mean": round(float(gathered.mean().item()), 4),
+            # per-rank rates of the timed region (value = all ranks' episodes / the slowest rank's time) and the collective's span
+            "per_rank_episodes_per_s": {"min": round(args.steps * B / max(rank_elapsed), 3), "max": round(args.steps * B / min(rank_elapsed), 3),
+                                        "ranks": len(rank_elapsed)},
+            "collective": collective,
         }
         if dry:
             out["dry_run"] = True
@@ -496,12 +524,13 @@ def run(args):
             if timer is not None and timer.launches:
                 ms, flops, n = timer.result()
                 achieved = flops / (ms * 1e-3) / 1e12
+                traffic, traffic_src = measured_traffic(B) if (args.config == "cfg2" and args.precision == "bf16") else (None, None)
                 out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                                    "frac_scope": "dominant kernel only: the bf16 MFMA GEMM launches of rank 0 (HIP events)",
                                    # episodes/s x TFLOP/episode / peak -- every kernel, launch gaps and the tail included
                                    "frac_end_to_end": round(e2e_tflops / PEAK_BF16_TFLOPS, 4),
-                                   "traffic": measured_traffic(B) if args.config == "cfg2" else None,   # the PMC passes were made on cfg2
+                                   "traffic": traffic, "traffic_source": traffic_src,                 # the PMC passes were made on cfg2, bf16
                                    "kernel": GEMM_KERNEL_NOTE,
                                    "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                                    "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3),

@@ -29,6 +29,12 @@ struct VitGemmArgs {          // kernel argument block
     // contiguous per (frame, head) -- what the attention kernel reads.  ha_tokens: the residual instance reads its A operand from
     // A[((f H + h) T + t) * 64 + c] (K tile kt = head kt), the attention kernel's output in the same blocking.
     int hb_tokens, hb_heads, ha_tokens;
+    // Round 4 (the fp16 numerics mode).  nka: K tiles of A.  nka < K / 64 = "split weights": W is [N, 2 ka] = [W_hi | W_lo] (the fp16
+    // rounding of the fp32 weight and the fp16 rounding of its remainder) and K tile kt >= nka of A is K tile kt - nka again, i.e. the
+    // kernel accumulates A W_hi^T + A W_lo^T in one fp32 chain: the weight carries ~22 bits at twice the MFMA work.
+    // res_lo (wide residual instance, MODE 6): second fp16 word of the residual stream (the rounding remainder of the first) or NULL.
+    int nka;
+    void* res_lo;
 #ifdef CFSAR_DEV
     int dbg;                  // ablations: 4 = no epilogue, 8 = every workgroup reads tile (0, 0), 16 = epilogue without its global stores,
                               // 128 = start-time stagger: workgroup b sleeps ((b >> 3) & 31) * stagger_unit * 64 cycles before its first tile
@@ -55,6 +61,9 @@ struct VitGemmCall {          // host-side request
     int group, colfast;
     int dbg;
     int hb_tokens, hb_heads, ha_tokens;
+    int ka = 0;               // K of A when the weights are split ([N, 2 ka]); 0 = K
+    int wide = 0;             // residual call: fp32 residual add before the ONE rounding to the fp16 stream (MODE 6), res_lo optional
+    void* res_lo = nullptr;
 };
 
 // 0 = launched, > 0 = error (cfsar_last_error), -2 = outside this kernel's contract (caller falls back)

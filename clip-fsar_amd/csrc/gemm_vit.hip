@@ -381,6 +381,108 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
 #endif
 }
 
+// ---- MODE 6 epilogue ("wide" residual; the fp16 numerics mode, round 4).  What differs from epilogue_rows<HAS_RES>: the GEMM result is
+// NOT rounded to fp16 before the residual add (round 3 added two fp16 numbers in packed fp16: two roundings per stream update, and the
+// first one -- 2^-12 of the update -- is what an fp32 or two-word stream would otherwise be free of).  The accumulators cross the LDS as
+// fp32, the residual is added in fp32 and the sum is rounded ONCE: hi = fp16(s); with res_lo != NULL the stream carries a second word
+// lo = fp16(s - hi) (hi + lo ~ 22 bits; the next residual add reads both, the LN-folded consumers read hi only and take its
+// statistics).  One pass = one 32-row x 32-column half of an MFMA tile (4 KiB of fp32 = the wave's slab): 4 ds_write_b128, 4
+// ds_read_b128, 2 x (16 B hi [+ 16 B lo] in, 16 B [+ 16 B] out) per lane; 4 lanes own the 64 contiguous bytes of a row's half.
+// 16-byte slot s of row r sits at physical slot s ^ sw(r), sw(r) = ((r >> 1) & 7) ^ ((r & 1) << 2): distinct over 8 consecutive rows (the
+// 8-lane groups of ds_write_b128) and over the row sets of ds_read_b128's 16-lane groups (MI355X_MICROARCH.md, LDS table).
+template <int STORE, bool FULL, int NMI>
+__device__ __forceinline__ void epilogue_rows_wide(f32x16 (&acc)[NMI][2], const VitGemmArgs& p, int mb, int nb, int lane, char* slab) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lr = lane & 31, hi = lane >> 5;
+    const int rr = lane >> 2, Q = lane & 3;                 // read-back: row rr + 16 it, columns 8 Q .. 8 Q + 7 of the half
+    const bool colok = FULL || nb + 64 <= p.N;
+    const int ncl = colok ? nb : p.N - 64;
+    const int wsw = ((lr >> 1) & 7) ^ ((lr & 1) << 2);
+    const int rsw = ((rr >> 1) & 7) ^ ((rr & 1) << 2);      // rows rr and rr + 16 swizzle alike
+    char* wr = slab + lr * 128;
+    const char* rd = slab + rr * 128;
+    const bool has_lo = p.res_lo != nullptr;                // kernel-uniform
+    const size_t eoff = ((size_t)(mb + rr) * p.ldo + ncl + 8 * Q) * 2;       // residual in place: ldr == ldo
+    char* outp = reinterpret_cast<char*>(p.out) + eoff;
+    char* lop = has_lo ? reinterpret_cast<char*>(p.res_lo) + eoff : nullptr;
+    const unsigned rstep = (unsigned)p.ldo * 32u;           // 16 rows
+    u32x4 rh[2], rl[2], nh[2], nl[2];
+    auto load_res = [&](int pass) __attribute__((always_inline)) {          // pass = 2 mi + ni
+        const int mi_ = pass >> 1, ni_ = pass & 1;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int step = mi_ * 2 + it;
+            const bool ok = FULL || mb + rr + step * 16 < p.M;
+            const size_t o = (size_t)step * rstep + ni_ * 64;
+            nh[it] = ok ? *reinterpret_cast<const u32x4*>(outp + o) : u32x4{0, 0, 0, 0};
+            nl[it] = (ok && has_lo) ? *reinterpret_cast<const u32x4*>(lop + o) : u32x4{0, 0, 0, 0};
+        }
+    };
+    load_res(0);
+    float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 2 * NMI; ++pass) {
+        const int mi = pass >> 1, ni = pass & 1;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) { rh[it] = nh[it]; rl[it] = nl[it]; }
+        if (pass + 1 < 2 * NMI) load_res(pass + 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+            *reinterpret_cast<f4*>(wr + (((2 * g + hi) ^ wsw) << 4)) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const f4 a = *reinterpret_cast<const f4*>(rd + it * 2048 + (((2 * Q) ^ rsw) << 4));
+            const f4 b = *reinterpret_cast<const f4*>(rd + it * 2048 + (((2 * Q + 1) ^ rsw) << 4));
+            const h8 xh = __builtin_bit_cast(h8, rh[it]), xl = __builtin_bit_cast(h8, rl[it]);
+            h8 oh, ol;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = j < 4 ? a[j] : b[j - 4];
+                const float sum = d + ((float)xh[j] + (float)xl[j]);          // hi + lo is exact in fp32
+                const _Float16 h = (_Float16)sum;
+                oh[j] = h;
+                ol[j] = (_Float16)(sum - (float)h);
+            }
+            const int step = mi * 2 + it;
+            const bool rowok = FULL || mb + rr + step * 16 < p.M;
+            if (p.stats_out) {                               // wave-uniform: statistics of the STORED hi words (what the consumer reads)
+                const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+                const h2 s01 = __builtin_shufflevector(oh, oh, 0, 1), s23 = __builtin_shufflevector(oh, oh, 2, 3);
+                const h2 s45 = __builtin_shufflevector(oh, oh, 4, 5), s67 = __builtin_shufflevector(oh, oh, 6, 7);
+                float s_ = 0.f, q_ = 0.f;
+                s_ = __builtin_amdgcn_fdot2(s01, ones, s_, false);
+                q_ = __builtin_amdgcn_fdot2(s01, s01, q_, false);
+                s_ = __builtin_amdgcn_fdot2(s23, ones, s_, false);
+                q_ = __builtin_amdgcn_fdot2(s23, s23, q_, false);
+                s_ = __builtin_amdgcn_fdot2(s45, ones, s_, false);
+                q_ = __builtin_amdgcn_fdot2(s45, s45, q_, false);
+                s_ = __builtin_amdgcn_fdot2(s67, ones, s_, false);
+                q_ = __builtin_amdgcn_fdot2(s67, s67, q_, false);
+                s_ += dpp_move<0xB1>(s_);                    // the 4 lanes Q = 0..3 of a row are one quad
+                q_ += dpp_move<0xB1>(q_);
+                s_ += dpp_move<0x4E>(s_);
+                q_ += dpp_move<0x4E>(q_);
+                if (ni == 0) { ps[it] = s_; pq[it] = q_; }
+                else {
+                    ps[it] += s_; pq[it] += q_;
+                    if (Q == 0 && (FULL || (rowok && colok)))
+                        *reinterpret_cast<float2*>(p.stats_out + ((size_t)(mb + rr + step * 16) * p.stats_slots + (nb >> 6)) * 2) =
+                            make_float2(ps[it], pq[it]);
+                }
+            }
+            if (FULL || (rowok && colok)) {
+                const size_t o = (size_t)step * rstep + ni * 64;
+                store16<STORE>(outp + o, __builtin_bit_cast(u32x4, oh));
+                if (has_lo) store16<STORE>(lop + o, __builtin_bit_cast(u32x4, ol));
+            }
+        }
+    }
+}
+
 // OPATH 0: register-staged operands (global_load_dwordx4 -> VGPR -> ds_write_b128), loads two K tiles ahead.
 // OPATH 1: LDS-DMA operands (global_load_lds_dwordx4), one K tile ahead.
 // MODE 0: out = act(A W^T + bias)                      (TI = bf16 operands; dev builds also instantiate TI = f16 for timing A/B)
@@ -402,7 +504,8 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     constexpr int WR = 32 * MIW;                  // rows of one wave
     constexpr int NM = 2 * MIW;                   // MFMAs per sub-step
     constexpr int NL = MIW + 2;                   // fragment loads per sub-step
-    constexpr bool HAS_RES = MODE == 1;
+    constexpr bool WIDE = MODE == 6;              // residual with the fp32 add + optional second stream word (epilogue_rows_wide)
+    constexpr bool HAS_RES = MODE == 1 || WIDE;
     constexpr bool LNFOLD = MODE == 2 || MODE == 4;       // 4 = LN-folded with head-blocked output (the QKV GEMM)
     constexpr bool HB = MODE == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -611,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     u32x4 GX[4], GW[4];
     uint4 xfA[4], wfA[2], xfB[4], wfB[2];
     auto gloadX = [&](const unsigned (&ox)[4], int kt, auto J) __attribute__((always_inline)) {
-        GX[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.A + (size_t)kt * akstride + ox[decltype(J)::value]);
+        GX[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.A + (size_t)(kt >= p.nka ? kt - p.nka : kt) * akstride + ox[decltype(J)::value]);
     };
     auto gloadW = [&](const unsigned (&ow)[4], int kt, auto J) __attribute__((always_inline)) {
         GW[decltype(J)::value] = *reinterpret_cast<const u32x4*>(p.W + (size_t)kt * ROWB + ow[decltype(J)::value]);
@@ -623,7 +726,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         *reinterpret_cast<u32x4*>(smem + stage * STAGE + TM * ROWB + wr_off + decltype(J)::value * 8192) = GW[decltype(J)::value];
     };
     auto dmaX = [&](const unsigned (&ox)[4], int kt, int stage, auto J) __attribute__((always_inline)) {
-        const char* src = p.A + (size_t)kt * akstride + ox[decltype(J)::value];
+        const char* src = p.A + (size_t)(kt >= p.nka ? kt - p.nka : kt) * akstride + ox[decltype(J)::value];      // split weights: A's K tiles repeat
         const unsigned dst = ldsw + (unsigned)stage * (unsigned)STAGE + (unsigned)decltype(J)::value * 8192u;
 #ifdef CFSAR_DEV
         if (p.dbg & 4096) { glds16_asm_pol<1>(src, dst); return; }       // A/B: streaming operand loaded nt / sc1
@@ -795,7 +898,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         u32x4 rv0[4] = {};
         // (LDS-DMA instance only: in the register-staged one 16 more live registers across the last K step cost 22-30 spills and 10 %)
         auto residual_prefetch = [&]() __attribute__((always_inline)) {     // rows rr + 8 it of the wave's first 32-row pass
-            if constexpr (HAS_RES && (OPATH >= kPreMinOpath && OPATH <= kPreMaxOpath)) {
+            if constexpr (HAS_RES && !WIDE && (OPATH >= kPreMinOpath && OPATH <= kPreMaxOpath)) {
                 const int mb_ = m0 + wm * WR, nb_ = n0 + wn * 64;
                 const int ncl_ = nb_ + 64 <= p.N ? nb_ : p.N - 64;
                 const int rr_ = lane >> 3, Q_ = lane & 7;
@@ -851,6 +954,10 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
 #endif
         {
             const int mb = m0 + wm * WR, nb = n0 + wn * 64;
+            if constexpr (WIDE) {
+                if (mb + WR <= p.M && nb + 64 <= p.N) epilogue_rows_wide<STORE, true, MIW>(acc, p, mb, nb, lane, slab);
+                else epilogue_rows_wide<STORE, false, MIW>(acc, p, mb, nb, lane, slab);
+            } else
             if (mb + WR <= p.M && nb + 64 <= p.N) epilogue_rows<TO, ACT, HAS_RES, STORE, true, LNFOLD, HAS_RES && (OPATH >= kPreMinOpath && OPATH <= kPreMaxOpath), HB, MIW>(acc, p, mb, nb, lane, slab, rscale, rv0);
             else epilogue_rows<TO, ACT, HAS_RES, STORE, false, LNFOLD, HAS_RES && (OPATH >= kPreMinOpath && OPATH <= kPreMaxOpath), HB, MIW>(acc, p, mb, nb, lane, slab, rscale, rv0);
         }
@@ -877,7 +984,7 @@ int persistent_grid() {
 // the 192-row form exists for the product policy's instances only (compile time): LN-folded on the early-DMA path with write-through
 // stores, residual on the early-DMA and the register-staged path with plain stores
 constexpr bool vit_has_192(int mode, int opath, int store) {
-    return (mode == 1 && store == 0 && (opath == 0 || opath == 2)) || ((mode == 2 || mode == 4) && opath == 2 && store == 2);
+    return ((mode == 1 || mode == 6) && store == 0 && (opath == 0 || opath == 2)) || ((mode == 2 || mode == 4) && opath == 2 && store == 2);
 }
 
 int persistent_grid();
@@ -918,6 +1025,7 @@ int launch_inst(const VitGemmArgs& a, hipStream_t s) {
 template <int OPATH, int STORE>
 int launch_path(const VitGemmArgs& a, int mode, bool f16io, hipStream_t s) {
     if (mode == 5) return launch_inst<__bf16, __bf16, CFSAR_ACT_NONE, 1, OPATH, STORE>(a, s);     // bf16 residual (+ ReLU): RN50 conv3
+    if (mode == 6) return launch_inst<_Float16, _Float16, CFSAR_ACT_NONE, 6, OPATH, STORE>(a, s);  // wide residual (fp16 numerics mode)
     if (mode == 1) {
         if (f16io) return launch_inst<_Float16, _Float16, CFSAR_ACT_NONE, 1, OPATH, STORE>(a, s);
         return launch_inst<__bf16, _Float16, CFSAR_ACT_NONE, 1, OPATH, STORE>(a, s);
@@ -973,9 +1081,16 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     a.bias = c.bias;
     a.res = c.res;
     a.rowstats = c.rowstats;
-    a.part = c.part; a.part_slots = c.part_slots; a.part_invD = 1.0f / (float)c.K; a.part_eps = c.part_eps;
-    if (c.part && !(c.opath == 2 && c.K >= 512 && (c.part_slots == 12 || c.part_slots == 16) && c.part_slots * 64 == c.K))
-        return cfsar_fail("cfsar_gemm_lnfold_partials: needs K = 64 slots in {768, 1024} (K=%d, slots=%d)", c.K, c.part_slots);
+    const int ka = c.ka > 0 ? c.ka : c.K;           // K of A (split weights: K = 2 ka)
+    if (!(ka == c.K || (2 * ka == c.K && ka % 64 == 0 && ka >= 128 && c.ha_tokens == 0 && c.hb_tokens == 0 && c.in_dtype == CFSAR_F16)))
+        return cfsar_fail("cfsar_gemm (vit): split weights need K = 2 ka, ka %% 64 == 0, fp16 operands, row-major layouts (K=%d, ka=%d)", c.K, ka);
+    if (c.wide && !(f16res && c.in_dtype == CFSAR_F16 && c.res == c.out && c.ldr == c.ldo && c.ha_tokens == 0))
+        return cfsar_fail("cfsar_gemm_residual_wide: fp16 operands, the residual stream updated in place");
+    a.nka = ka / 64;
+    a.res_lo = c.wide ? c.res_lo : nullptr;
+    a.part = c.part; a.part_slots = c.part_slots; a.part_invD = 1.0f / (float)ka; a.part_eps = c.part_eps;
+    if (c.part && !(c.opath == 2 && ka >= 512 && (c.part_slots == 12 || c.part_slots == 16) && c.part_slots * 64 == ka))
+        return cfsar_fail("cfsar_gemm_lnfold_partials: needs K = 64 slots in {768, 1024} (K=%d, slots=%d)", ka, c.part_slots);
     a.cvec = c.cvec;
     a.stats_out = c.stats_out;
     a.stats_slots = c.N / 64;
@@ -986,7 +1101,7 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     a.tiles_n = (c.N + TN - 1) / TN;
     // Tile height: 192 rows when that saves a tenth of the rounds-x-rows the persistent grid walks (one or two episodes per call:
     // 62 bands x 9 columns of 256-row tiles are 2.2 rounds on 256 CUs and cost 3; 83 x 9 of 192 rows cost 3 x 0.75)
-    a.miw = vit_pick_miw(c.M, a.tiles_n, lnfold ? 2 : ((f16res || bf16res) ? 1 : 0), c.opath, c.store, c.K, c.dbg);
+    a.miw = vit_pick_miw(c.M, a.tiles_n, lnfold ? 2 : ((f16res || bf16res) ? (c.wide ? 6 : 1) : 0), c.opath, c.store, c.K, c.dbg);
     if (c.part && a.miw != 3) return cfsar_fail("cfsar_gemm_lnfold_partials: internal: fused statistics need the 192-row instance");
     a.ntiles = ((c.M + 64 * a.miw - 1) / (64 * a.miw)) * a.tiles_n;
     a.group = c.group > 0 ? c.group : 8;
@@ -1002,7 +1117,7 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     a.stagger_unit = g_stagger_unit;
     a.trace = g_trace;
 #endif
-    int mode = lnfold ? 2 : (f16res ? 1 : (bf16res ? 5 : 0));
+    int mode = lnfold ? 2 : (f16res ? (c.wide ? 6 : 1) : (bf16res ? 5 : 0));
 #ifdef CFSAR_DEV
     if (mode == 0 && c.act == CFSAR_ACT_NONE && (c.dbg & 64)) mode = 3;
 #endif
@@ -1058,13 +1173,16 @@ extern "C" void cfsar_debug_set_vit_trace(void* trace, int stagger_unit) { g_tra
 // out = act(LayerNorm(x; gamma, beta) W^T + bias) with the LayerNorm folded into the GEMM (MODE 2 above).  See the header.
 static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
                             const float* rowstats, int M, int N, int K, int lda, int ldw, int ldo, int act, int out_dtype, int hb_tokens,
-                            int hb_heads, cfsar_stream_t stream, const float* partial = nullptr, int slots = 0, float eps = 0.f) {
+                            int hb_heads, cfsar_stream_t stream, const float* partial = nullptr, int slots = 0, float eps = 0.f, int wsplit = 0) {
     CFSAR_REQUIRE(out_dtype == CFSAR_BF16 || out_dtype == CFSAR_F16, "cfsar_gemm_lnfold: out_dtype must be bf16 or fp16, got %d", out_dtype);
     CFSAR_REQUIRE(x && Wg && out && cvec && dvec && (rowstats || partial), "cfsar_gemm_lnfold: null pointer");
     CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_lnfold: bad shape M=%d N=%d K=%d (K %% 64, N %% 64, K >= 128)", M, N, K);
-    CFSAR_REQUIRE(lda >= K && ldw >= K && ldo >= N && lda % 8 == 0 && ldw % 8 == 0 && ldo % 8 == 0, "cfsar_gemm_lnfold: bad leading dimension");
+    CFSAR_REQUIRE(lda >= K && ldw >= (wsplit ? 2 * K : K) && ldo >= N && lda % 8 == 0 && ldw % 8 == 0 && ldo % 8 == 0, "cfsar_gemm_lnfold: bad leading dimension");
     CFSAR_REQUIRE(act == CFSAR_ACT_NONE || act == CFSAR_ACT_QUICKGELU, "cfsar_gemm_lnfold: bad act %d", act);
+    const int ka_ = K;
+    if (wsplit) K = 2 * K;                            // split weights [N, 2 ka] = [hi | lo]: see VitGemmArgs::nka
     VitGemmCall c;
+    c.ka = ka_;
     c.A = x; c.W = Wg; c.out = out; c.bias = dvec; c.res = nullptr; c.rowstats = partial ? nullptr : rowstats; c.cvec = cvec; c.stats_out = nullptr;
     c.part = partial; c.part_slots = slots; c.part_eps = eps;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = 0;
@@ -1097,9 +1215,9 @@ extern "C" int cfsar_gemm_lnfold_heads(const void* x, const void* Wg, void* out,
 // cfsar_gemm_lnfold / cfsar_gemm_lnfold_heads (tokens > 0) with the row statistics taken straight from the producer's partials
 // (cfsar_gemm_residual_stats: [M, slots, 2]) and finalized inside the kernel: no cfsar_ln_stats_finalize launch in between.  K = 64 slots
 // in {768, 1024} (the ViT-B / ViT-L widths); other widths keep the two-launch form.  See the header.
-extern "C" int cfsar_gemm_lnfold_partials(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
-                                          const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda,
-                                          int ldw, int ldo, int act, int out_dtype, int tokens, int heads, cfsar_stream_t stream) {
+static int lnfold_partials_impl(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
+                                const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda,
+                                int ldw, int ldo, int act, int out_dtype, int tokens, int heads, int wsplit, cfsar_stream_t stream) {
     CFSAR_REQUIRE(partial != nullptr && rowstats_ws != nullptr, "cfsar_gemm_lnfold_partials: null partials / workspace");
     CFSAR_REQUIRE(slots > 0 && slots * 64 == K, "cfsar_gemm_lnfold_partials: K=%d is not 64 x slots=%d", K, slots);
     int dbg = 0;
@@ -1108,19 +1226,40 @@ extern "C" int cfsar_gemm_lnfold_partials(const void* x, const void* Wg, void* o
 #endif
     // The 192-row instances (small M: one or two episodes per call) finalize the statistics themselves; at batch scale the 256-row
     // instances have no registers to spare for it and the finalize launch is 0.4 % of the step: two launches from here.
-    const bool fused = vit_policy_opath(K) == 2 && (slots == 12 || slots == 16) && K >= 512 &&
-                       vit_pick_miw(M, (N + TN - 1) / TN, 2, 2, vit_policy_store(2), K, dbg) == 3;
+    const int Kt = wsplit ? 2 * K : K;
+    const bool fused = vit_policy_opath(Kt) == 2 && (slots == 12 || slots == 16) && K >= 512 &&
+                       vit_pick_miw(M, (N + TN - 1) / TN, 2, 2, vit_policy_store(2), Kt, dbg) == 3;
     if (!fused) {
         if (int rc = cfsar_ln_stats_finalize(partial, rowstats_ws, M, slots, K, eps, stream)) return rc;
         if (tokens > 0) return cfsar_gemm_lnfold_heads(x, Wg, out, cvec, dvec, rowstats_ws, M, N, K, lda, ldw, tokens, heads, stream);
-        return cfsar_gemm_lnfold(x, Wg, out, cvec, dvec, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, stream);
+        return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, nullptr, 0, 0.f, wsplit);
     }
     if (tokens > 0) {
         CFSAR_REQUIRE(tokens >= 128 && heads > 0 && N == 192 * heads && M % tokens == 0 && act == CFSAR_ACT_NONE && out_dtype == CFSAR_BF16,
                       "cfsar_gemm_lnfold_partials: head-blocked output needs tokens >= 128, N = 192 heads, M a multiple of tokens, act NONE, bf16");
         return gemm_lnfold_impl(x, Wg, out, cvec, dvec, nullptr, M, N, K, lda, ldw, N, act, out_dtype, tokens, heads, stream, partial, slots, eps);
     }
-    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, nullptr, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, partial, slots, eps);
+    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, nullptr, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, partial, slots, eps, wsplit);
+}
+
+extern "C" int cfsar_gemm_lnfold_partials(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
+                                          const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda,
+                                          int ldw, int ldo, int act, int out_dtype, int tokens, int heads, cfsar_stream_t stream) {
+    return lnfold_partials_impl(x, Wg, out, cvec, dvec, partial, slots, eps, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, tokens, heads, 0, stream);
+}
+
+// The fp16 numerics mode's LN-folded GEMM with SPLIT weights: Wg2 [N, 2 K] = [fp16(W gamma) | fp16(W gamma - fp16(W gamma))], the kernel walks
+// x's K tiles twice in one fp32 accumulation chain (see the header).  Statistics: rowstats [M, 4] (partial == NULL) or the producer's
+// partials [M, slots, 2] finalized here (rowstats_ws [M, 4] is then the workspace of the two-launch form).
+extern "C" int cfsar_gemm_lnfold_split(const void* x, const void* Wg2, void* out, const float* cvec, const float* dvec, const float* rowstats,
+                                       const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda, int ldw,
+                                       int ldo, int act, int out_dtype, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(out_dtype == CFSAR_F16, "cfsar_gemm_lnfold_split: fp16 output only (the fp16 numerics mode)");
+    if (partial != nullptr) {
+        CFSAR_REQUIRE(slots > 0 && slots * 64 == K, "cfsar_gemm_lnfold_split: K=%d is not 64 x slots=%d", K, slots);
+        return lnfold_partials_impl(x, Wg2, out, cvec, dvec, partial, slots, eps, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, 1, stream);
+    }
+    return gemm_lnfold_impl(x, Wg2, out, cvec, dvec, rowstats, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, nullptr, 0, 0.f, 1);
 }
 
 // x = x + A W^T + bias (fp16 residual stream, in place) and, if stats_partial != NULL, the per-row partial LayerNorm
@@ -1148,6 +1287,29 @@ static int gemm_residual_stats_impl(const void* A, const void* W, void* x, const
 extern "C" int cfsar_gemm_residual_stats(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M,
                                          int N, int K, int lda, int ldw, int ldx, int in_dtype, cfsar_stream_t stream) {
     return gemm_residual_stats_impl(A, W, x, bias, stats_partial, M, N, K, lda, ldw, ldx, in_dtype, 0, stream);
+}
+
+// The fp16 numerics mode's residual GEMM: x = x + A W^T + bias with the add in fp32 and ONE rounding (MODE 6); x_lo != NULL: two-word
+// stream (x_hi + x_lo); wsplit: W is [N, 2 K] = [hi | lo].  See the header.
+extern "C" int cfsar_gemm_residual_wide(const void* A, const void* W, void* x_hi, void* x_lo, const float* bias, float* stats_partial, int M,
+                                        int N, int K, int wsplit, int lda, int ldw, int ldx, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(A && W && x_hi && bias, "cfsar_gemm_residual_wide: null pointer");
+    CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_residual_wide: bad shape M=%d N=%d K=%d", M, N, K);
+    const int Kt = wsplit ? 2 * K : K;
+    CFSAR_REQUIRE(lda >= K && ldw >= Kt && ldx >= N && lda % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, "cfsar_gemm_residual_wide: bad leading dimension");
+    VitGemmCall c;
+    c.A = A; c.W = W; c.out = x_hi; c.bias = bias; c.res = x_hi; c.rowstats = nullptr; c.cvec = nullptr; c.stats_out = stats_partial;
+    c.part = nullptr; c.part_slots = 0; c.part_eps = 0.f;
+    c.M = M; c.N = N; c.K = Kt; c.lda = lda; c.ldw = ldw; c.ldo = ldx; c.ldr = ldx;
+    c.out_dtype = CFSAR_F16; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
+    c.opath = vit_policy_opath(Kt); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;
+    c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = 0;
+    c.ka = K; c.wide = 1; c.res_lo = x_lo;
+#ifdef CFSAR_DEV
+    c.dbg = g_force_dbg & ((1 << 17) | (1 << 18));
+#endif
+    const int rc = cfsar_gemm_vit_try(c, static_cast<hipStream_t>(stream));
+    return rc == -2 ? cfsar_fail("cfsar_gemm_residual_wide: operands too large for 32-bit offsets") : rc;
 }
 
 // The out_proj form: A is the attention output in head-blocked layout A[((f heads + h) tokens + t) * 64 + c], heads = K / 64.

@@ -419,6 +419,39 @@ extern "C" int cfsar_ln_stats_finalize(const float* partial, float* rowstats, in
     return cfsar_check_launch("cfsar_ln_stats_finalize");
 }
 
+namespace {
+// two-word fp16 stream -> fp32 (round 4: in front of ln_post on the class-token rows)
+__global__ __launch_bounds__(256) void f16_pair_to_f32_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo,
+                                                              float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)hi[i] + (float)lo[i];
+}
+
+// strided row gather in 4-byte words: one workgroup per row
+__global__ __launch_bounds__(256) void copy_rows_strided_kernel(const char* __restrict__ src, long long src_stride, char* __restrict__ dst,
+                                                                long long dst_stride, int words) {
+    const unsigned* s = reinterpret_cast<const unsigned*>(src + (long long)blockIdx.x * src_stride);
+    unsigned* d = reinterpret_cast<unsigned*>(dst + (long long)blockIdx.x * dst_stride);
+    for (int i = threadIdx.x; i < words; i += 256) d[i] = s[i];
+}
+}  // namespace
+
+extern "C" int cfsar_f16_pair_to_f32(const void* hi, const void* lo, float* out, int64_t n, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(hi && lo && out && n > 0, "cfsar_f16_pair_to_f32: bad argument");
+    hipLaunchKernelGGL(f16_pair_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const _Float16*>(hi), static_cast<const _Float16*>(lo), out, (long long)n);
+    return cfsar_check_launch("cfsar_f16_pair_to_f32");
+}
+
+extern "C" int cfsar_copy_rows_strided(const void* src, int64_t src_stride, void* dst, int64_t dst_stride, int rows, int row_bytes,
+                                       cfsar_stream_t stream) {
+    CFSAR_REQUIRE(src && dst && rows > 0 && row_bytes > 0 && row_bytes % 4 == 0 && src_stride % 4 == 0 && dst_stride % 4 == 0,
+                  "cfsar_copy_rows_strided: bad argument (rows=%d row_bytes=%d)", rows, row_bytes);
+    hipLaunchKernelGGL(copy_rows_strided_kernel, dim3((unsigned)rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const char*>(src), (long long)src_stride, static_cast<char*>(dst), (long long)dst_stride, row_bytes / 4);
+    return cfsar_check_launch("cfsar_copy_rows_strided");
+}
+
 extern "C" int cfsar_row_stats(const void* x, float* rowstats, int M, int D, int ld, float eps, cfsar_stream_t stream) {
     CFSAR_REQUIRE(x && rowstats && M > 0 && D > 0 && D % 8 == 0 && ld >= D && ld % 8 == 0, "cfsar_row_stats: bad argument");
     hipLaunchKernelGGL(row_stats_f16_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),

@@ -67,5 +67,6 @@ int cfsar_num_cus() {
     return n;
 }
 
-extern "C" int cfsar_version(void) { return 201; /* 0.2.1 */ }
+extern "C" int cfsar_version(void) { return 400; /* 0.4.0 */ }
+extern "C" int cfsar_abi_version(void) { return CFSAR_ABI_VERSION; }
 extern "C" const char* cfsar_last_error(void) { return cfsar_err_buf; }

@@ -2,7 +2,7 @@
 
 The reference's loader yields the 7-key episode dict with a leading batch dim of 1 per GPU
 (TEST.BATCH_SIZE / NUM_GPUS = 1) which the test loop strips (runs/test_net_few_shot.py:59-62).  This loader yields
-the same dict with a leading dim of ``cfg.TEST.EPISODES_PER_STEP`` (default 1) episodes, for the static shard
+the same dict with a leading dim of ``cfg.TEST.EPISODES_PER_STEP`` episodes (unset / 0: chosen by ``auto_episodes_per_step``), for the static shard
 {e : e % world == rank} of a seed-indexed episode list."""
 import torch
 
@@ -47,6 +47,37 @@ def build_dataset(name, cfg, split):
     return cls(cfg, split)
 
 
+AUTO_EPISODES_PER_STEP_MAX = 16      # the tower's GEMMs run at their batch-scale rate from ~1 000 frames per launch
+
+
+def auto_episodes_per_step(cfg, n_local):
+    """Episodes per model call when the config does not say (a reference-shaped config has no TEST.EPISODES_PER_STEP: the reference
+    feeds ONE episode per iteration, runs/test_net_few_shot.py:57-64, which leaves 20 % of this tower's throughput on the table).
+    The loader collates k episodes -- per-episode results do not depend on k (tests/test_gpu_e2e.py: batch invariance) -- with k
+    bounded by the rank's episode count, by 16, and by half of the free HBM over an upper estimate of one episode's footprint (two
+    upload buffers of fp32 frames + the tower's activation workspace)."""
+    if not (torch.cuda.is_available() and int(getattr(cfg, "NUM_GPUS", 1) or 0) > 0):
+        return 1
+    arch = synth.ARCHS.get(cfg.VIDEO.HEAD.BACKBONE_NAME, None)
+    way = int(getattr(cfg.TRAIN, "WAT_TEST", 0) or cfg.TRAIN.WAY)
+    shot = int(getattr(cfg.TRAIN, "SHOT_TEST", getattr(cfg.TRAIN, "SHOT", 1)))
+    qpc = int(getattr(cfg.TRAIN, "QUERY_PER_CLASS_TEST", getattr(cfg.TRAIN, "QUERY_PER_CLASS", 1)))
+    frames = way * (shot + qpc) * int(cfg.DATA.NUM_INPUT_FRAMES)
+    res = int(getattr(cfg.DATA, "TEST_CROP_SIZE", arch["res"] if arch else 224))
+    per_frame = 2 * 3 * res * res * 4
+    if arch and arch.get("kind") != "rn":
+        ntok = (arch["res"] // arch["patch"]) ** 2 + 1
+        per_frame += ntok * arch["width"] * 28          # x (two words), qkv, o, u, patches, statistics: < 28 bytes per token-channel
+    else:
+        per_frame += 12 << 20                           # RN50: NHWC activations of the widest stage, generously
+    try:
+        free = torch.cuda.mem_get_info()[0]
+    except Exception:
+        return 1
+    k = int(0.5 * free // max(1, per_frame * frames))
+    return max(1, min(AUTO_EPISODES_PER_STEP_MAX, k, max(1, int(n_local))))
+
+
 def build_loader(cfg, split):
     assert split in ("test", "val", "train")
     name = getattr(cfg.TEST, "DATASET", "Synthetic_few_shot")
@@ -56,7 +87,9 @@ def build_loader(cfg, split):
     ds = build_dataset(name, cfg, split)
     idx = du.shard_episodes(len(ds))
     sub = torch.utils.data.Subset(ds, idx)
-    bs = int(getattr(cfg.TEST, "EPISODES_PER_STEP", 1))
+    bs = int(getattr(cfg.TEST, "EPISODES_PER_STEP", 0) or 0)
+    if bs <= 0:
+        bs = auto_episodes_per_step(cfg, len(idx))
     # DATA_LOADER.{NUM_WORKERS, PIN_MEMORY} as in the reference (datasets/base/builder.py:83-92; its configs pin): pinned batches are what
     # makes the copy-stream upload of runs/test_net_few_shot.py asynchronous (utils/prefetch.py).  Pinning needs a GPU runtime.
     dl = getattr(cfg, "DATA_LOADER", None)

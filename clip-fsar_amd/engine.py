@@ -24,6 +24,10 @@ import torch
 from . import hip
 
 
+# fp16 numerics mode: the GEMMs whose weights are carried as hi + lo pairs by default (see HipViT.__init__ and profiles/r04_parity_table.md)
+FP16_SPLIT_DEFAULT = "qkv,out,pr"
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -31,7 +35,7 @@ def _round_up(x, m):
 class HipViT:
     """CLIP VisionTransformer.forward (reference few_shot.py:671-688) on the HIP kernels."""
 
-    def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda", stream_dtype=None):
+    def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda", stream_dtype=None, fp16_split=None):
         if precision not in ("bf16", "fp16", "fp32"):
             raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
         self.arch = dict(arch)
@@ -100,6 +104,35 @@ class HipViT:
             wmax16 = max(wmax16, float(self.w_patch.float().abs().max()))
             if not wmax16 < 6.0e4:
                 raise ValueError("precision 'fp16': a weight exceeds the fp16 range (max |w| = %.3g); use 'bf16' or 'fp32'" % wmax16)
+        # fp16 numerics mode, round 4 (profiles/r04_parity_table.md; tools/numerics_lab.py is the CPU model that chose these):
+        #   wide   -- out_proj / c_proj add their result to the stream in fp32 and round ONCE (cfsar_gemm_residual_wide; round 3 rounded
+        #             the GEMM result to fp16 and added in fp16);
+        #   two_word -- the stream is x_hi + x_lo (two fp16 words, ~22 bits): residual adds read and write both, the LN-folded GEMMs
+        #             read x_hi and its statistics;
+        #   split  -- which GEMMs carry their weights as fp16 hi + lo pairs [N, 2K] (the rounding of the WEIGHTS is the error that
+        #             does not average out over tokens and frames): twice the MFMA work of each GEMM named.
+        # CFSAR_FP16_WIDE / CFSAR_FP16_LO / CFSAR_FP16_SPLIT override the defaults (ablation: tools/parity_report.py).
+        self.wide = precision == "fp16" and os.environ.get("CFSAR_FP16_WIDE", "1") != "0"
+        self.two_word = self.wide and os.environ.get("CFSAR_FP16_LO", "1") != "0"
+        sp = os.environ.get("CFSAR_FP16_SPLIT", FP16_SPLIT_DEFAULT if fp16_split is None else fp16_split) if precision == "fp16" else ""
+        self.split = set(t for t in sp.split(",") if t)
+        if not self.split <= {"qkv", "out", "fc", "pr"}:
+            raise ValueError("CFSAR_FP16_SPLIT: names out of qkv,out,fc,pr expected, got %r" % sp)
+        if self.split and not self.wide and (self.split & {"out", "pr"}):
+            raise ValueError("split out_proj / c_proj weights need the wide residual GEMM (CFSAR_FP16_WIDE=1)")
+
+        def hilo(W32):
+            """fp32 [N, K] -> fp16 [N, 2K] = [hi | lo]"""
+            hi = W32.to(torch.float16)
+            lo = (W32 - hi.float()).to(torch.float16)
+            return torch.cat([hi, lo], 1).contiguous()
+
+        for i, blk in enumerate(self.blocks if self.split else []):
+            b = "transformer.resblocks.%d." % i
+            if "out" in self.split:
+                blk["w_out"] = hilo(g(b + "attn.out_proj.weight"))
+            if "pr" in self.split:
+                blk["w_pr"] = hilo(g(b + "mlp.c_proj.weight"))
         if self.fold:
             for i, blk in enumerate(self.blocks):
                 b = "transformer.resblocks.%d." % i
@@ -107,9 +140,12 @@ class HipViT:
                                               ("fc", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln2")):
                     W = g(b + wname)
                     gamma, beta = blk[ln]
-                    Wg = (W * gamma[None, :]).to(torch.float16).contiguous()
+                    if tag in self.split:
+                        Wg = hilo(W * gamma[None, :])
+                    else:
+                        Wg = (W * gamma[None, :]).to(torch.float16).contiguous()
                     blk["wg_" + tag] = Wg
-                    blk["c_" + tag] = Wg.double().sum(1).float().contiguous()          # of the ROUNDED folded weights
+                    blk["c_" + tag] = Wg.double().sum(1).float().contiguous()          # of the ROUNDED folded weights (hi + lo when split)
                     blk["d_" + tag] = (W.double() @ beta.double() + g(b + bname).double()).float().contiguous()
             # the kernel feeds c, d, mean and std to the matrix pipe as fp16 hi + lo pairs and the folded weights as fp16: a checkpoint
             # whose folded quantities leave the fp16 range cannot use the folded block (CLIP's are O(1) ... O(10))
@@ -132,6 +168,8 @@ class HipViT:
         # 3 us: GPU busy time 311.4 vs 308.7 ms per 6 steps.  Kept (bit-identical results, tests/test_gpu_kernels.py) for a future
         # attention kernel that can use whole contiguous items.
         self.head_blocked = (self.fold and self.ntok >= 128 and D == 64 * self.H and os.environ.get("CFSAR_HEAD_BLOCKED", "0") == "1")
+        if self.head_blocked and precision == "fp16":
+            raise ValueError("CFSAR_HEAD_BLOCKED=1 exists for the bf16 mode only (the head-blocked GEMM instances write bf16)")
         # Last block, class token only.  VisionTransformer.forward reads x[:, 0] after the last block and nothing else of it
         # (few_shot.py:683), so in THAT block the attention output, out_proj and the MLP are needed for row 0 of every frame alone
         # (K and V still come from all tokens): -6.3 % of the tower's FLOPs (ViT-B/16, 12 layers), same class-token arithmetic.
@@ -165,6 +203,10 @@ class HipViT:
                 ws["part"] = torch.empty(M, D // 64, 2, device=dev, dtype=torch.float32)    # partial row statistics
                 ws["rstat"] = torch.empty(M, 4, device=dev, dtype=torch.float32)            # (mean, std, 1/std, -)
             # class-token rows of the last block (prune_last): [F, .]
+            if self.two_word:
+                ws["xlo"] = torch.empty(M, D, device=dev, dtype=torch.float16)                # second word of the stream
+                ws["xlc"] = torch.empty(F_, D, device=dev, dtype=torch.float16)
+                ws["c32"] = torch.empty(F_, D, device=dev, dtype=torch.float32)
             ws["xc"] = torch.empty(F_, D, device=dev, dtype=self.xd)
             ws["hc"] = torch.empty(F_, D, device=dev, dtype=cd)
             ws["oc"] = torch.empty(F_, D, device=dev, dtype=cd)
@@ -208,43 +250,66 @@ class HipViT:
         if taps is not None:
             taps["ln_pre"] = x[:M].clone()
         xc_final = None
+        es = x.element_size()
+
+        def class_rows(src, dst, row_elems, elem_bytes):
+            """dst[f] = src[f * N] (row 0 of every frame): the class-token rows / their statistics (few_shot.py:683 reads nothing else)"""
+            hip.copy_rows_strided(src, N * row_elems * elem_bytes, dst, row_elems * elem_bytes, F_, row_elems * elem_bytes)
+
         if self.fold:
             part, rstat, S = ws["part"], ws["rstat"], D // 64
+            xlo = ws["xlo"] if self.two_word else None
+            if xlo is not None:
+                xlo[:M].zero_()                                                       # memset: the stream enters the blocks as ln_pre's fp16 output
             hip.row_stats(x, rstat, M, D)                                             # statistics of ln_pre's output
             prune = self.prune_last and taps is None and not self.head_blocked
             # ViT-B / ViT-L widths: the LN-folded GEMMs finalize the producer's partial statistics themselves (cfsar_gemm_lnfold_partials):
             # no kernel between out_proj and c_fc, c_proj and the next block's QKV (46 launches per tower call; 8 % of a one-episode step)
             fuse = self.fuse_stats
             in_part = False                                                           # statistics of x: finalized in rstat / raw in part
+            split = self.split
 
-            def fold(xx, wg, out, c, d, pt, rs, act=hip.ACT_NONE, rows=M, from_part=False, heads=False):
-                if from_part:
+            def fold(xx, wg, out, c, d, pt, rs, act=hip.ACT_NONE, rows=M, from_part=False, heads=False, sp=False):
+                if sp:                                                                # split weights [N, 2K] (fp16 numerics mode)
+                    hip.gemm_lnfold_split(xx, wg, out, c, d, rowstats=None if from_part else rs, partial=pt if from_part else None,
+                                          slots=S if from_part else 0, rowstats_ws=rs, act=act, M=rows)
+                elif from_part:
                     hip.gemm_lnfold_partials(xx, wg, out, c, d, pt, S, rs, act=act, M=rows, tokens=N if heads else 0, heads=self.H if heads else 0)
                 elif heads:
                     hip.gemm_lnfold_heads(xx, wg, out, c, d, rs, N, self.H, M=rows)
                 else:
                     hip.gemm_lnfold(xx, wg, out, c, d, rs, act=act, M=rows)
 
+            def resid(A, blk, key, xx, xl, pt, rows):
+                """xx (+ xl) += A W^T + bias, partial LayerNorm statistics of the new stream -> pt"""
+                if self.wide:
+                    hip.gemm_residual_wide(A, blk["w_" + key], xx, xl, blk["b_" + key], pt, M=rows, wsplit=key in split)
+                else:
+                    hip.gemm_residual_stats(A, blk["w_" + key], xx, blk["b_" + key], pt, M=rows)
+
             for i, b in enumerate(self.blocks):                                       # :679-681, LayerNorms folded away
                 if prune and i == self.L - 1:
                     # last block: K / V from every token, everything behind the attention for the class-token rows only
                     xc, oc, uc, partc, rstatc = ws["xc"][:F_], ws["oc"][:F_], ws["uc"][:F_], ws["partc"][:F_], ws["rstatc"][:F_]
+                    xlc = ws["xlc"][:F_] if xlo is not None else None
                     # ... and of q only the class-token rows: K | V for all M rows (N = 2 D: two thirds of the QKV GEMM), q for F rows
                     kv = qkv.view(-1)[:M * 2 * D].view(M, 2 * D)
-                    fold(x, b["wg_qkv"][D:], kv, b["c_qkv"][D:], b["d_qkv"][D:], part, rstat, from_part=in_part)
-                    xc.copy_(x[:M].view(F_, N, D)[:, 0, :])                           # class-token rows of the stream
+                    fold(x, b["wg_qkv"][D:], kv, b["c_qkv"][D:], b["d_qkv"][D:], part, rstat, from_part=in_part, sp="qkv" in split)
+                    class_rows(x, xc, D, es)                                          # class-token rows of the stream
+                    if xlo is not None:
+                        class_rows(xlo, xlc, D, 2)
                     if in_part:
-                        partc.copy_(part[:M].view(F_, N, S, 2)[:, 0])
+                        class_rows(part, partc, 2 * S, 4)
                     else:
-                        rstatc.copy_(rstat[:M].view(F_, N, 4)[:, 0, :])
+                        class_rows(rstat, rstatc, 4, 4)
                     qc = ws["hc"][:F_]
-                    fold(xc, b["wg_qkv"][:D], qc, b["c_qkv"][:D], b["d_qkv"][:D], partc, rstatc, rows=F_, from_part=in_part)
+                    fold(xc, b["wg_qkv"][:D], qc, b["c_qkv"][:D], b["d_qkv"][:D], partc, rstatc, rows=F_, from_part=in_part, sp="qkv" in split)
                     hip.vit_attention_cls(None, oc, F_, N, D, self.H, q=qc, kv=kv)
-                    hip.gemm_residual_stats(oc, b["w_out"], xc, b["b_out"], partc, M=F_)
+                    resid(oc, b, "out", xc, xlc, partc, F_)
                     if not fuse:
                         hip.ln_stats_finalize(partc, rstatc, F_, S, D)
-                    fold(xc, b["wg_fc"], uc, b["c_fc"], b["d_fc"], partc, rstatc, act=hip.ACT_QUICKGELU, rows=F_, from_part=fuse)
-                    hip.gemm_residual_stats(uc, b["w_pr"], xc, b["b_pr"], None, M=F_)
+                    fold(xc, b["wg_fc"], uc, b["c_fc"], b["d_fc"], partc, rstatc, act=hip.ACT_QUICKGELU, rows=F_, from_part=fuse, sp="fc" in split)
+                    resid(uc, b, "pr", xc, xlc, None, F_)
                     xc_final = xc
                     break
                 if self.head_blocked:
@@ -253,69 +318,67 @@ class HipViT:
                     fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, heads=True)
                     hip.vit_attention(qkv, o, F_ * self.H, N, 64, 1)
                     hip.gemm_residual_stats_heads(o, b["w_out"], x, b["b_out"], N, part, M=M)
-                elif self.chunk_frames and fuse and F_ > self.chunk_frames:
-                    # band-chunked schedule: the block runs chunk by chunk of frames, the chunk's qkv / o / u live in
-                    # ONE reused buffer prefix so that they are consumed while cache-resident (see profiles/r04_chunked_schedule.md)
+                elif self.chunk_frames and fuse and F_ > self.chunk_frames and not self.wide:
+                    # band-chunked schedule (developer switch, measured SLOWER at every chunk size:
+                    # profiles/r04_chunked_schedule.md): the block runs chunk by chunk of frames, the chunk's qkv / o / u live in ONE
+                    # reused buffer prefix so that they are consumed while cache-resident
                     cf, mode = self.chunk_frames, self.chunk_mode
-                    for f0 in range(0, F_, cf):
-                        f1 = min(F_, f0 + cf)
+
+                    def attn_part(f0, f1):
                         r0, r1, nr = f0 * N, f1 * N, (f1 - f0) * N
                         xs, ps, rs = x[r0:r1], part[r0:r1], rstat[r0:r1]
-                        if mode == "block":          # the whole block per chunk
-                            fold(xs, b["wg_qkv"], qkv[:nr], b["c_qkv"], b["d_qkv"], ps, rs, rows=nr, from_part=in_part)
-                            hip.vit_attention(qkv[:nr], o[:nr], f1 - f0, N, D, self.H)
-                            hip.gemm_residual_stats(o[:nr], b["w_out"], xs, b["b_out"], ps, M=nr)
-                            fold(xs, b["wg_fc"], u[:nr], b["c_fc"], b["d_fc"], ps, rs, act=hip.ACT_QUICKGELU, rows=nr, from_part=True)
-                            hip.gemm_residual_stats(u[:nr], b["w_pr"], xs, b["b_pr"], ps, M=nr)
-                    if mode == "pairs":              # QKV -> attention -> out_proj per chunk, then c_fc -> c_proj per chunk
-                        for f0 in range(0, F_, cf):
-                            f1 = min(F_, f0 + cf)
-                            r0, r1, nr = f0 * N, f1 * N, (f1 - f0) * N
-                            xs, ps, rs = x[r0:r1], part[r0:r1], rstat[r0:r1]
-                            fold(xs, b["wg_qkv"], qkv[:nr], b["c_qkv"], b["d_qkv"], ps, rs, rows=nr, from_part=in_part)
-                            hip.vit_attention(qkv[:nr], o[:nr], f1 - f0, N, D, self.H)
-                            hip.gemm_residual_stats(o[:nr], b["w_out"], xs, b["b_out"], ps, M=nr)
-                        for f0 in range(0, F_, cf):
-                            f1 = min(F_, f0 + cf)
-                            r0, r1, nr = f0 * N, f1 * N, (f1 - f0) * N
-                            xs, ps, rs = x[r0:r1], part[r0:r1], rstat[r0:r1]
-                            fold(xs, b["wg_fc"], u[:nr], b["c_fc"], b["d_fc"], ps, rs, act=hip.ACT_QUICKGELU, rows=nr, from_part=True)
-                            hip.gemm_residual_stats(u[:nr], b["w_pr"], xs, b["b_pr"], ps, M=nr)
-                    elif mode == "mlp":              # only c_fc -> c_proj per chunk
-                        fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part)
-                        hip.vit_attention(qkv, o, F_, N, D, self.H)
-                        hip.gemm_residual_stats(o, b["w_out"], x, b["b_out"], part, M=M)
-                        for f0 in range(0, F_, cf):
-                            f1 = min(F_, f0 + cf)
-                            r0, r1, nr = f0 * N, f1 * N, (f1 - f0) * N
-                            xs, ps, rs = x[r0:r1], part[r0:r1], rstat[r0:r1]
-                            fold(xs, b["wg_fc"], u[:nr], b["c_fc"], b["d_fc"], ps, rs, act=hip.ACT_QUICKGELU, rows=nr, from_part=True)
-                            hip.gemm_residual_stats(u[:nr], b["w_pr"], xs, b["b_pr"], ps, M=nr)
+                        fold(xs, b["wg_qkv"], qkv[:nr], b["c_qkv"], b["d_qkv"], ps, rs, rows=nr, from_part=in_part)
+                        hip.vit_attention(qkv[:nr], o[:nr], f1 - f0, N, D, self.H)
+                        hip.gemm_residual_stats(o[:nr], b["w_out"], xs, b["b_out"], ps, M=nr)
+
+                    def mlp_part(f0, f1):
+                        r0, r1, nr = f0 * N, f1 * N, (f1 - f0) * N
+                        xs, ps, rs = x[r0:r1], part[r0:r1], rstat[r0:r1]
+                        fold(xs, b["wg_fc"], u[:nr], b["c_fc"], b["d_fc"], ps, rs, act=hip.ACT_QUICKGELU, rows=nr, from_part=True)
+                        hip.gemm_residual_stats(u[:nr], b["w_pr"], xs, b["b_pr"], ps, M=nr)
+
+                    chunks = [(f0, min(F_, f0 + cf)) for f0 in range(0, F_, cf)]
+                    if mode == "block":              # the whole block per chunk
+                        for f0, f1 in chunks:
+                            attn_part(f0, f1)
+                            mlp_part(f0, f1)
+                    elif mode == "pairs":            # QKV -> attention -> out_proj per chunk, then c_fc -> c_proj per chunk
+                        for f0, f1 in chunks:
+                            attn_part(f0, f1)
+                        for f0, f1 in chunks:
+                            mlp_part(f0, f1)
+                    else:                            # "mlp": only c_fc -> c_proj per chunk
+                        attn_part(0, F_)
+                        for f0, f1 in chunks:
+                            mlp_part(f0, f1)
                     in_part = True
                     if taps is not None:
                         taps["block%d" % i] = x[:M].clone()
                     continue
                 else:
-                    fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part)
+                    fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, sp="qkv" in split)
                     hip.vit_attention(qkv, o, F_, N, D, self.H)
-                    hip.gemm_residual_stats(o, b["w_out"], x, b["b_out"], part, M=M)  # x += out_proj(attn); stats of the new x
+                    resid(o, b, "out", x, xlo, part, M)                               # x += out_proj(attn); stats of the new x
                 if not fuse:
                     hip.ln_stats_finalize(part, rstat, M, S, D)
-                fold(x, b["wg_fc"], u, b["c_fc"], b["d_fc"], part, rstat, act=hip.ACT_QUICKGELU, from_part=fuse)
-                hip.gemm_residual_stats(u, b["w_pr"], x, b["b_pr"], part, M=M)        # x += c_proj(gelu(c_fc))
+                fold(x, b["wg_fc"], u, b["c_fc"], b["d_fc"], part, rstat, act=hip.ACT_QUICKGELU, from_part=fuse, sp="fc" in split)
+                if self.head_blocked:
+                    hip.gemm_residual_stats(u, b["w_pr"], x, b["b_pr"], part, M=M)
+                else:
+                    resid(u, b, "pr", x, xlo, part, M)                                # x += c_proj(gelu(c_fc))
                 if fuse:
                     in_part = True
                 else:
                     hip.ln_stats_finalize(part, rstat, M, S, D)
                 if taps is not None:
-                    taps["block%d" % i] = x[:M].clone()
+                    taps["block%d" % i] = (x[:M].float() + xlo[:M].float()) if xlo is not None else x[:M].clone()
         for i, b in enumerate(self.blocks if not self.fold else []):                  # :679-681
             if self.prune_last and taps is None and i == self.L - 1:
                 xc, hc, oc, uc = ws["xc"][:F_], ws["hc"][:F_], ws["oc"][:F_], ws["uc"][:F_]
                 hip.layernorm(x, h, b["ln1"][0], b["ln1"][1], M, D)
                 hip.gemm(h, b["w_qkv"], qkv, bias=b["b_qkv"], M=M)
                 hip.vit_attention_cls(qkv, oc, F_, N, D, self.H)
-                xc.copy_(x[:M].view(F_, N, D)[:, 0, :])
+                class_rows(x, xc, D, es)
                 hip.gemm(oc, b["w_out"], xc, bias=b["b_out"], residual=xc, M=F_)
                 hip.layernorm(xc, hc, b["ln2"][0], b["ln2"][1], F_, D)
                 hip.gemm(hc, b["w_fc"], uc, bias=b["b_fc"], act=hip.ACT_QUICKGELU, M=F_)
@@ -332,7 +395,14 @@ class HipViT:
             if taps is not None:
                 taps["block%d" % i] = x[:M].clone()
         # A8: ln_post on the class-token rows (stride N*D) then @ proj, fp32
-        if xc_final is not None:
+        if self.fold and self.two_word:                                                # two-word stream: ln_post reads x_hi + x_lo
+            if xc_final is None:
+                xc_final = ws["xc"][:F_]
+                class_rows(x, xc_final, D, es)
+                class_rows(ws["xlo"], ws["xlc"][:F_], D, 2)
+            hip.f16_pair_to_f32(xc_final, ws["xlc"][:F_], ws["c32"][:F_])
+            hip.layernorm(ws["c32"], ws["c"], self.ln_post[0], self.ln_post[1], F_, D, in_stride=D, out_stride=D)
+        elif xc_final is not None:
             hip.layernorm(xc_final, ws["c"], self.ln_post[0], self.ln_post[1], F_, D, in_stride=D, out_stride=D)
         else:
             hip.layernorm(x, ws["c"], self.ln_post[0], self.ln_post[1], F_, D, in_stride=N * D, out_stride=D)
@@ -586,11 +656,13 @@ class ClipFsarEngine:
     """Full episodic forward A0 -> A15 for a batch of B episodes with identical (way, shot, query, T)."""
 
     def __init__(self, arch: dict, head_sd: dict, text_train, text_test, depth: int = 1, precision: str = "bf16",
-                 device="cuda", max_frames: int = 1280):
+                 device="cuda", max_frames: int = 1280, fp16_split=None):
         self.dev = torch.device(device)
         self.arch = dict(arch)
-        tower = HipResNet if arch.get("kind") == "rn" else HipViT
-        self.vit = tower(arch, head_sd, prefix="backbone.", precision=precision, device=device)
+        if arch.get("kind") == "rn":
+            self.vit = HipResNet(arch, head_sd, prefix="backbone.", precision=precision, device=device)
+        else:
+            self.vit = HipViT(arch, head_sd, prefix="backbone.", precision=precision, device=device, fp16_split=fp16_split)
         self.temporal = HipTemporalHead(head_sd, arch["embed"], depth=depth, device=device)
         f32 = lambda t: (t if isinstance(t, torch.Tensor) else torch.from_numpy(t)).detach().to(
             device=self.dev, dtype=torch.float32).contiguous()

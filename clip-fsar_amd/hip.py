@@ -11,6 +11,7 @@ import os
 import torch  # noqa: F401  (imported first so that torch's libamdhip64.so.7 is the HIP runtime the library binds to)
 
 F32, BF16, F16 = 0, 1, 2
+ABI_VERSION = 4          # CFSAR_ABI_VERSION of include/clipfsar_hip.h this file's SIGNATURES were written against
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -37,6 +38,11 @@ SIGNATURES = {
     "cfsar_gemm_lnfold_heads": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
     "cfsar_gemm_lnfold_partials": [_c_p] * 6 + [_c_int, ctypes.c_float, _c_p] + [_c_int] * 10 + [_c_p],
     "cfsar_gemm_residual_stats_heads": [_c_p] * 5 + [_c_int] * 6 + [_c_p],
+    "cfsar_gemm_lnfold_split": [_c_p] * 7 + [_c_int, ctypes.c_float, _c_p] + [_c_int] * 8 + [_c_p],
+    "cfsar_gemm_residual_wide": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
+    "cfsar_f16_pair_to_f32": [_c_p, _c_p, _c_p, _c_i64, _c_p],
+    "cfsar_copy_rows_strided": [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_int, _c_p],
+    "cfsar_abi_version": [],
     "cfsar_ln_stats_finalize": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p],
     "cfsar_row_stats": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p],
     "cfsar_nchw_to_nhwc": [_c_p, _c_p] + [_c_int] * 5 + [_c_p],
@@ -75,6 +81,9 @@ def lib():
             fn.restype = _c_int
         L.cfsar_last_error.restype = ctypes.c_char_p
         L.cfsar_last_error.argtypes = []
+        if L.cfsar_abi_version() != ABI_VERSION:
+            raise RuntimeError("clip_fsar_amd: %s has ABI revision %d, this binding was written against %d -- rebuild it "
+                               "(python clip-fsar_amd/build.py --force)" % (LIB_PATH, L.cfsar_abi_version(), ABI_VERSION))
         if DEV_LIB:
             L.cfsar_debug_set_gemm_variant.argtypes = [ctypes.c_int, ctypes.c_int]
             L.cfsar_debug_set_gemm_variant.restype = None
@@ -240,6 +249,42 @@ def gemm_residual_stats(A, W, x, bias, stats_partial=None, M=None):
                                            _dev(bias, torch.float32, "bias"), _opt(stats_partial, torch.float32, "stats_partial"),
                                            M, W.shape[0], W.shape[1], A.shape[1], W.shape[1], x.shape[1], _code(A.dtype), _stream()),
            "cfsar_gemm_residual_stats")
+
+
+def gemm_lnfold_split(x, Wg2, out, cvec, dvec, rowstats=None, partial=None, slots=0, rowstats_ws=None, act=ACT_NONE, M=None, eps=1e-5):
+    """gemm_lnfold / gemm_lnfold_partials with split weights Wg2 [N, 2K] = [hi | lo] (fp16 numerics mode; cfsar_gemm_lnfold_split)."""
+    M = x.shape[0] if M is None else M
+    K = x.shape[1]
+    if Wg2.shape[1] != 2 * K or out.dtype != torch.float16:
+        raise RuntimeError("gemm_lnfold_split: Wg2 must be [N, 2K] and out fp16")
+    _check(lib().cfsar_gemm_lnfold_split(_dev(x, torch.float16, "x"), _dev(Wg2, torch.float16, "Wg2"), _dev(out, None, "out"),
+                                         _dev(cvec, torch.float32, "cvec"), _dev(dvec, torch.float32, "dvec"),
+                                         _opt(rowstats, torch.float32, "rowstats"), _opt(partial, torch.float32, "partial"), slots, eps,
+                                         _opt(rowstats_ws, torch.float32, "rowstats_ws"), M, Wg2.shape[0], K, x.shape[1], Wg2.shape[1],
+                                         out.shape[-1], act, _code(out.dtype), _stream()), "cfsar_gemm_lnfold_split")
+
+
+def gemm_residual_wide(A, W, x, x_lo, bias, stats_partial=None, M=None, wsplit=False):
+    """x (+ x_lo) += A @ W.T + bias with the add in fp32 and ONE rounding; W [N, K] or split [N, 2K] (cfsar_gemm_residual_wide)."""
+    M = A.shape[0] if M is None else M
+    K = A.shape[1]
+    if W.shape[1] != (2 * K if wsplit else K):
+        raise RuntimeError("gemm_residual_wide: W has %d columns, expected %d" % (W.shape[1], 2 * K if wsplit else K))
+    _check(lib().cfsar_gemm_residual_wide(_dev(A, torch.float16, "A"), _dev(W, torch.float16, "W"), _dev(x, torch.float16, "x"),
+                                          _opt(x_lo, torch.float16, "x_lo"), _dev(bias, torch.float32, "bias"),
+                                          _opt(stats_partial, torch.float32, "stats_partial"), M, W.shape[0], K, int(bool(wsplit)),
+                                          A.shape[1], W.shape[1], x.shape[1], _stream()), "cfsar_gemm_residual_wide")
+
+
+def f16_pair_to_f32(hi, lo, out):
+    _check(lib().cfsar_f16_pair_to_f32(_dev(hi, torch.float16, "hi"), _dev(lo, torch.float16, "lo"), _dev(out, torch.float32, "out"),
+                                       hi.numel(), _stream()), "cfsar_f16_pair_to_f32")
+
+
+def copy_rows_strided(src, src_stride_bytes, dst, dst_stride_bytes, rows, row_bytes):
+    """dst row r <- src row r (byte strides); src / dst: device tensors whose data_ptr is row 0 (cfsar_copy_rows_strided)."""
+    _check(lib().cfsar_copy_rows_strided(_dev(src, None, "src"), src_stride_bytes, _dev(dst, None, "dst"), dst_stride_bytes, rows,
+                                         row_bytes, _stream()), "cfsar_copy_rows_strided")
 
 
 def gemm_lnfold_heads(x, Wg, out, cvec, dvec, rowstats, tokens, heads, M=None):

@@ -45,7 +45,14 @@ def test_epoch(val_loader, model, val_meter, cur_epoch, cfg, writer=None):
             if head is not None and hasattr(head, "validate_labels_host") and not host["support_labels"].is_cuda:
                 return {"_labels_validated_way": head.validate_labels_host(host["support_labels"], host["real_support_labels"])}
             return None
-        batches = DevicePrefetcher(val_loader, dev, pre_upload=check_on_host)
+        # A loader that yields ONE episode per item (the reference's own: TEST.BATCH_SIZE / NUM_GPUS = 1, :57-64) under a config that
+        # does not set TEST.EPISODES_PER_STEP: the prefetcher collates k items per model call (k from the free HBM, <= 16); per-episode
+        # results do not depend on k.  build_loader's own loaders already come batched (datasets/base/builder.py).
+        k = 1
+        if not int(getattr(cfg.TEST, "EPISODES_PER_STEP", 0) or 0) and int(getattr(val_loader, "batch_size", 0) or 0) == 1:
+            from ..datasets.base.builder import auto_episodes_per_step
+            k = auto_episodes_per_step(cfg, len(val_loader))
+        batches = DevicePrefetcher(val_loader, dev, pre_upload=check_on_host, collate=k)
     for cur_iter, task_dict in enumerate(batches):
         if n_local >= cfg.TRAIN.NUM_TEST_TASKS:
             break
@@ -90,7 +97,8 @@ def test_epoch(val_loader, model, val_meter, cur_epoch, cfg, writer=None):
     acc = 100.0 - allstats[:, 1]
     result = {"episodes": int(allstats.shape[0]), "top1_acc": float(acc.mean()) if len(acc) else float("nan"),
               "top1_acc_ci95": float(1.96 * acc.std(unbiased=False) / max(len(acc), 1) ** 0.5) if len(acc) else float("nan"),
-              "loss": float(allstats[:, 0].mean()) if len(acc) else float("nan"), "epoch_stats": epoch_stats}
+              "loss": float(allstats[:, 0].mean()) if len(acc) else float("nan"), "epoch_stats": epoch_stats,
+              "top1_per_class": {c: (top1_per_class[c], num_per_class[c]) for c in sorted(top1_per_class)}}
     val_meter.reset()
     return result
 

@@ -16,33 +16,48 @@ import torch
 
 
 class DevicePrefetcher:
-    def __init__(self, loader, device, pre_upload=None):
+    def __init__(self, loader, device, pre_upload=None, collate=1):
         self.loader = loader
         self.device = torch.device(device)
         self.pre_upload = pre_upload          # callable(host_batch) -> dict of extra (non-tensor) entries, run BEFORE the upload
+        # collate = k > 1: k consecutive loader items are concatenated along dim 0 into ONE step (a reference-shaped loader yields one
+        # episode per item, runs/test_net_few_shot.py:57-64; the tower wants ~16): host items are copied straight into their slice of
+        # the device buffer, resident items are concatenated on the device
+        self.collate = max(1, int(collate))
         self.copy_stream = torch.cuda.Stream(self.device)
         self._bufs = [None, None]
         self._ready = [None, None]
         self._done = [None, None]
 
     def __len__(self):
-        return len(self.loader)
+        return (len(self.loader) + self.collate - 1) // self.collate
 
-    def _stage(self, i, host):
-        extra = self.pre_upload(host) if self.pre_upload is not None else None
-        tens = {k: v for k, v in host.items() if isinstance(v, torch.Tensor)}
-        if tens and all(v.is_cuda for v in tens.values()):              # already resident: hand it through
+    def _stage(self, i, hosts):
+        extra = None
+        if self.pre_upload is not None:
+            for h in hosts:
+                e = self.pre_upload(h)
+                if e is not None and extra is not None and e != extra:
+                    raise ValueError("DevicePrefetcher: the collated episodes disagree on %r vs %r" % (e, extra))
+                extra = e if e is not None else extra
+        host = hosts[0]
+        keys = [k for k, v in host.items() if isinstance(v, torch.Tensor)]
+        if keys and all(h[k].is_cuda for h in hosts for k in keys):      # already resident: hand it through / concatenate on the device
             out = dict(host)
+            if len(hosts) > 1:
+                for k in keys:
+                    out[k] = torch.cat([h[k] for h in hosts], 0)
             if extra:
                 out.update(extra)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
             self._ready[i] = ev
             return out
+        rows = {k: sum(int(h[k].shape[0]) for h in hosts) for k in keys}
         buf = self._bufs[i]
-        if buf is None or any(k not in buf or buf[k].shape[1:] != v.shape[1:] or buf[k].dtype != v.dtype or buf[k].shape[0] < v.shape[0]
-                              for k, v in tens.items()):
-            buf = {k: torch.empty(v.shape, dtype=v.dtype, device=self.device) for k, v in tens.items()}
+        if buf is None or any(k not in buf or buf[k].shape[1:] != host[k].shape[1:] or buf[k].dtype != host[k].dtype or buf[k].shape[0] < rows[k]
+                              for k in keys):
+            buf = {k: torch.empty((rows[k],) + tuple(host[k].shape[1:]), dtype=host[k].dtype, device=self.device) for k in keys}
             self._bufs[i] = buf
             # the caching allocator may hand out a block whose previous owner still has kernels queued on the compute stream: the copy
             # stream must not write it before they ran
@@ -52,10 +67,13 @@ class DevicePrefetcher:
         with torch.cuda.stream(self.copy_stream):
             if self._done[i] is not None:
                 self.copy_stream.wait_event(self._done[i])          # the compute work that read this buffer two steps ago
-            for k, v in tens.items():
-                dst = buf[k][:v.shape[0]]                            # ragged last step: a prefix view of the same buffer
-                dst.copy_(v, non_blocking=True)
-                out[k] = dst
+            for k in keys:
+                r = 0
+                for h in hosts:
+                    v = h[k]
+                    buf[k][r:r + v.shape[0]].copy_(v, non_blocking=True)
+                    r += int(v.shape[0])
+                out[k] = buf[k][:r]                                  # ragged last step: a prefix view of the same buffer
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         self._ready[i] = ev
@@ -66,9 +84,22 @@ class DevicePrefetcher:
             out.update(extra)
         return out
 
+    def _groups(self):
+        it = iter(self.loader)
+        while True:
+            g = []
+            for _ in range(self.collate):
+                h = next(it, None)
+                if h is None:
+                    break
+                g.append(h)
+            if not g:
+                return
+            yield g
+
     def __iter__(self):
         comp = torch.cuda.current_stream(self.device)
-        it = iter(self.loader)
+        it = self._groups()
         host = next(it, None)
         if host is None:
             return

@@ -44,6 +44,10 @@ typedef void* cfsar_stream_t;
 
 /* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
 int cfsar_version(void);
+/* ABI revision: bumped whenever an exported signature changes or is added; a binding compares it with the CFSAR_ABI_VERSION it was
+ * written against at load time (clip-fsar_amd/hip.py does) instead of calling through a stale prototype. */
+#define CFSAR_ABI_VERSION 4
+int cfsar_abi_version(void);
 const char* cfsar_last_error(void);
 
 /* ---- N2 test-time frame transform (the step BEFORE the path; reference datasets/base/ssv2_few_shot.py:614-642,
@@ -240,6 +244,31 @@ int cfsar_gemm_residual_stats(const void* A, const void* W, void* x, const float
  * A[((f heads + h) tokens + t) * 64 + c], heads = K / 64 (K tile kt of the GEMM = head kt), M a multiple of tokens. */
 int cfsar_gemm_residual_stats_heads(const void* A, const void* W, void* x, const float* bias, float* stats_partial, int M, int N,
                                     int K, int ldw, int ldx, int tokens, cfsar_stream_t stream);
+
+/* ---- Round 4: the fp16 numerics mode's forms of the two GEMMs above (VIDEO.HEAD.PRECISION = "fp16"; same reference ops).
+ * SPLIT WEIGHTS: a weight matrix is handed over as [N, 2 K] = [hi | lo], hi = fp16(w), lo = fp16(w - hi) (~22 bits per weight); the
+ * kernel walks the K tiles of the activation operand twice inside ONE fp32 accumulation chain (A hi^T + A lo^T): twice the MFMA work of
+ * the GEMM it is applied to, no second pass over the output.
+ * WIDE RESIDUAL: the GEMM result is added to the residual stream in fp32 and rounded ONCE (cfsar_gemm_residual_stats rounds the GEMM
+ * result to fp16 first and adds in fp16); with x_lo != NULL the stream carries two fp16 words per element, x = x_hi + x_lo, x_lo the
+ * rounding remainder of x_hi: the update reads and writes both, LN-folded consumers read x_hi (and its statistics) only.
+ *
+ * cfsar_gemm_lnfold_split: cfsar_gemm_lnfold with Wg2 [N, ldw >= 2 K] split, cvec = sum_k (hi + lo), fp16 output.  Statistics either
+ * finalized (rowstats [M, 4], partial = NULL) or the producer's partials (partial [M, slots, 2], rowstats = NULL, rowstats_ws [M, 4] as
+ * in cfsar_gemm_lnfold_partials).
+ * cfsar_gemm_residual_wide: x = x + A W^T + bias, A [M, lda] fp16, W [N, ldw] fp16 (wsplit = 0) or [N, ldw >= 2 K] split (wsplit = 1),
+ * x_hi [M, ldx] fp16 in place, x_lo [M, ldx] fp16 in place or NULL; stats_partial as in cfsar_gemm_residual_stats (of the new x_hi). */
+int cfsar_gemm_lnfold_split(const void* x, const void* Wg2, void* out, const float* cvec, const float* dvec, const float* rowstats,
+                            const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda, int ldw,
+                            int ldo, int act, int out_dtype, cfsar_stream_t stream);
+int cfsar_gemm_residual_wide(const void* A, const void* W, void* x_hi, void* x_lo, const float* bias, float* stats_partial, int M,
+                             int N, int K, int wsplit, int lda, int ldw, int ldx, cfsar_stream_t stream);
+/* out[i] = (float)hi[i] + (float)lo[i], i < n (the two-word stream -> fp32, e.g. in front of ln_post, few_shot.py:683). */
+int cfsar_f16_pair_to_f32(const void* hi, const void* lo, float* out, int64_t n, cfsar_stream_t stream);
+/* dst[r][0 .. row_bytes) = src[r][0 .. row_bytes), rows at byte strides src_stride / dst_stride (row_bytes % 4 == 0): the
+ * class-token rows x[:, 0, :] of few_shot.py:683 and their statistics, gathered for the last block's class-token-only tail. */
+int cfsar_copy_rows_strided(const void* src, int64_t src_stride, void* dst, int64_t dst_stride, int rows, int row_bytes,
+                            cfsar_stream_t stream);
 
 /* rowstats[m] = (mean, std, 1/std, 0) with std = sqrt(biased variance + eps) from the partials above (D = row length). */
 int cfsar_ln_stats_finalize(const float* partial, float* rowstats, int M, int slots, int D, float eps, cfsar_stream_t stream);

@@ -10,25 +10,31 @@ import clip_fsar_amd.synth as synth
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
+# trained-CLIP-like activation statistics (two ln_pre channels at |x| ~ 100, row mean away from zero): the LayerNorm-folded GEMMs'
+# cancellation regime.  The outlier channels swamp the tiny tower's class signal (top-1 at chance in the reference
+# itself): these are numerics fixtures, not accuracy fixtures.
+OUTLIER_CASES = ["t_outlier_5w1s_T8", "t197_outlier_5w1s_T2"]
 SMALL_CASES = ["t_5w1s_T8", "t_5w5s_T8_mb", "t_5w5s_q2_T8", "t_5w3s_T16_mb_d2", "t_5w2s_T4_sd", "t197_5w1s_T2",
                "t257_5w1s_T2", "rn_t_5w2s_T4"]
 
-# max |logits - reference| measured per golden case (MI355X, round 3, tools/parity_report.py -> profiles/r03_parity_table.md; the larger of
-# the mid-round and the end-of-round table: the attention and last-block changes moved single cases by up to 25 % either way).  The 16-bit
-# modes' regression bounds are 2 x these (a bound 10 x the measured value lets a 10 x regression through); fp32 and the
-# full-size fp16 cases are held to the north-star 1e-3.
+# max |logits - reference| measured per golden case (MI355X, tools/parity_report.py -> profiles/r04_parity_table.md; bf16: the larger of
+# the round-3 and round-4 tables, fp16: round 4's mode -- fp32 residual add, two-word stream, split QKV / out_proj / c_proj weights).  The
+# 16-bit modes' regression bounds are 2 x these (a bound 10 x the measured value lets a 10 x regression through); fp32 and the
+# full-size fp16 cases (cfg2 / cfg3 / cfg4) are held to the north-star 1e-3 in tests/test_gpu_e2e.py.
 MEASURED_DLOGITS = {
-    "t_5w1s_T8": {"bf16": 0.01404, "fp16": 0.003856},
-    "t_5w5s_T8_mb": {"bf16": 0.0145, "fp16": 0.003317},
-    "t_5w5s_q2_T8": {"bf16": 0.0135, "fp16": 0.0034},
-    "t_5w3s_T16_mb_d2": {"bf16": 0.02286, "fp16": 0.004746},
-    "t_5w2s_T4_sd": {"bf16": 0.004334, "fp16": 0.001298},
-    "t197_5w1s_T2": {"bf16": 0.008597, "fp16": 0.001422},
-    "t257_5w1s_T2": {"bf16": 0.003435, "fp16": 0.0005039},
+    "t_5w1s_T8": {"bf16": 0.01404, "fp16": 0.001567},
+    "t_5w5s_T8_mb": {"bf16": 0.0145, "fp16": 0.002047},
+    "t_5w5s_q2_T8": {"bf16": 0.0135, "fp16": 0.00253},
+    "t_5w3s_T16_mb_d2": {"bf16": 0.02286, "fp16": 0.003726},
+    "t_5w2s_T4_sd": {"bf16": 0.004334, "fp16": 0.0009908},
+    "t197_5w1s_T2": {"bf16": 0.008597, "fp16": 0.0007654},
+    "t257_5w1s_T2": {"bf16": 0.003436, "fp16": 0.0007384},
     "rn_t_5w2s_T4": {"bf16": 0.001986, "fp16": None},
-    "cfg2_B16_5w1s_T8": {"bf16": 0.003892, "fp16": 0.0005054},
-    "cfg3_B16_5w5s_T8_mb": {"bf16": 0.003085, "fp16": 0.001057},
-    "cfg4_L14_5w1s_T16": {"bf16": 0.005449, "fp16": 0.001774},
+    "t_outlier_5w1s_T8": {"bf16": 0.0007324, "fp16": 0.0001574},
+    "t197_outlier_5w1s_T2": {"bf16": 0.0002892, "fp16": 0.0001304},
+    "cfg2_B16_5w1s_T8": {"bf16": 0.003892, "fp16": 0.0003586},
+    "cfg3_B16_5w5s_T8_mb": {"bf16": 0.003086, "fp16": 0.0002785},
+    "cfg4_L14_5w1s_T16": {"bf16": 0.00545, "fp16": 0.0005741},
     "rn50_5w1s_T2": {"bf16": 0.008433, "fp16": None},
 }
 

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 import clip_fsar_amd.synth as synth  # noqa: E402
 import clipfsar_oracle as orc  # noqa: E402
-from _cases import GOLD, SMALL_CASES, bound, case_inputs, load_golden, maxdiff, run_engine  # noqa: E402
+from _cases import OUTLIER_CASES, GOLD, SMALL_CASES, bound, case_inputs, load_golden, maxdiff, run_engine  # noqa: E402
 from clip_fsar_amd import LOGITS_TOLERANCE, NORTH_STAR_TOLERANCE  # noqa: E402
 
 
@@ -112,6 +112,29 @@ def test_small_cases_fp16_bounded(name):
     assert torch.equal(logits[0].argmax(1), ref.argmax(1))
 
 
+@pytest.mark.parametrize("name", OUTLIER_CASES)
+def test_outlier_channel_statistics(name, monkeypatch):
+    """Reference-generated goldens whose residual stream carries two channels at |x| ~ 100 and a non-zero row mean (trained-CLIP-like
+    "massive activations"; synth.apply_outlier_channels): the regime where the LayerNorm-folded GEMM computes (x Wg - mean c) / std by
+    cancelling large terms.  fp32 mode: the north-star 1e-3.  16-bit modes: bounded at 2 x their measured deviation, and the folded
+    block must not be worse than the unfolded one (separate fp32 LayerNorm kernels) beyond rounding noise."""
+    g = load_golden(name)
+    m = g["meta"]
+    a, sd, tt, te, ep = case_inputs(m)
+    assert float(sd["backbone.ln_pre.bias"].abs().max()) > 50.0             # the fixture really carries the outlier channels
+    taps = {}
+    l32, _ = run_engine(m, a, sd, tt, te, [ep], "fp32", taps=taps)
+    assert float(taps["block0"].abs().max()) > 60.0                          # ... and so does the stream on the device
+    assert maxdiff(l32[0], g["logits"]) < NORTH_STAR_TOLERANCE
+    lh, _ = run_engine(m, a, sd, tt, te, [ep], "fp16")
+    assert maxdiff(lh[0], g["logits"]) < bound(name, "fp16")
+    lb, _ = run_engine(m, a, sd, tt, te, [ep], "bf16")
+    assert maxdiff(lb[0], g["logits"]) < bound(name, "bf16")
+    monkeypatch.setenv("CFSAR_LN_FOLD", "0")
+    lu, _ = run_engine(m, a, sd, tt, te, [ep], "bf16")
+    assert maxdiff(lb[0], g["logits"]) < 2.0 * maxdiff(lu[0], g["logits"]) + 1e-3, (maxdiff(lb[0], g["logits"]), maxdiff(lu[0], g["logits"]))
+
+
 def test_fp16_mode_refuses_what_it_cannot_represent():
     """The RN50 tower has no fp16 path; the engine says so instead of silently running bf16."""
     g = load_golden("rn_t_5w2s_T4")
@@ -152,7 +175,7 @@ def test_cfg2_full_size_fp32_and_bf16():
     lb, _ = run_engine(m, a, sd, tt, te, [ep], "bf16")
     assert maxdiff(lb[0], g["logits"]) < LOGITS_TOLERANCE["bf16"]
     lh, ch = run_engine(m, a, sd, tt, te, [ep], "fp16")
-    assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE            # the 16-bit mode that meets the north star (measured 7.6e-4)
+    assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE            # the 16-bit mode that meets the north star (measured 3.6e-4)
     assert torch.equal(lh[0].argmax(1), torch.from_numpy(g["logits"]).argmax(1))
 
 
@@ -192,7 +215,7 @@ def test_cfg3_four_episodes_per_step():
     lb, _ = run_engine(m, a, sd, tt, te, eps, "bf16")
     assert maxdiff(lb[0], g["logits"]) < LOGITS_TOLERANCE["bf16"]
     lh, _ = run_engine(m, a, sd, tt, te, eps, "fp16")
-    assert maxdiff(lh[0], g["logits"]) < bound("cfg3_B16_5w5s_T8_mb", "fp16")      # 0.9e-3 ... 1.1e-3 over builds: AT the north-star bound
+    assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE                      # round 4: 2.8e-4 measured (r3's fp16 mode: 1.06e-3)
     l1, _ = run_engine(m, a, sd, tt, te, [eps[2]], "bf16")
     assert maxdiff(lb[2], l1[0]) <= 4e-6
 
@@ -217,10 +240,10 @@ def test_cfg3_cfg4_full_size(name, tol_feat):
     assert maxdiff(lb[0], g["logits"]) < bound(name, "bf16")
     if a.get("kind") != "rn":
         lh, _ = run_engine(m, a, sd, tt, te, [ep], "fp16")
-        # cfg3 (ViT-B/16, 240 frames): 0.86e-3 ... 1.06e-3 over builds (the max over 25 logits of a rounding-noise sum: AT the north-star
-        # bound, not safely under it).  cfg4 (ViT-L/14, 24 layers): 1.5e-3 ... 1.8e-3 -- twice the layers' worth of fp16 stream / weight
-        # roundings (tools/fp16_error_budget.py).  Both bounded at 2 x measured; fp32 is the mode that meets 1e-3 everywhere.
-        assert maxdiff(lh[0], g["logits"]) < bound(name, "fp16"), name
+        # Round 4: the fp16 mode (single-rounding residual add, two-word stream, split QKV / out_proj / c_proj weights) is held to the
+        # NORTH-STAR 1e-3 on every full-size configuration: measured 3.6e-4 (cfg2), 2.8e-4 (cfg3), 5.7e-4 (cfg4) --
+        # profiles/r04_parity_table.md; round 3's fp16 mode measured 5.1e-4 / 1.06e-3 / 1.78e-3.
+        assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE, name
     print("%s: fp32 |dlogits| %.2e, bf16 |dlogits| %.3f" % (name, maxdiff(logits[0], g["logits"]), maxdiff(lb[0], g["logits"])))
 
 

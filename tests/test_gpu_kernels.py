@@ -905,3 +905,121 @@ def test_head_blocked_qkv_attention_outproj_chain(hip, F_, T, H):
     # argument checks
     with pytest.raises(RuntimeError, match="tokens"):
         hip.gemm_lnfold_heads(x, Wg, qkv_hb, c, d, rstat, 64, H, M=M)
+
+
+# ---------------------------------------------------------------------------------------------- round 4: fp16 numerics mode forms
+def _hilo(W):
+    hi = W.to(torch.float16)
+    lo = (W - hi.float()).to(torch.float16)
+    return torch.cat([hi, lo], 1).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(777, 128, 128), (1300, 192, 192), (5000, 768, 768), (30000, 768, 3072), (15760, 768, 3072),
+                                   (15760, 768, 768), (80, 768, 768), (1280, 1024, 4096)])
+@pytest.mark.parametrize("two_word", [False, True])
+@pytest.mark.parametrize("wsplit", [False, True])
+def test_gemm_residual_wide(hip, M, N, K, two_word, wsplit):
+    """cfsar_gemm_residual_wide == x + A W^T + b with the add in fp32 and ONE rounding (few_shot.py:633-635 / :639-640): the result is
+    compared with a float64 reference of the operands the kernel sees; tolerance = fp32 accumulation round-off (+ half an fp16 ulp when
+    the stream keeps one word).  Statistics: exact sums of the STORED hi words per 64-column slot."""
+    g = torch.Generator().manual_seed(21)
+    A = (torch.randn(M, K, generator=g) * 0.7).to(torch.float16).cuda()
+    W32 = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    W = _hilo(W32) if wsplit else W32.to(torch.float16).contiguous()
+    Weff = (W[:, :K].double() + W[:, K:].double()) if wsplit else W.double()
+    bias = torch.randn(N, generator=g).cuda()
+    x32 = (torch.randn(M, N, generator=g) * 3.0).cuda()
+    xh = x32.to(torch.float16)
+    xl = (x32 - xh.float()).to(torch.float16) if two_word else None
+    ref = (xh.double() + (xl.double() if two_word else 0.0)) + A.double() @ Weff.t() + bias.double()
+    S = N // 64
+    part = torch.full((M, S, 2), float("nan"), device="cuda")
+    xh2, xl2 = xh.clone(), (xl.clone() if two_word else None)
+    hip.gemm_residual_wide(A, W, xh2, xl2, bias, part, wsplit=wsplit)
+    got = xh2.double() + (xl2.double() if two_word else 0.0)
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    if two_word:
+        assert err < 3e-6 * scale, (err, scale)             # ~2^-22 of the value + fp32 accumulation
+        # lo is the rounding remainder of hi: at most half an fp16 ulp of it
+        ulp_hi = torch.pow(2.0, torch.floor(torch.log2(xh2.float().abs().clamp_min(2.0 ** -14))) - 10)
+        assert bool((xl2.float().abs() <= 0.5 * ulp_hi * 1.001).all())
+    else:
+        # one rounding: within half an fp16 ulp of the exact sum (+ fp32 accumulation round-off)
+        ulp = torch.maximum(torch.abs(ref), torch.tensor(2.0 ** -14, dtype=torch.float64, device="cuda"))
+        ulp = torch.pow(2.0, torch.floor(torch.log2(ulp)) - 10)
+        assert bool(((got - ref).abs() <= 0.5 * ulp + 2e-6 * scale).all())
+    hs = xh2.float().reshape(M, S, 64)
+    assert maxdiff(part[:, :, 0], hs.sum(2)) < 1e-4 * max(1.0, float(hs.sum(2).abs().max()))
+    assert maxdiff(part[:, :, 1], (hs * hs).sum(2)) < 1e-5 * float((hs * hs).sum(2).abs().max())
+    # without statistics: same stream
+    xh3, xl3 = xh.clone(), (xl.clone() if two_word else None)
+    hip.gemm_residual_wide(A, W, xh3, xl3, bias, None, wsplit=wsplit)
+    assert torch.equal(xh3, xh2) and (not two_word or torch.equal(xl3, xl2))
+
+
+@pytest.mark.parametrize("M,N,K,act", [(777, 384, 128, "none"), (5000, 2304, 768, "none"), (30000, 3072, 768, "gelu"), (15760, 2304, 768, "none"),
+                                       (80, 768, 768, "none"), (12850, 3072, 1024, "gelu")])
+@pytest.mark.parametrize("from_part", [False, True])
+def test_gemm_lnfold_split(hip, M, N, K, act, from_part):
+    """cfsar_gemm_lnfold_split == act(LayerNorm(x) W^T + b) with the weights carried as fp16 hi + lo: against the float64 computation on
+    the operands the kernel sees (fp16 x, hi + lo weights) the only error left is the fp16 rounding of the OUTPUT (2^-12) + fp32
+    accumulation; the same call with plain fp16 weights (cfsar_gemm_lnfold) must be measurably farther from the fp32-weight reference."""
+    if from_part and K % 64 != 0:
+        pytest.skip("partials need K = 64 slots")
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 2.0) + torch.randn(M, 1, generator=g)).to(torch.float16).cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    gamma = (1.0 + 0.3 * torch.randn(K, generator=g)).cuda()
+    beta = (0.3 * torch.randn(K, generator=g)).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Wg32 = W * gamma[None, :]
+    Wg2 = _hilo(Wg32)
+    c = Wg2.double().sum(1).float()
+    d = (W.double() @ beta.double() + bias.double()).float()
+    S = K // 64
+    xs = x.float().reshape(M, S, 64)
+    part = torch.stack([xs.sum(2), (xs * xs).sum(2)], 2).contiguous()
+    rstat = torch.empty(M, 4, device="cuda")
+    hip.ln_stats_finalize(part, rstat, M, S, K)
+    a = hip.ACT_QUICKGELU if act == "gelu" else hip.ACT_NONE
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
+    if from_part:
+        ws = torch.full((M, 4), float("nan"), device="cuda")
+        hip.gemm_lnfold_split(x, Wg2, out, c, d, partial=part, slots=S, rowstats_ws=ws, act=a)
+    else:
+        hip.gemm_lnfold_split(x, Wg2, out, c, d, rowstats=rstat, act=a)
+    xd = x.double()
+    mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    ref = ((xd - mean) / torch.sqrt(var + 1e-5)) @ Wg32.double().t() + d.double()
+    if act == "gelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+    scale = max(1.0, float(ref.abs().max()))
+    e_split = float((out.double() - ref).abs().max())
+    assert e_split < 6e-4 * scale, (e_split, scale)                # half an fp16 ulp of the largest output (+ accumulation)
+    # the rounding of the weights is what the split removes: rms error against the fp32-weight reference, split vs plain
+    out1 = torch.empty_like(out)
+    Wg1 = Wg32.to(torch.float16).contiguous()
+    hip.gemm_lnfold(x, Wg1, out1, Wg1.double().sum(1).float(), d, rstat, act=a)
+    r_split = float((out.double() - ref).pow(2).mean().sqrt())
+    r_plain = float((out1.double() - ref).pow(2).mean().sqrt())
+    assert r_split <= r_plain * 1.02, (r_split, r_plain)
+
+
+def test_copy_rows_strided_and_f16_pair(hip):
+    g = torch.Generator().manual_seed(5)
+    F_, N, D = 37, 197, 768
+    x = torch.randn(F_ * N, D, generator=g).to(torch.float16).cuda()
+    out = torch.zeros(F_, D, device="cuda", dtype=torch.float16)
+    hip.copy_rows_strided(x, N * D * 2, out, D * 2, F_, D * 2)
+    assert torch.equal(out, x.view(F_, N, D)[:, 0, :])
+    st = torch.randn(F_ * N, 4, generator=g).cuda()
+    o2 = torch.zeros(F_, 4, device="cuda")
+    hip.copy_rows_strided(st, N * 16, o2, 16, F_, 16)
+    assert torch.equal(o2, st.view(F_, N, 4)[:, 0, :])
+    v = torch.randn(F_, D, generator=g).cuda() * 7
+    hi = v.to(torch.float16)
+    lo = (v - hi.float()).to(torch.float16)
+    o3 = torch.empty(F_, D, device="cuda")
+    hip.f16_pair_to_f32(hi, lo, o3)
+    assert torch.equal(o3, hi.float() + lo.float())

@@ -371,3 +371,84 @@ def test_test_epoch_with_pinned_host_inputs_keeps_up_with_resident_inputs():
     (t_res, r_res), (t_host, r_host) = min(runs_res, key=lambda r: r[0]), min(runs_host, key=lambda r: r[0])   # best of 3 each
     assert r_host["episodes"] == B * steps and abs(r_host["top1_acc"] - r_res["top1_acc"]) < 1e-6
     assert t_res / t_host >= 0.95, "host-input harness %.1f episodes/s vs resident %.1f" % (B * steps / t_host, B * steps / t_res)
+
+
+@gpu
+@needs_gpu
+def test_per_class_tallies_survive_the_prefetchers_buffer_reuse():
+    """the prefetcher hands out prefix views of two reused device buffers; test_epoch must keep COPIES of the label tensors it
+    accumulates.  Five steps from a pinned host loader (every buffer overwritten at least once before the final concatenation) must give
+    the per-class tallies of the same steps fed as resident tensors (handed through, never overwritten)."""
+    from clip_fsar_amd.models.base.builder import build_model
+    from clip_fsar_amd.runs.test_net_few_shot import test_epoch
+    from clip_fsar_amd.utils.meters import ValMeter
+    B, steps = 2, 5
+    cfg = _cfg(B * steps, eps_per_step=B, precision="fp32")
+    model, _ = build_model(cfg)
+    a = synth.ARCHS[ARCH]
+    eps = [{k: torch.from_numpy(v) for k, v in synth.make_episode(5, 1, 1, T, a["res"], N_TEST, e, 18).items()} for e in range(B * steps)]
+    host = [{k: torch.stack([eps[j * B + i][k] for i in range(B)]).pin_memory() for k in eps[0]} for j in range(steps)]
+    resident = [{k: v.cuda() for k, v in b.items()} for b in host]
+
+    class _Steps:
+        def __init__(self, items):
+            self.items, self.dataset, self.batch_size = items, list(range(B * steps)), B
+        def __len__(self):
+            return steps
+        def __iter__(self):
+            return iter(self.items)
+    r_host = test_epoch(_Steps(host), model, ValMeter(steps, cfg), 0, cfg)
+    r_res = test_epoch(_Steps(resident), model, ValMeter(steps, cfg), 0, cfg)
+    assert r_host["episodes"] == r_res["episodes"] == B * steps
+    assert r_host["top1_per_class"] == r_res["top1_per_class"], (r_host["top1_per_class"], r_res["top1_per_class"])
+    assert len(r_host["top1_per_class"]) > 5 and sum(n for _, n in r_host["top1_per_class"].values()) == B * steps * 5
+    assert abs(r_host["top1_acc"] - r_res["top1_acc"]) < 1e-6
+
+
+@gpu
+@needs_gpu
+def test_reference_shaped_cfg_reaches_the_batched_rate():
+    """a reference-shaped config (no TEST.EPISODES_PER_STEP) over a loader that yields ONE episode per item -- what the
+    reference's own harness feeds (runs/test_net_few_shot.py:57-64) -- must deliver the batched rate: test_epoch collates k items per
+    model call.  Resident synthetic cfg2 episodes (ViT-B/16, bf16): >= 0.93 x the rate of the same harness over pre-built 16-episode steps."""
+    import time
+    from clip_fsar_amd.models.base.builder import build_model
+    from clip_fsar_amd.runs.test_net_few_shot import test_epoch
+    from clip_fsar_amd.utils.meters import ValMeter
+    from clip_fsar_amd.datasets.base.builder import auto_episodes_per_step
+    B, n = 16, 96
+    a = synth.ARCHS["ViT-B/16"]
+
+    def cfg_of(**test_extra):
+        return NS(VIDEO=NS(HEAD=NS(NAME="CNN_OTAM_CLIPFSAR", BACKBONE_NAME="ViT-B/16", PRECISION="bf16"), BACKBONE=NS(META_ARCH="Identity")),
+                  TRAIN=NS(CLASS_NAME=["c%d" % i for i in range(N_TRAIN)], WAY=5, SHOT=1, QUERY_PER_CLASS=1, NUM_TEST_TASKS=n,
+                           BATCH_SIZE=1, CHECKPOINT_FILE_PATH=""),
+                  TEST=NS(CLASS_NAME=["t%d" % i for i in range(N_TEST)], DATASET="Synthetic_few_shot", CHECKPOINT_FILE_PATH="", **test_extra),
+                  DATA=NS(NUM_INPUT_FRAMES=8, TEST_CROP_SIZE=a["res"]), MODEL=NS(NAME="BaseVideoModel", EMA=NS(ENABLE=False)),
+                  BN=NS(FREEZE=False), NUM_GPUS=1, NUM_SHARDS=1, RANDOM_SEED=18, LOG_PERIOD=100, OUTPUT_DIR="")
+    cfg_ref, cfg_b = cfg_of(), cfg_of(EPISODES_PER_STEP=B)
+    assert auto_episodes_per_step(cfg_ref, n) == B
+    model, _ = build_model(cfg_ref)
+    eps = [{k: torch.from_numpy(v).unsqueeze(0).cuda() for k, v in synth.make_episode(5, 1, 1, 8, a["res"], N_TEST, e, 18).items()} for e in range(4)]
+    steps16 = [{k: torch.cat([eps[(j + i) % 4][k] for i in range(B)]) for k in eps[0]} for j in range(2)]
+
+    class _Loader:
+        def __init__(self, items, count, bs):
+            self.items, self.count, self.batch_size, self.dataset = items, count, bs, list(range(n))
+        def __len__(self):
+            return self.count
+        def __iter__(self):
+            return (self.items[i % len(self.items)] for i in range(self.count))
+
+    def timed(loader, cfg):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = test_epoch(loader, model, ValMeter(len(loader), cfg), 0, cfg)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, res
+    timed(_Loader(steps16, n // B, B), cfg_b)
+    timed(_Loader(eps, n, 1), cfg_ref)
+    t_b, r_b = min((timed(_Loader(steps16, n // B, B), cfg_b) for _ in range(3)), key=lambda r: r[0])
+    t_1, r_1 = min((timed(_Loader(eps, n, 1), cfg_ref) for _ in range(3)), key=lambda r: r[0])
+    assert r_1["episodes"] == r_b["episodes"] == n
+    assert t_b / t_1 >= 0.93, "one-episode loader %.1f episodes/s vs 16-episode steps %.1f" % (n / t_1, n / t_b)

@@ -60,7 +60,7 @@ def test_vit_layer_taps_tiny():
 
 
 SMALL = ["t_5w1s_T8", "t_5w5s_T8_mb", "t_5w5s_q2_T8", "t_5w3s_T16_mb_d2", "t_5w2s_T4_sd",
-         "t197_5w1s_T2", "t257_5w1s_T2", "rn_t_5w2s_T4"]
+         "t197_5w1s_T2", "t257_5w1s_T2", "rn_t_5w2s_T4", "t_outlier_5w1s_T8", "t197_outlier_5w1s_T2"]
 LARGE = ["cfg2_B16_5w1s_T8", "rn50_5w1s_T2"]
 
 
@@ -69,7 +69,7 @@ def _run_case(name, atol_feat, atol_logit):
     m = json.loads(str(z["meta"]))
     a = synth.ARCHS[m["arch"]]
     depth = m.get("depth", 1)
-    sd = {k: _t(v) for k, v in synth.head_state_dict(m["arch"], seed=m["seed"], depth=depth).items()}
+    sd = {k: _t(v) for k, v in synth.head_state_dict(m["arch"], seed=m["seed"], depth=depth, outliers=m.get("outliers")).items()}
     tt = _t(synth.text_features(m["n_train"], a["embed"], "train", m["seed"]))
     te = _t(synth.text_features(m["n_test"], a["embed"], "test", m["seed"]))
     ep = synth.make_episode(way=m["way"], shot=m["shot"], query_per_class=m["q"], frames=m["T"], res=a["res"],

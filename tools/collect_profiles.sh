@@ -44,7 +44,13 @@ for k in f:
     traffic[k] = {"launches": len(fv), "fetch_bytes_per_launch": fb / len(fv), "write_bytes_per_launch": wb / max(len(wv), 1)}
     if "vit_gemm" in k or "gemm_kernel_p" in k:
         tot += fb + wb; n += len(fv)
+import hashlib, socket
+h = hashlib.sha256()
+for nm in ("common.h", "gemm.hip", "gemm_vit.h", "gemm_vit.hip"):          # bench.py::csrc_fingerprint
+    h.update(open(os.path.join("clip-fsar_amd", "csrc", nm), "rb").read())
 traffic["_all_bf16_gemm"] = {"launches": n, "hbm_bytes_per_launch": tot / max(n, 1),
+                             "csrc_sha16": h.hexdigest()[:16], "commit": os.environ.get("COMMIT", "unknown (no .git on the GPU box)"),
+                             "box": socket.gethostname(),
                              "note": "FETCH_SIZE*1024*2 (gfx950 correction) + WRITE_SIZE*1024, separate --pmc passes, bench.py --episodes-per-step $EPS"}
 json.dump(traffic, open("$OUT/gemm_traffic.json", "w"), indent=1)
 m, l = agg("$OUT/mfma/p_counter_collection.csv"), agg("$OUT/lds/p_counter_collection.csv")
