@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
          "-Rpass-analysis=kernel-resource-usage"]      # per-kernel VGPR / scratch report -> build/resource_usage.json
 # Every source is compiled WITHOUT packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  Round 2: builds of the
 # LN-folded GEMM that scaled accumulators with v_pk_mul_f32 occasionally returned stale values in lanes 48-63 of the HIGH register of one
-# packed pair (once per ~100 launches, more often with a second kernel on the chip; DESIGN.md "A fault worth recording").  Neither the
+# packed pair (once per ~100 launches, more often with a second kernel on the chip; docs/history/design_r01-r03.md "A fault worth recording").  Neither the
 # round-2 microtests nor round 3's tools/ubench/pk_trans_waw.hip (transcendental -> packed WAW / RAW under a transcendental- or
 # MFMA-heavy partner wave) reproduce it, so it is FENCED, not explained: with scalar fp32 VALU code it has not been seen (0 of 1 500
 # stress launches against 44 of 150), and the fence now covers gemm.hip, attention.hip, tail.hip, conv.hip and rowops.hip as well (the same

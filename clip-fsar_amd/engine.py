@@ -50,7 +50,7 @@ class HipViT:
         # residual stream: fp32 in the validation mode.  The bf16 mode keeps it in IEEE fp16, as CLIP's own GPU path does
         # (fp16 model, few_shot.py:605-611 casts LayerNorm to fp32 and back): out_proj / c_proj / LayerNorm are bound by the
         # stream's bytes, and on top of bf16 operands the fp16 rounding is not measurable (feature rms error 0.0064 with an
-        # fp16 stream vs 0.0067 with an fp32 one, against 0.0092 for a bf16 stream; DESIGN.md "Numerics modes").
+        # fp16 stream vs 0.0067 with an fp32 one, against 0.0092 for a bf16 stream; docs/history/design_r01-r03.md "Numerics modes").
         if stream_dtype is None:
             stream_dtype = "fp16" if precision == "fp16" else os.environ.get("CFSAR_STREAM", "fp16" if precision == "bf16" else "fp32")
         if stream_dtype not in ("fp16", "fp32") or (precision == "fp32" and stream_dtype != "fp32") or (precision == "fp16" and stream_dtype != "fp16"):

@@ -729,7 +729,7 @@ def test_vit_gemms_are_bit_stable_under_a_second_stream(hip):
     (engine.py: ClipFsarEngine.dual_frames).  Every ViT-block GEMM must give bit-identical results whether or not a second
     instance shares the chip.  Regression test for a fault seen in round 2: builds of the LN-folded QKV kernel that used packed-fp32
     VALU instructions returned stale values in lanes 48-63 of single accumulator registers -- in one build about once per 100
-    concurrent launches and never alone (DESIGN.md "A fault worth recording"; csrc/gemm_vit.hip is now compiled without those
+    concurrent launches and never alone (docs/history/design_r01-r03.md "A fault worth recording"; csrc/gemm_vit.hip is now compiled without those
     instructions; tools/stream_stress.py is the long version of this test)."""
     F_, N, D = 40, 197, 768
     M = F_ * N

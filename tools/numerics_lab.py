@@ -54,6 +54,14 @@ def make_tower(s):
     def feed(x):             # what a consumer GEMM reads of the stream (16-bit operand)
         return x.half().float()
 
+    def mm(A, W32, kind):
+        """A [F, N, K] @ W^T with the weight precision `kind`: f16 | x (exact) | m (fp16 word + the low word applied to the per-frame
+        TOKEN MEAN of the operand only: a [F, K] x [K, N_out] GEMM, the coherent part of the weight-rounding error)"""
+        if kind == "m":
+            Wh = W32.half().float()
+            return A @ Wh.t() + (A.mean(1, keepdim=True) @ (W32 - Wh).half().float().t())
+        return A @ rnd(W32, kind).t()
+
     def tower(frames, sd, arch, prefix="backbone.", chunk=40):
         outs = []
         g = lambda n: sd[prefix + n]
@@ -75,8 +83,7 @@ def make_tower(s):
                 xi = feed(x)
                 gam, bet = g(b + "ln_1.weight"), g(b + "ln_1.bias")
                 mu, var = xi.mean(-1, keepdim=True), xi.var(-1, unbiased=False, keepdim=True)
-                Wg = rnd(g(b + "attn.in_proj_weight") * gam[None, :], wqkv)
-                qkv = ((xi @ Wg.t() - mu * Wg.sum(1)) / torch.sqrt(var + 1e-5)) + (g(b + "attn.in_proj_weight") @ bet + g(b + "attn.in_proj_bias"))
+                qkv = mm((xi - mu) / torch.sqrt(var + 1e-5), g(b + "attn.in_proj_weight") * gam[None, :], wqkv) + (g(b + "attn.in_proj_weight") @ bet + g(b + "attn.in_proj_bias"))
                 qkv = rnd(qkv, kq)
                 q, k, v = qkv.split(D, -1)
                 q = q.reshape(F_, N, heads, hd).transpose(1, 2); k = k.reshape(F_, N, heads, hd).transpose(1, 2)
@@ -85,14 +92,13 @@ def make_tower(s):
                 e = torch.exp(sc - sc.max(-1, keepdim=True).values)
                 o = (rnd(e, kp) @ v) / e.sum(-1, keepdim=True)
                 o = rnd(o.transpose(1, 2).reshape(F_, N, D), ko)
-                x = store(x + delta(o @ rnd(g(b + "attn.out_proj.weight"), wout).t() + g(b + "attn.out_proj.bias")))
+                x = store(x + delta(mm(o, g(b + "attn.out_proj.weight"), wout) + g(b + "attn.out_proj.bias")))
                 xi = feed(x)
                 gam, bet = g(b + "ln_2.weight"), g(b + "ln_2.bias")
                 mu, var = xi.mean(-1, keepdim=True), xi.var(-1, unbiased=False, keepdim=True)
-                Wg = rnd(g(b + "mlp.c_fc.weight") * gam[None, :], wfc)
-                u = ((xi @ Wg.t() - mu * Wg.sum(1)) / torch.sqrt(var + 1e-5)) + (g(b + "mlp.c_fc.weight") @ bet + g(b + "mlp.c_fc.bias"))
+                u = mm((xi - mu) / torch.sqrt(var + 1e-5), g(b + "mlp.c_fc.weight") * gam[None, :], wfc) + (g(b + "mlp.c_fc.weight") @ bet + g(b + "mlp.c_fc.bias"))
                 u = rnd(orc.quick_gelu(u), ku)
-                x = store(x + delta(u @ rnd(g(b + "mlp.c_proj.weight"), wpr).t() + g(b + "mlp.c_proj.bias")))
+                x = store(x + delta(mm(u, g(b + "mlp.c_proj.weight"), wpr) + g(b + "mlp.c_proj.bias")))
             c = orc.layer_norm(x[:, 0, :], g("ln_post.weight"), g("ln_post.bias"))
             outs.append(c @ g("proj"))
         return torch.cat(outs, 0)

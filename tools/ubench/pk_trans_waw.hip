@@ -1,4 +1,4 @@
-// Microtest (gfx950), round 3 of the stale-lanes hunt (DESIGN.md "A fault worth recording"): a quarter-rate transcendental
+// Microtest (gfx950), round 3 of the stale-lanes hunt (docs/history/design_r01-r03.md "A fault worth recording"): a quarter-rate transcendental
 // (v_exp_f32 / v_rcp_f32) is still executing when a PACKED fp32 instruction writes (WAW) or reads (RAW) the same register as
 // the HIGH or LOW half of its 64-bit operand.  The failing builds of csrc/gemm_vit.hip had exactly this neighbourhood in their
 // epilogues (v_rcp_f32 v137 ... v_pk_mul_f32 v[136:137]) and lost lanes 48-63 of the HIGH register of one pair -- the lanes a
