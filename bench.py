@@ -94,9 +94,10 @@ class GemmTimer:
                 return r
             setattr(self.hip, name, timed)
         # engine.py binds `hip` as a module attribute, so patching the module functions is enough
-        # _partials: + its finalize launch at batch scale; _split / _wide: the fp16 numerics mode's forms (FLOPs stay the ALGORITHMIC
+        # _partials: + its finalize launch at batch scale; _hp / _wide: the fp16 numerics mode's forms (their tiny per-frame correction
+        # GEMMs go through hip.corr_gemm and are not counted) (FLOPs stay the ALGORITHMIC
         # 2 M N K of the reference op: a split-weight launch executes twice that on the matrix cores)
-        for name in ("gemm", "gemm_lnfold", "gemm_lnfold_partials", "gemm_residual_stats", "gemm_lnfold_split", "gemm_residual_wide"):
+        for name in ("gemm", "gemm_lnfold", "gemm_lnfold_partials", "gemm_residual_stats", "gemm_lnfold_hp", "gemm_residual_wide"):
             wrap(name)
 
     def result(self):

@@ -35,6 +35,13 @@ struct VitGemmArgs {          // kernel argument block
     // res_lo (wide residual instance, MODE 6): second fp16 word of the residual stream (the rounding remainder of the first) or NULL.
     int nka;
     void* res_lo;
+    // Per-frame low-word correction (round 4, fp16-output instances): corr [ceil(M / corr_tokens), N] fp32 is added to every row of its frame
+    // -- corr[f] = (token mean of frame f's operand rows) x W_lo^T, the part of the weights' fp16 rounding error that is common to a frame's
+    // tokens.  In the LN-folded instances it is added in normalised units (before the activation).  It rides in the tail MFMA: the k
+    // slot 3 of the hi == 0 lanes carries frame f0 = first row of the wave's tile / corr_tokens, that of the hi == 1 lanes frame f0 + 1
+    // (corr_tokens >= rows of a wave's tile: a tile spans at most two frames).  NULL = off.
+    const float* corr;
+    int corr_tokens;
 #ifdef CFSAR_DEV
     int dbg;                  // ablations: 4 = no epilogue, 8 = every workgroup reads tile (0, 0), 16 = epilogue without its global stores,
                               // 128 = start-time stagger: workgroup b sleeps ((b >> 3) & 31) * stagger_unit * 64 cycles before its first tile
@@ -64,6 +71,8 @@ struct VitGemmCall {          // host-side request
     int ka = 0;               // K of A when the weights are split ([N, 2 ka]); 0 = K
     int wide = 0;             // residual call: fp32 residual add before the ONE rounding to the fp16 stream (MODE 6), res_lo optional
     void* res_lo = nullptr;
+    const float* corr = nullptr;    // see VitGemmArgs
+    int corr_tokens = 0;
 };
 
 // 0 = launched, > 0 = error (cfsar_last_error), -2 = outside this kernel's contract (caller falls back)

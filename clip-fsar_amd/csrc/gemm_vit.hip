@@ -579,6 +579,10 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     constexpr bool kFuseStatsDecl = LNFOLD && OPATH == 2 && MIW == 3;     // see kFuseStats below
     constexpr int NTL = LNFOLD ? 10 : 2;
     float tl[NTL] = {};                  // [0..1] bias | c (hi == 0) / d (hi == 1) of column 32 ni + lr; LNFOLD: [2..5] mean | std, [6..9] 1 / std
+    // per-frame low-word correction (VitGemmArgs::corr; fp16-output LN-folded and wide-residual instances only)
+    constexpr bool CORR = std::is_same<TO, _Float16>::value && std::is_same<TI, _Float16>::value && (MODE == 2 || MODE == 6);
+    float tcq[2] = {0.f, 0.f};           // corr[f0 + hi][column 32 ni + lr]
+    int corr_bnd = 0;                    // rows of the wave's tile that belong to frame f0 (the others: f0 + 1)
     float rscale[4] = {1.f, 1.f, 1.f, 1.f};
     auto asm_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
         float v;
@@ -591,6 +595,18 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         const float* cd = LNFOLD ? (hi ? p.bias : p.cvec) : p.bias;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) tl[ni] = asm_load(cd + nb_ + ni * 32 + lr);
+        if constexpr (CORR) {
+            if (p.corr != nullptr) {                                   // kernel-uniform
+                const int r0 = m0_ + wm * WR;                          // first row of the wave's tile (wave-uniform)
+                const int f0 = r0 / p.corr_tokens;
+                corr_bnd = (f0 + 1) * p.corr_tokens - r0;
+                int f = f0 + hi;
+                const int fl = (p.M - 1) / p.corr_tokens;
+                f = f < fl ? f : fl;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) tcq[ni] = asm_load(p.corr + (size_t)f * p.N + nb_ + ni * 32 + lr);
+            }
+        }
         if constexpr (LNFOLD) {
             if (!(kFuseStatsDecl && p.part != nullptr))
 #pragma unroll
@@ -604,6 +620,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     };
     // after the wait that covers tail_loads: the values are defined from here on (the compiler must not have copied them earlier)
     auto tail_pin = [&]() __attribute__((always_inline)) {
+        if constexpr (CORR) asm volatile("" : "+v"(tcq[0]), "+v"(tcq[1]));
         if constexpr (LNFOLD)
             asm volatile("" : "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]), "+v"(tl[3]), "+v"(tl[4]), "+v"(tl[5]), "+v"(tl[6]), "+v"(tl[7]), "+v"(tl[8]), "+v"(tl[NTL - 1]));
         else
@@ -622,17 +639,25 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                 const float r1 = bv - (float)h;
                 const TI m = (TI)r1;
                 const TI l = (TI)(r1 - (float)m);
-                bw[ni] = TI8{h, m, l, 0, 0, 0, 0, 0};
+                TI q = (TI)0.f;
+                if constexpr (CORR) q = (TI)tcq[ni];                    // k slot 3: corr[f0 + hi][n] x [row in frame f0 + hi]
+                bw[ni] = TI8{h, m, l, q, 0, 0, 0, 0};
             }
             const TI one = (TI)(hi ? 0.f : 1.f);
-            const TI8 ones = TI8{one, one, one, 0, 0, 0, 0, 0};
+            TI8 ones = TI8{one, one, one, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int mi = 0; mi < MIW; ++mi)
+            for (int mi = 0; mi < MIW; ++mi) {
+                if constexpr (CORR) {
+                    const bool in0 = mi * 32 + lr < corr_bnd;
+                    const TI ind = (TI)((p.corr != nullptr && (hi ? !in0 : in0)) ? 1.f : 0.f);
+                    ones = TI8{one, one, one, ind, 0, 0, 0, 0};
+                }
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     if constexpr (std::is_same<TI, _Float16>::value) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[ni], ones, acc[mi][ni], 0, 0, 0);
                     else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[ni], ones, acc[mi][ni], 0, 0, 0);
                 }
+            }
         } else {
             // k slots 0..2 of the lanes with hi == 0 carry (c_hi, c_hi, c_lo) x (-mean_hi, -mean_lo, -mean_hi), the same slots of the
             // lanes with hi == 1 (k = 8..10) carry (d_hi, d_hi, d_lo) x (std_hi, std_lo, std_hi): every other k slot is zero.
@@ -640,13 +665,21 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const _Float16 h = (_Float16)tl[ni], l = (_Float16)(tl[ni] - (float)h);
-                cw[ni] = f16x8{h, h, l, 0, 0, 0, 0, 0};
+                _Float16 q = (_Float16)0.f;
+                if constexpr (CORR) q = (_Float16)tcq[ni];             // k slot 3: corr[f0 + hi][n] x std(row) [row in frame f0 + hi]
+                cw[ni] = f16x8{h, h, l, q, 0, 0, 0, 0};
             }
 #pragma unroll
             for (int mi = 0; mi < MIW; ++mi) {
                 const float nm = hi ? tl[2 + mi] : -tl[2 + mi];
                 const _Float16 h = (_Float16)nm, l = (_Float16)(nm - (float)h);
-                mx[mi] = f16x8{h, l, h, 0, 0, 0, 0, 0};
+                _Float16 sdh = (_Float16)0.f;
+                if constexpr (CORR) {
+                    // the accumulator is divided by std in the epilogue: the correction (normalised units) enters multiplied by it
+                    const bool in0 = mi * 32 + lr < corr_bnd;
+                    sdh = (_Float16)((p.corr != nullptr && (hi ? !in0 : in0)) ? __builtin_amdgcn_rcpf(tl[6 + mi]) : 0.f);
+                }
+                mx[mi] = f16x8{h, l, h, sdh, 0, 0, 0, 0};
                 rscale[mi] = tl[6 + mi];
             }
 #pragma unroll
@@ -1088,6 +1121,10 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
         return cfsar_fail("cfsar_gemm_residual_wide: fp16 operands, the residual stream updated in place");
     a.nka = ka / 64;
     a.res_lo = c.wide ? c.res_lo : nullptr;
+    a.corr = c.corr;
+    a.corr_tokens = c.corr_tokens;
+    if (c.corr && !(c.corr_tokens >= 128 && c.in_dtype == CFSAR_F16 && c.out_dtype == CFSAR_F16 && (lnfold || c.wide) && c.hb_tokens == 0))
+        return cfsar_fail("cfsar_gemm (vit): the per-frame correction needs >= 128 tokens per frame and an fp16-mode instance (tokens=%d)", c.corr_tokens);
     a.part = c.part; a.part_slots = c.part_slots; a.part_invD = 1.0f / (float)ka; a.part_eps = c.part_eps;
     if (c.part && !(c.opath == 2 && ka >= 512 && (c.part_slots == 12 || c.part_slots == 16) && c.part_slots * 64 == ka))
         return cfsar_fail("cfsar_gemm_lnfold_partials: needs K = 64 slots in {768, 1024} (K=%d, slots=%d)", ka, c.part_slots);
@@ -1173,7 +1210,8 @@ extern "C" void cfsar_debug_set_vit_trace(void* trace, int stagger_unit) { g_tra
 // out = act(LayerNorm(x; gamma, beta) W^T + bias) with the LayerNorm folded into the GEMM (MODE 2 above).  See the header.
 static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
                             const float* rowstats, int M, int N, int K, int lda, int ldw, int ldo, int act, int out_dtype, int hb_tokens,
-                            int hb_heads, cfsar_stream_t stream, const float* partial = nullptr, int slots = 0, float eps = 0.f, int wsplit = 0) {
+                            int hb_heads, cfsar_stream_t stream, const float* partial = nullptr, int slots = 0, float eps = 0.f, int wsplit = 0,
+                            const float* corr = nullptr, int corr_tokens = 0) {
     CFSAR_REQUIRE(out_dtype == CFSAR_BF16 || out_dtype == CFSAR_F16, "cfsar_gemm_lnfold: out_dtype must be bf16 or fp16, got %d", out_dtype);
     CFSAR_REQUIRE(x && Wg && out && cvec && dvec && (rowstats || partial), "cfsar_gemm_lnfold: null pointer");
     CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_lnfold: bad shape M=%d N=%d K=%d (K %% 64, N %% 64, K >= 128)", M, N, K);
@@ -1183,6 +1221,7 @@ static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const floa
     if (wsplit) K = 2 * K;                            // split weights [N, 2 ka] = [hi | lo]: see VitGemmArgs::nka
     VitGemmCall c;
     c.ka = ka_;
+    c.corr = corr; c.corr_tokens = corr_tokens;
     c.A = x; c.W = Wg; c.out = out; c.bias = dvec; c.res = nullptr; c.rowstats = partial ? nullptr : rowstats; c.cvec = cvec; c.stats_out = nullptr;
     c.part = partial; c.part_slots = slots; c.part_eps = eps;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = 0;
@@ -1217,7 +1256,8 @@ extern "C" int cfsar_gemm_lnfold_heads(const void* x, const void* Wg, void* out,
 // in {768, 1024} (the ViT-B / ViT-L widths); other widths keep the two-launch form.  See the header.
 static int lnfold_partials_impl(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
                                 const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda,
-                                int ldw, int ldo, int act, int out_dtype, int tokens, int heads, int wsplit, cfsar_stream_t stream) {
+                                int ldw, int ldo, int act, int out_dtype, int tokens, int heads, int wsplit, cfsar_stream_t stream,
+                                const float* corr = nullptr, int corr_tokens = 0) {
     CFSAR_REQUIRE(partial != nullptr && rowstats_ws != nullptr, "cfsar_gemm_lnfold_partials: null partials / workspace");
     CFSAR_REQUIRE(slots > 0 && slots * 64 == K, "cfsar_gemm_lnfold_partials: K=%d is not 64 x slots=%d", K, slots);
     int dbg = 0;
@@ -1232,14 +1272,14 @@ static int lnfold_partials_impl(const void* x, const void* Wg, void* out, const 
     if (!fused) {
         if (int rc = cfsar_ln_stats_finalize(partial, rowstats_ws, M, slots, K, eps, stream)) return rc;
         if (tokens > 0) return cfsar_gemm_lnfold_heads(x, Wg, out, cvec, dvec, rowstats_ws, M, N, K, lda, ldw, tokens, heads, stream);
-        return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, nullptr, 0, 0.f, wsplit);
+        return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, nullptr, 0, 0.f, wsplit, corr, corr_tokens);
     }
     if (tokens > 0) {
         CFSAR_REQUIRE(tokens >= 128 && heads > 0 && N == 192 * heads && M % tokens == 0 && act == CFSAR_ACT_NONE && out_dtype == CFSAR_BF16,
                       "cfsar_gemm_lnfold_partials: head-blocked output needs tokens >= 128, N = 192 heads, M a multiple of tokens, act NONE, bf16");
         return gemm_lnfold_impl(x, Wg, out, cvec, dvec, nullptr, M, N, K, lda, ldw, N, act, out_dtype, tokens, heads, stream, partial, slots, eps);
     }
-    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, nullptr, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, partial, slots, eps, wsplit);
+    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, nullptr, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, partial, slots, eps, wsplit, corr, corr_tokens);
 }
 
 extern "C" int cfsar_gemm_lnfold_partials(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
@@ -1248,18 +1288,20 @@ extern "C" int cfsar_gemm_lnfold_partials(const void* x, const void* Wg, void* o
     return lnfold_partials_impl(x, Wg, out, cvec, dvec, partial, slots, eps, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, tokens, heads, 0, stream);
 }
 
-// The fp16 numerics mode's LN-folded GEMM with SPLIT weights: Wg2 [N, 2 K] = [fp16(W gamma) | fp16(W gamma - fp16(W gamma))], the kernel walks
-// x's K tiles twice in one fp32 accumulation chain (see the header).  Statistics: rowstats [M, 4] (partial == NULL) or the producer's
+// The fp16 numerics mode's LN-folded GEMM: wsplit = 1: SPLIT weights Wg [N, 2 K] = [fp16(W gamma) | fp16(W gamma - fp16(W gamma))], the kernel
+// walks x's K tiles twice in one fp32 accumulation chain; corr != NULL: per-frame low-word correction [ceil(M / corr_tokens), N] (see the header).  Statistics: rowstats [M, 4] (partial == NULL) or the producer's
 // partials [M, slots, 2] finalized here (rowstats_ws [M, 4] is then the workspace of the two-launch form).
-extern "C" int cfsar_gemm_lnfold_split(const void* x, const void* Wg2, void* out, const float* cvec, const float* dvec, const float* rowstats,
-                                       const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda, int ldw,
-                                       int ldo, int act, int out_dtype, cfsar_stream_t stream) {
-    CFSAR_REQUIRE(out_dtype == CFSAR_F16, "cfsar_gemm_lnfold_split: fp16 output only (the fp16 numerics mode)");
+extern "C" int cfsar_gemm_lnfold_hp(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec, const float* rowstats,
+                                    const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda, int ldw,
+                                    int ldo, int act, int out_dtype, int wsplit, const float* corr, int corr_tokens, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(out_dtype == CFSAR_F16, "cfsar_gemm_lnfold_hp: fp16 output only (the fp16 numerics mode)");
+    CFSAR_REQUIRE(corr == nullptr || corr_tokens >= 128, "cfsar_gemm_lnfold_hp: the per-frame correction needs >= 128 tokens per frame");
     if (partial != nullptr) {
-        CFSAR_REQUIRE(slots > 0 && slots * 64 == K, "cfsar_gemm_lnfold_split: K=%d is not 64 x slots=%d", K, slots);
-        return lnfold_partials_impl(x, Wg2, out, cvec, dvec, partial, slots, eps, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, 1, stream);
+        CFSAR_REQUIRE(slots > 0 && slots * 64 == K, "cfsar_gemm_lnfold_hp: K=%d is not 64 x slots=%d", K, slots);
+        return lnfold_partials_impl(x, Wg, out, cvec, dvec, partial, slots, eps, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, wsplit, stream,
+                                    corr, corr_tokens);
     }
-    return gemm_lnfold_impl(x, Wg2, out, cvec, dvec, rowstats, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, nullptr, 0, 0.f, 1);
+    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, nullptr, 0, 0.f, wsplit, corr, corr_tokens);
 }
 
 // x = x + A W^T + bias (fp16 residual stream, in place) and, if stats_partial != NULL, the per-row partial LayerNorm
@@ -1292,7 +1334,9 @@ extern "C" int cfsar_gemm_residual_stats(const void* A, const void* W, void* x, 
 // The fp16 numerics mode's residual GEMM: x = x + A W^T + bias with the add in fp32 and ONE rounding (MODE 6); x_lo != NULL: two-word
 // stream (x_hi + x_lo); wsplit: W is [N, 2 K] = [hi | lo].  See the header.
 extern "C" int cfsar_gemm_residual_wide(const void* A, const void* W, void* x_hi, void* x_lo, const float* bias, float* stats_partial, int M,
-                                        int N, int K, int wsplit, int lda, int ldw, int ldx, cfsar_stream_t stream) {
+                                        int N, int K, int wsplit, int lda, int ldw, int ldx, const float* corr, int corr_tokens,
+                                        cfsar_stream_t stream) {
+    CFSAR_REQUIRE(corr == nullptr || corr_tokens >= 128, "cfsar_gemm_residual_wide: the per-frame correction needs >= 128 tokens per frame");
     CFSAR_REQUIRE(A && W && x_hi && bias, "cfsar_gemm_residual_wide: null pointer");
     CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_residual_wide: bad shape M=%d N=%d K=%d", M, N, K);
     const int Kt = wsplit ? 2 * K : K;
@@ -1304,7 +1348,7 @@ extern "C" int cfsar_gemm_residual_wide(const void* A, const void* W, void* x_hi
     c.out_dtype = CFSAR_F16; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
     c.opath = vit_policy_opath(Kt); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;
     c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = 0;
-    c.ka = K; c.wide = 1; c.res_lo = x_lo;
+    c.ka = K; c.wide = 1; c.res_lo = x_lo; c.corr = corr; c.corr_tokens = corr_tokens;
 #ifdef CFSAR_DEV
     c.dbg = g_force_dbg & ((1 << 17) | (1 << 18));
 #endif

@@ -436,6 +436,51 @@ __global__ __launch_bounds__(256) void copy_rows_strided_kernel(const char* __re
 }
 }  // namespace
 
+namespace {
+// out[f][k] = (1 / tokens) sum_t w_t (A[f tokens + t][k] - mu_t), (mu_t, w_t) = (mean, 1 / std) of row t from rowstats [M, 4], or
+// (0, 1) without them: the per-frame TOKEN MEAN of a GEMM's activation operand (of LayerNorm(x) without materialising it, for the
+// LN-folded GEMMs).  One workgroup per (256-column chunk, frame): 32 lanes x 16 bytes across, 8 row groups down, fixed summation order.
+__global__ __launch_bounds__(256) void frame_col_means_kernel(const _Float16* __restrict__ A, long long lda, const float* __restrict__ rowstats,
+                                                              __bf16* __restrict__ out, int tokens, int K) {
+    __shared__ float red[8][256];
+    const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int col = blockIdx.x * 256 + cg * 8;
+    const long long row0 = (long long)blockIdx.y * tokens;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (col < K) {
+        for (int t = rg; t < tokens; t += 8) {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            const h8 a = *reinterpret_cast<const h8*>(A + (row0 + t) * lda + col);
+            float mu = 0.f, w = 1.f;
+            if (rowstats) {
+                mu = rowstats[(row0 + t) * 4];
+                w = rowstats[(row0 + t) * 4 + 2];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w * ((float)a[j] - mu);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rg][cg * 8 + j] = acc[j];
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (blockIdx.x * 256 + c < K) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += red[r][c];
+        out[(long long)blockIdx.y * K + blockIdx.x * 256 + c] = (__bf16)(s / (float)tokens);
+    }
+}
+}  // namespace
+
+extern "C" int cfsar_frame_col_means(const void* A, int lda, const float* rowstats, void* out, int frames, int tokens, int K,
+                                     cfsar_stream_t stream) {
+    CFSAR_REQUIRE(A && out && frames > 0 && tokens > 0 && K > 0 && K % 8 == 0 && lda >= K && lda % 8 == 0, "cfsar_frame_col_means: bad argument");
+    hipLaunchKernelGGL(frame_col_means_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)frames), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const _Float16*>(A), (long long)lda, rowstats, static_cast<__bf16*>(out), tokens, K);
+    return cfsar_check_launch("cfsar_frame_col_means");
+}
+
 extern "C" int cfsar_f16_pair_to_f32(const void* hi, const void* lo, float* out, int64_t n, cfsar_stream_t stream) {
     CFSAR_REQUIRE(hi && lo && out && n > 0, "cfsar_f16_pair_to_f32: bad argument");
     hipLaunchKernelGGL(f16_pair_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),

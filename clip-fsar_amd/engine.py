@@ -24,8 +24,13 @@ import torch
 from . import hip
 
 
-# fp16 numerics mode: the GEMMs whose weights are carried as hi + lo pairs by default (see HipViT.__init__ and profiles/r04_parity_table.md)
-FP16_SPLIT_DEFAULT = "qkv,out,pr"
+# fp16 numerics mode (HipViT.__init__, profiles/r04_parity_table.md): the GEMMs whose weights' second fp16 word is applied to the per-frame
+# token mean of the operand (MCORR: one pass over the operand + a 1 / tokens-size GEMM) or to the whole operand (SPLIT: a second MFMA pass).
+# 16 fresh episodes per configuration against the fp32 mode, rms / max |dlogits| on cfg2, cfg3, cfg4:  mcorr all 2.4e-4 / 2.2e-4 / 2.5e-4 and
+# 7.4e-4 / 6.7e-4 / 6.5e-4 at 275 episodes/s;  split qkv,out,pr 2.5 / 2.1 / 2.9 and 8.2 / 6.3 / 8.2 at 217;  split all 2.2 / 1.7 / 1.9 and
+# 6.7 / 5.5 / 5.3 at 194;  neither 3.3 / 2.8 / 5.0 and 9.0 / 9.3 / 16.0 at 308.
+FP16_SPLIT_DEFAULT = ""
+FP16_MCORR_DEFAULT = "qkv,out,fc,pr"
 
 
 def _round_up(x, m):
@@ -35,7 +40,7 @@ def _round_up(x, m):
 class HipViT:
     """CLIP VisionTransformer.forward (reference few_shot.py:671-688) on the HIP kernels."""
 
-    def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda", stream_dtype=None, fp16_split=None):
+    def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda", stream_dtype=None, fp16_split=None, fp16_mcorr=None):
         if precision not in ("bf16", "fp16", "fp32"):
             raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
         self.arch = dict(arch)
@@ -116,8 +121,20 @@ class HipViT:
         self.two_word = self.wide and os.environ.get("CFSAR_FP16_LO", "1") != "0"
         sp = os.environ.get("CFSAR_FP16_SPLIT", FP16_SPLIT_DEFAULT if fp16_split is None else fp16_split) if precision == "fp16" else ""
         self.split = set(t for t in sp.split(",") if t)
-        if not self.split <= {"qkv", "out", "fc", "pr"}:
-            raise ValueError("CFSAR_FP16_SPLIT: names out of qkv,out,fc,pr expected, got %r" % sp)
+        #   mcorr  -- which GEMMs get the PER-FRAME LOW-WORD CORRECTION instead: the second weight word multiplies only the per-frame
+        #             token mean of the GEMM's operand ([F, K] x W_lo^T, a 1 / tokens-size GEMM) and the [F, N] result is added to every row
+        #             of its frame inside the main GEMM's tail MFMA.  It removes the part of the weight-rounding error that is common to a
+        #             frame's tokens -- most of what the split buys (tools/numerics_lab.py, scheme "m") -- for one pass over the operand
+        #             instead of a second MFMA pass.  Needs >= 128 tokens per frame (tiny test towers fall back to the split); the
+        #             last block's class-token rows (one row per frame) use the split form.
+        mc = os.environ.get("CFSAR_FP16_MCORR", FP16_MCORR_DEFAULT if fp16_mcorr is None else fp16_mcorr) if precision == "fp16" else ""
+        self.mcorr = set(t for t in mc.split(",") if t)
+        if not (self.split | self.mcorr) <= {"qkv", "out", "fc", "pr"}:
+            raise ValueError("CFSAR_FP16_SPLIT / CFSAR_FP16_MCORR: names out of qkv,out,fc,pr expected, got %r / %r" % (sp, mc))
+        self.mcorr -= self.split                                  # a split GEMM needs no correction
+        if self.mcorr and (self.ntok < 128 or not self.wide):
+            self.split |= self.mcorr                              # frames too short for the kernel's two-frames-per-tile form
+            self.mcorr = set()
         if self.split and not self.wide and (self.split & {"out", "pr"}):
             raise ValueError("split out_proj / c_proj weights need the wide residual GEMM (CFSAR_FP16_WIDE=1)")
 
@@ -127,12 +144,21 @@ class HipViT:
             lo = (W32 - hi.float()).to(torch.float16)
             return torch.cat([hi, lo], 1).contiguous()
 
-        for i, blk in enumerate(self.blocks if self.split else []):
+        def lo_word(W32):
+            """fp32 [N, K] -> bf16 [N, K]: the remainder of the fp16 rounding (bf16: fp32's exponent range, 8 bits are plenty for a term
+            2^-12 of the product)"""
+            return (W32 - W32.to(torch.float16).float()).to(torch.bfloat16).contiguous()
+
+        last = len(self.blocks) - 1
+        for i, blk in enumerate(self.blocks if (self.split or self.mcorr) else []):
             b = "transformer.resblocks.%d." % i
-            if "out" in self.split:
-                blk["w_out"] = hilo(g(b + "attn.out_proj.weight"))
-            if "pr" in self.split:
-                blk["w_pr"] = hilo(g(b + "mlp.c_proj.weight"))
+            for key, name in (("out", "attn.out_proj.weight"), ("pr", "mlp.c_proj.weight")):
+                if key in self.split:
+                    blk["w_" + key] = hilo(g(b + name))
+                elif key in self.mcorr:
+                    blk["wlo_" + key] = lo_word(g(b + name))
+                    if i == last:
+                        blk["ws_" + key] = hilo(g(b + name))      # class-token rows of the last block: split form
         if self.fold:
             for i, blk in enumerate(self.blocks):
                 b = "transformer.resblocks.%d." % i
@@ -144,6 +170,12 @@ class HipViT:
                         Wg = hilo(W * gamma[None, :])
                     else:
                         Wg = (W * gamma[None, :]).to(torch.float16).contiguous()
+                    if tag in self.mcorr:
+                        blk["wlo_" + tag] = lo_word(W * gamma[None, :])
+                        if i == len(self.blocks) - 1:                                   # class-token rows of the last block: split form
+                            Ws = hilo(W * gamma[None, :]) if tag == "fc" else hilo((W * gamma[None, :])[:D])
+                            blk["wgs_" + tag] = Ws
+                            blk["cs_" + tag] = Ws.double().sum(1).float().contiguous()
                     blk["wg_" + tag] = Wg
                     blk["c_" + tag] = Wg.double().sum(1).float().contiguous()          # of the ROUNDED folded weights (hi + lo when split)
                     blk["d_" + tag] = (W.double() @ beta.double() + g(b + bname).double()).float().contiguous()
@@ -177,6 +209,8 @@ class HipViT:
         self.prune_last = os.environ.get("CFSAR_FULL_LAST_BLOCK", "0") != "1"
         # LN statistics finalized inside the consuming GEMM (ViT-B / ViT-L widths; CFSAR_FUSE_STATS=0: the separate finalize launches)
         self.fuse_stats = bool(self.fold) and hip.lnfold_partials_ok(self.D, self.D // 64) and os.environ.get("CFSAR_FUSE_STATS", "1") != "0"
+        if self.mcorr & {"qkv", "fc"}:
+            self.fuse_stats = False          # the token means of LayerNorm(x) need the finalized statistics in front of the GEMM
         # band-chunked layer schedule (developer switch; measured in profiles/r04_chunked_schedule.md): CFSAR_CHUNK_FRAMES=k,
         # CFSAR_CHUNK_MODE = block | pairs | mlp
         self.chunk_frames = int(os.environ.get("CFSAR_CHUNK_FRAMES", "0"))
@@ -203,6 +237,9 @@ class HipViT:
                 ws["part"] = torch.empty(M, D // 64, 2, device=dev, dtype=torch.float32)    # partial row statistics
                 ws["rstat"] = torch.empty(M, 4, device=dev, dtype=torch.float32)            # (mean, std, 1/std, -)
             # class-token rows of the last block (prune_last): [F, .]
+            if self.mcorr:
+                ws["mA"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.bfloat16)         # per-frame token means of a GEMM operand
+                ws["corr"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.float32)        # ... x W_lo^T
             if self.two_word:
                 ws["xlo"] = torch.empty(M, D, device=dev, dtype=torch.float16)                # second word of the stream
                 ws["xlc"] = torch.empty(F_, D, device=dev, dtype=torch.float16)
@@ -269,10 +306,25 @@ class HipViT:
             in_part = False                                                           # statistics of x: finalized in rstat / raw in part
             split = self.split
 
-            def fold(xx, wg, out, c, d, pt, rs, act=hip.ACT_NONE, rows=M, from_part=False, heads=False, sp=False):
-                if sp:                                                                # split weights [N, 2K] (fp16 numerics mode)
-                    hip.gemm_lnfold_split(xx, wg, out, c, d, rowstats=None if from_part else rs, partial=pt if from_part else None,
-                                          slots=S if from_part else 0, rowstats_ws=rs, act=act, M=rows)
+            mcorr = self.mcorr
+
+            def mc(blk, key, A, rs=None, wrows=None):
+                """per-frame low-word correction of GEMM `key` for the full-size launch: token means of the operand x W_lo^T -> [F, N]"""
+                if key not in mcorr:
+                    return None
+                wlo = blk["wlo_" + key] if wrows is None else blk["wlo_" + key][wrows]
+                Kd, Nn = A.shape[1], wlo.shape[0]
+                mA = ws["mA"][:F_ * Kd].view(F_, Kd)
+                hip.frame_col_means(A, mA, F_, N, rowstats=rs)
+                cr = ws["corr"][:F_ * Nn].view(F_, Nn)
+                hip.corr_gemm(mA, wlo, cr)
+                return cr
+
+            def fold(xx, wg, out, c, d, pt, rs, act=hip.ACT_NONE, rows=M, from_part=False, heads=False, sp=False, corr=None):
+                if sp or corr is not None:                                            # fp16 numerics mode: split weights [N, 2K] / correction
+                    hip.gemm_lnfold_hp(xx, wg, out, c, d, rowstats=None if from_part else rs, partial=pt if from_part else None,
+                                       slots=S if from_part else 0, rowstats_ws=rs, act=act, M=rows, wsplit=sp, corr=corr,
+                                       corr_tokens=N if corr is not None else 0)
                 elif from_part:
                     hip.gemm_lnfold_partials(xx, wg, out, c, d, pt, S, rs, act=act, M=rows, tokens=N if heads else 0, heads=self.H if heads else 0)
                 elif heads:
@@ -280,10 +332,13 @@ class HipViT:
                 else:
                     hip.gemm_lnfold(xx, wg, out, c, d, rs, act=act, M=rows)
 
-            def resid(A, blk, key, xx, xl, pt, rows):
-                """xx (+ xl) += A W^T + bias, partial LayerNorm statistics of the new stream -> pt"""
-                if self.wide:
-                    hip.gemm_residual_wide(A, blk["w_" + key], xx, xl, blk["b_" + key], pt, M=rows, wsplit=key in split)
+            def resid(A, blk, key, xx, xl, pt, rows, corr=None, cls=False):
+                """xx (+ xl) += A W^T + bias, partial LayerNorm statistics of the new stream -> pt (cls: the last block's class-token rows)"""
+                if self.wide and cls and key in mcorr:
+                    hip.gemm_residual_wide(A, blk["ws_" + key], xx, xl, blk["b_" + key], pt, M=rows, wsplit=True)
+                elif self.wide:
+                    hip.gemm_residual_wide(A, blk["w_" + key], xx, xl, blk["b_" + key], pt, M=rows, wsplit=key in split, corr=corr,
+                                           corr_tokens=N if corr is not None else 0)
                 else:
                     hip.gemm_residual_stats(A, blk["w_" + key], xx, blk["b_" + key], pt, M=rows)
 
@@ -294,7 +349,8 @@ class HipViT:
                     xlc = ws["xlc"][:F_] if xlo is not None else None
                     # ... and of q only the class-token rows: K | V for all M rows (N = 2 D: two thirds of the QKV GEMM), q for F rows
                     kv = qkv.view(-1)[:M * 2 * D].view(M, 2 * D)
-                    fold(x, b["wg_qkv"][D:], kv, b["c_qkv"][D:], b["d_qkv"][D:], part, rstat, from_part=in_part, sp="qkv" in split)
+                    fold(x, b["wg_qkv"][D:], kv, b["c_qkv"][D:], b["d_qkv"][D:], part, rstat, from_part=in_part, sp="qkv" in split,
+                         corr=mc(b, "qkv", x, rstat, wrows=slice(D, 3 * D)))
                     class_rows(x, xc, D, es)                                          # class-token rows of the stream
                     if xlo is not None:
                         class_rows(xlo, xlc, D, 2)
@@ -303,13 +359,19 @@ class HipViT:
                     else:
                         class_rows(rstat, rstatc, 4, 4)
                     qc = ws["hc"][:F_]
-                    fold(xc, b["wg_qkv"][:D], qc, b["c_qkv"][:D], b["d_qkv"][:D], partc, rstatc, rows=F_, from_part=in_part, sp="qkv" in split)
+                    if "qkv" in mcorr:
+                        fold(xc, b["wgs_qkv"], qc, b["cs_qkv"], b["d_qkv"][:D], partc, rstatc, rows=F_, from_part=in_part, sp=True)
+                    else:
+                        fold(xc, b["wg_qkv"][:D], qc, b["c_qkv"][:D], b["d_qkv"][:D], partc, rstatc, rows=F_, from_part=in_part, sp="qkv" in split)
                     hip.vit_attention_cls(None, oc, F_, N, D, self.H, q=qc, kv=kv)
-                    resid(oc, b, "out", xc, xlc, partc, F_)
+                    resid(oc, b, "out", xc, xlc, partc, F_, cls=True)
                     if not fuse:
                         hip.ln_stats_finalize(partc, rstatc, F_, S, D)
-                    fold(xc, b["wg_fc"], uc, b["c_fc"], b["d_fc"], partc, rstatc, act=hip.ACT_QUICKGELU, rows=F_, from_part=fuse, sp="fc" in split)
-                    resid(uc, b, "pr", xc, xlc, None, F_)
+                    if "fc" in mcorr:
+                        fold(xc, b["wgs_fc"], uc, b["cs_fc"], b["d_fc"], partc, rstatc, act=hip.ACT_QUICKGELU, rows=F_, from_part=fuse, sp=True)
+                    else:
+                        fold(xc, b["wg_fc"], uc, b["c_fc"], b["d_fc"], partc, rstatc, act=hip.ACT_QUICKGELU, rows=F_, from_part=fuse, sp="fc" in split)
+                    resid(uc, b, "pr", xc, xlc, None, F_, cls=True)
                     xc_final = xc
                     break
                 if self.head_blocked:
@@ -356,16 +418,18 @@ class HipViT:
                         taps["block%d" % i] = x[:M].clone()
                     continue
                 else:
-                    fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, sp="qkv" in split)
+                    fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, sp="qkv" in split,
+                         corr=mc(b, "qkv", x, rstat))
                     hip.vit_attention(qkv, o, F_, N, D, self.H)
-                    resid(o, b, "out", x, xlo, part, M)                               # x += out_proj(attn); stats of the new x
+                    resid(o, b, "out", x, xlo, part, M, corr=mc(b, "out", o))         # x += out_proj(attn); stats of the new x
                 if not fuse:
                     hip.ln_stats_finalize(part, rstat, M, S, D)
-                fold(x, b["wg_fc"], u, b["c_fc"], b["d_fc"], part, rstat, act=hip.ACT_QUICKGELU, from_part=fuse, sp="fc" in split)
+                fold(x, b["wg_fc"], u, b["c_fc"], b["d_fc"], part, rstat, act=hip.ACT_QUICKGELU, from_part=fuse, sp="fc" in split,
+                     corr=mc(b, "fc", x, rstat))
                 if self.head_blocked:
                     hip.gemm_residual_stats(u, b["w_pr"], x, b["b_pr"], part, M=M)
                 else:
-                    resid(u, b, "pr", x, xlo, part, M)                                # x += c_proj(gelu(c_fc))
+                    resid(u, b, "pr", x, xlo, part, M, corr=mc(b, "pr", u))           # x += c_proj(gelu(c_fc))
                 if fuse:
                     in_part = True
                 else:
@@ -656,13 +720,14 @@ class ClipFsarEngine:
     """Full episodic forward A0 -> A15 for a batch of B episodes with identical (way, shot, query, T)."""
 
     def __init__(self, arch: dict, head_sd: dict, text_train, text_test, depth: int = 1, precision: str = "bf16",
-                 device="cuda", max_frames: int = 1280, fp16_split=None):
+                 device="cuda", max_frames: int = 1280, fp16_split=None, fp16_mcorr=None):
         self.dev = torch.device(device)
         self.arch = dict(arch)
         if arch.get("kind") == "rn":
             self.vit = HipResNet(arch, head_sd, prefix="backbone.", precision=precision, device=device)
         else:
-            self.vit = HipViT(arch, head_sd, prefix="backbone.", precision=precision, device=device, fp16_split=fp16_split)
+            self.vit = HipViT(arch, head_sd, prefix="backbone.", precision=precision, device=device, fp16_split=fp16_split,
+                              fp16_mcorr=fp16_mcorr)
         self.temporal = HipTemporalHead(head_sd, arch["embed"], depth=depth, device=device)
         f32 = lambda t: (t if isinstance(t, torch.Tensor) else torch.from_numpy(t)).detach().to(
             device=self.dev, dtype=torch.float32).contiguous()

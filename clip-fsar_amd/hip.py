@@ -38,8 +38,9 @@ SIGNATURES = {
     "cfsar_gemm_lnfold_heads": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
     "cfsar_gemm_lnfold_partials": [_c_p] * 6 + [_c_int, ctypes.c_float, _c_p] + [_c_int] * 10 + [_c_p],
     "cfsar_gemm_residual_stats_heads": [_c_p] * 5 + [_c_int] * 6 + [_c_p],
-    "cfsar_gemm_lnfold_split": [_c_p] * 7 + [_c_int, ctypes.c_float, _c_p] + [_c_int] * 8 + [_c_p],
-    "cfsar_gemm_residual_wide": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
+    "cfsar_gemm_lnfold_hp": [_c_p] * 7 + [_c_int, ctypes.c_float, _c_p] + [_c_int] * 9 + [_c_p, _c_int, _c_p],
+    "cfsar_gemm_residual_wide": [_c_p] * 6 + [_c_int] * 7 + [_c_p, _c_int, _c_p],
+    "cfsar_frame_col_means": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_f16_pair_to_f32": [_c_p, _c_p, _c_p, _c_i64, _c_p],
     "cfsar_copy_rows_strided": [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_int, _c_p],
     "cfsar_abi_version": [],
@@ -208,6 +209,15 @@ def gemm(A, W, out, bias=None, residual=None, act=ACT_NONE, M=None, N=None, K=No
                             row_group, row_gap, row_off, res_mod, res_off, _stream()), "cfsar_gemm")
 
 
+_gemm_unwrapped = gemm
+
+
+def corr_gemm(meanA, w_lo, out):
+    """out [frames, N] fp32 = meanA [frames, K] bf16 @ w_lo [N, K]^T bf16: the per-frame low-word correction's small GEMM (cfsar_gemm).  A name
+    of its own so that bench.py's per-launch timer, which wraps `gemm`, does not count it among the path's algorithmic GEMM launches."""
+    _gemm_unwrapped(meanA, w_lo, out)
+
+
 def gemm_lnfold(x, Wg, out, cvec, dvec, rowstats, act=ACT_NONE, M=None):
     """out = act(LayerNorm(x) @ W.T + bias) with the LayerNorm folded into the GEMM (include/clipfsar_hip.h: cfsar_gemm_lnfold).
     out is bf16 (throughput mode) or fp16 (fp16 numerics mode)."""
@@ -251,29 +261,44 @@ def gemm_residual_stats(A, W, x, bias, stats_partial=None, M=None):
            "cfsar_gemm_residual_stats")
 
 
-def gemm_lnfold_split(x, Wg2, out, cvec, dvec, rowstats=None, partial=None, slots=0, rowstats_ws=None, act=ACT_NONE, M=None, eps=1e-5):
-    """gemm_lnfold / gemm_lnfold_partials with split weights Wg2 [N, 2K] = [hi | lo] (fp16 numerics mode; cfsar_gemm_lnfold_split)."""
+def gemm_lnfold_hp(x, Wg, out, cvec, dvec, rowstats=None, partial=None, slots=0, rowstats_ws=None, act=ACT_NONE, M=None, eps=1e-5,
+                   wsplit=False, corr=None, corr_tokens=0):
+    """fp16 numerics mode's LN-folded GEMM (cfsar_gemm_lnfold_hp): split weights Wg [N, 2K] = [hi | lo] (wsplit) and / or the per-frame
+    low-word correction corr [frames, N] fp32."""
     M = x.shape[0] if M is None else M
     K = x.shape[1]
-    if Wg2.shape[1] != 2 * K or out.dtype != torch.float16:
-        raise RuntimeError("gemm_lnfold_split: Wg2 must be [N, 2K] and out fp16")
-    _check(lib().cfsar_gemm_lnfold_split(_dev(x, torch.float16, "x"), _dev(Wg2, torch.float16, "Wg2"), _dev(out, None, "out"),
-                                         _dev(cvec, torch.float32, "cvec"), _dev(dvec, torch.float32, "dvec"),
-                                         _opt(rowstats, torch.float32, "rowstats"), _opt(partial, torch.float32, "partial"), slots, eps,
-                                         _opt(rowstats_ws, torch.float32, "rowstats_ws"), M, Wg2.shape[0], K, x.shape[1], Wg2.shape[1],
-                                         out.shape[-1], act, _code(out.dtype), _stream()), "cfsar_gemm_lnfold_split")
+    if Wg.shape[1] != (2 * K if wsplit else K) or out.dtype != torch.float16:
+        raise RuntimeError("gemm_lnfold_hp: Wg must be [N, %d] and out fp16" % (2 * K if wsplit else K))
+    if corr is not None and corr.shape[1] != Wg.shape[0]:
+        raise RuntimeError("gemm_lnfold_hp: corr must be [frames, N]")
+    _check(lib().cfsar_gemm_lnfold_hp(_dev(x, torch.float16, "x"), _dev(Wg, torch.float16, "Wg"), _dev(out, None, "out"),
+                                      _dev(cvec, torch.float32, "cvec"), _dev(dvec, torch.float32, "dvec"),
+                                      _opt(rowstats, torch.float32, "rowstats"), _opt(partial, torch.float32, "partial"), slots, eps,
+                                      _opt(rowstats_ws, torch.float32, "rowstats_ws"), M, Wg.shape[0], K, x.shape[1], Wg.shape[1],
+                                      out.shape[-1], act, _code(out.dtype), int(bool(wsplit)), _opt(corr, torch.float32, "corr"),
+                                      int(corr_tokens), _stream()), "cfsar_gemm_lnfold_hp")
 
 
-def gemm_residual_wide(A, W, x, x_lo, bias, stats_partial=None, M=None, wsplit=False):
-    """x (+ x_lo) += A @ W.T + bias with the add in fp32 and ONE rounding; W [N, K] or split [N, 2K] (cfsar_gemm_residual_wide)."""
+def gemm_residual_wide(A, W, x, x_lo, bias, stats_partial=None, M=None, wsplit=False, corr=None, corr_tokens=0):
+    """x (+ x_lo) += A @ W.T + bias with the add in fp32 and ONE rounding; W [N, K] or split [N, 2K]; corr: per-frame low-word
+    correction [frames, N] fp32 (cfsar_gemm_residual_wide)."""
     M = A.shape[0] if M is None else M
     K = A.shape[1]
     if W.shape[1] != (2 * K if wsplit else K):
         raise RuntimeError("gemm_residual_wide: W has %d columns, expected %d" % (W.shape[1], 2 * K if wsplit else K))
+    if corr is not None and corr.shape[1] != W.shape[0]:
+        raise RuntimeError("gemm_residual_wide: corr must be [frames, N]")
     _check(lib().cfsar_gemm_residual_wide(_dev(A, torch.float16, "A"), _dev(W, torch.float16, "W"), _dev(x, torch.float16, "x"),
                                           _opt(x_lo, torch.float16, "x_lo"), _dev(bias, torch.float32, "bias"),
                                           _opt(stats_partial, torch.float32, "stats_partial"), M, W.shape[0], K, int(bool(wsplit)),
-                                          A.shape[1], W.shape[1], x.shape[1], _stream()), "cfsar_gemm_residual_wide")
+                                          A.shape[1], W.shape[1], x.shape[1], _opt(corr, torch.float32, "corr"), int(corr_tokens),
+                                          _stream()), "cfsar_gemm_residual_wide")
+
+
+def frame_col_means(A, out, frames, tokens, rowstats=None):
+    """out [frames, K] bf16 = per-frame token mean of A's rows (normalised by the rows' (mean, 1/std) when rowstats is given)."""
+    _check(lib().cfsar_frame_col_means(_dev(A, torch.float16, "A"), A.shape[1], _opt(rowstats, torch.float32, "rowstats"),
+                                       _dev(out, torch.bfloat16, "out"), frames, tokens, out.shape[1], _stream()), "cfsar_frame_col_means")
 
 
 def f16_pair_to_f32(hi, lo, out):

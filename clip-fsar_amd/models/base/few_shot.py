@@ -186,7 +186,8 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
             self._engine = ClipFsarEngine(self.arch, sd, self.text_features_train, self.text_features_test,
                                           depth=self.depth, precision=self.precision, device=device,
                                           max_frames=int(getattr(self.args.VIDEO.HEAD, "MAX_FRAMES_PER_LAUNCH", 1280)),
-                                          fp16_split=getattr(self.args.VIDEO.HEAD, "FP16_SPLIT", None))
+                                          fp16_split=getattr(self.args.VIDEO.HEAD, "FP16_SPLIT", None),
+                                          fp16_mcorr=getattr(self.args.VIDEO.HEAD, "FP16_MCORR", None))
             self._engine_key = key
         return self._engine
 

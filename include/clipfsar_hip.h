@@ -253,16 +253,27 @@ int cfsar_gemm_residual_stats_heads(const void* A, const void* W, void* x, const
  * result to fp16 first and adds in fp16); with x_lo != NULL the stream carries two fp16 words per element, x = x_hi + x_lo, x_lo the
  * rounding remainder of x_hi: the update reads and writes both, LN-folded consumers read x_hi (and its statistics) only.
  *
- * cfsar_gemm_lnfold_split: cfsar_gemm_lnfold with Wg2 [N, ldw >= 2 K] split, cvec = sum_k (hi + lo), fp16 output.  Statistics either
- * finalized (rowstats [M, 4], partial = NULL) or the producer's partials (partial [M, slots, 2], rowstats = NULL, rowstats_ws [M, 4] as
- * in cfsar_gemm_lnfold_partials).
+ * PER-FRAME LOW-WORD CORRECTION (corr != NULL; frames of corr_tokens >= 128 rows): the part of the weights' fp16 rounding error that is
+ * the same for all tokens of a frame -- (token mean of the frame's operand rows) x W_lo^T, a [frames, K] x [K, N] product the caller forms
+ * with cfsar_frame_col_means + cfsar_gemm -- is added to every row of its frame inside the GEMM (in normalised units, before the
+ * activation, for the LN-folded form): most of what split weights buy at none of the second MFMA pass (profiles/r04_parity_table.md).
+ *
+ * cfsar_gemm_lnfold_hp: cfsar_gemm_lnfold with fp16 output; wsplit = 1: Wg [N, ldw >= 2 K] split, cvec = sum_k (hi + lo).  Statistics
+ * either finalized (rowstats [M, 4], partial = NULL) or the producer's partials (partial [M, slots, 2], rowstats = NULL, rowstats_ws
+ * [M, 4] as in cfsar_gemm_lnfold_partials).  corr [ceil(M / corr_tokens), N] fp32 or NULL.
  * cfsar_gemm_residual_wide: x = x + A W^T + bias, A [M, lda] fp16, W [N, ldw] fp16 (wsplit = 0) or [N, ldw >= 2 K] split (wsplit = 1),
- * x_hi [M, ldx] fp16 in place, x_lo [M, ldx] fp16 in place or NULL; stats_partial as in cfsar_gemm_residual_stats (of the new x_hi). */
-int cfsar_gemm_lnfold_split(const void* x, const void* Wg2, void* out, const float* cvec, const float* dvec, const float* rowstats,
-                            const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda, int ldw,
-                            int ldo, int act, int out_dtype, cfsar_stream_t stream);
+ * x_hi [M, ldx] fp16 in place, x_lo [M, ldx] fp16 in place or NULL; stats_partial as in cfsar_gemm_residual_stats (of the new x_hi);
+ * corr as above. */
+int cfsar_gemm_lnfold_hp(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec, const float* rowstats,
+                         const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda, int ldw, int ldo,
+                         int act, int out_dtype, int wsplit, const float* corr, int corr_tokens, cfsar_stream_t stream);
 int cfsar_gemm_residual_wide(const void* A, const void* W, void* x_hi, void* x_lo, const float* bias, float* stats_partial, int M,
-                             int N, int K, int wsplit, int lda, int ldw, int ldx, cfsar_stream_t stream);
+                             int N, int K, int wsplit, int lda, int ldw, int ldx, const float* corr, int corr_tokens,
+                             cfsar_stream_t stream);
+/* out[f][k] = mean over the frame's tokens t of w_t (A[f tokens + t][k] - mu_t), (mu_t, w_t) = (mean, 1 / std) of row t from rowstats
+ * [frames tokens, 4] (the token mean of LayerNorm(x) before its affine, few_shot.py:605-611) or (0, 1) when rowstats == NULL.
+ * A [frames tokens, lda] fp16, out [frames, K] bf16. */
+int cfsar_frame_col_means(const void* A, int lda, const float* rowstats, void* out, int frames, int tokens, int K, cfsar_stream_t stream);
 /* out[i] = (float)hi[i] + (float)lo[i], i < n (the two-word stream -> fp32, e.g. in front of ln_post, few_shot.py:683). */
 int cfsar_f16_pair_to_f32(const void* hi, const void* lo, float* out, int64_t n, cfsar_stream_t stream);
 /* dst[r][0 .. row_bytes) = src[r][0 .. row_bytes), rows at byte strides src_stride / dst_stride (row_bytes % 4 == 0): the

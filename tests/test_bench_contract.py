@@ -100,9 +100,8 @@ def test_bench_line_bf16_parity_roofline_rccl_ws1():
     assert par["checked"] and par["argmax_equal"] and par["max_abs_dlogits"] < LOGITS_TOLERANCE["bf16"], par
     assert par["north_star_tolerance"] == 1e-3 and par["meets_north_star"] == (par["max_abs_dlogits"] < 1e-3)
     f16 = out["fp16_mode"]                                  # the 1e-3-conforming 16-bit mode, timed in the same run
-    # (round 4: the mode carries three of its four GEMMs' weights as fp16 pairs + a two-word stream: ~0.6 x the bf16 rate, 6 x the fp32 mode's)
-    assert f16["parity"]["meets_north_star"] and f16["parity"]["argmax_equal"] and f16["value"] > 0.5 * out["value"], f16
-    assert f16["parity"]["max_abs_dlogits"] < 7e-4, f16
+    # (round 4: two-word stream + per-frame low-word correction of the weights: ~0.78 x the bf16 rate, 8 x the fp32 mode's)
+    assert f16["parity"]["meets_north_star"] and f16["parity"]["argmax_equal"] and f16["value"] > 0.7 * out["value"], f16
     assert out["collective"]["rccl_world_size"] == 1 and out["collective"]["backend"] == "nccl", out["collective"]
     assert out["per_rank_episodes_per_s"]["ranks"] == 1
     r = out["roofline"]

@@ -135,6 +135,25 @@ def test_outlier_channel_statistics(name, monkeypatch):
     assert maxdiff(lb[0], g["logits"]) < 2.0 * maxdiff(lu[0], g["logits"]) + 1e-3, (maxdiff(lb[0], g["logits"]), maxdiff(lu[0], g["logits"]))
 
 
+def test_fp16_mode_steady_parity_statistic():
+    """The golden cases hold ONE episode each (5 ... 25 logits): max |dlogits| of one episode moves by +-30 % with any change of a last
+    bit.  The steadier regression guard: 8 fresh cfg2 episodes (40 logits) in the fp16 mode against the fp32 mode of the same engine
+    (itself within 1e-5 of the reference on every golden) -- rms and max.  Measured (16 episodes, profiles/r04_parity_table.md): rms
+    2.4e-4, max 7.4e-4; round 3's fp16 mode: 4.2e-4 / 1.18e-3."""
+    g = load_golden("cfg2_B16_5w1s_T8")
+    m = g["meta"]
+    a, sd, tt, te, _ = case_inputs(m)
+    eps = [{k: torch.from_numpy(v) for k, v in synth.make_episode(way=m["way"], shot=m["shot"], query_per_class=m["q"], frames=m["T"],
+                                                                  res=a["res"], n_test_classes=m["n_test"], episode=2000 + e,
+                                                                  seed=m["seed"]).items()} for e in range(8)]
+    l32, _ = run_engine(m, a, sd, tt, te, eps, "fp32")
+    l16, _ = run_engine(m, a, sd, tt, te, eps, "fp16")
+    d = l16 - l32
+    assert float(d.pow(2).mean().sqrt()) < 3.5e-4, float(d.pow(2).mean().sqrt())
+    assert float(d.abs().max()) < NORTH_STAR_TOLERANCE, float(d.abs().max())
+    assert torch.equal(l16.argmax(2), l32.argmax(2))
+
+
 def test_fp16_mode_refuses_what_it_cannot_represent():
     """The RN50 tower has no fp16 path; the engine says so instead of silently running bf16."""
     g = load_golden("rn_t_5w2s_T4")
@@ -175,7 +194,7 @@ def test_cfg2_full_size_fp32_and_bf16():
     lb, _ = run_engine(m, a, sd, tt, te, [ep], "bf16")
     assert maxdiff(lb[0], g["logits"]) < LOGITS_TOLERANCE["bf16"]
     lh, ch = run_engine(m, a, sd, tt, te, [ep], "fp16")
-    assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE            # the 16-bit mode that meets the north star (measured 3.6e-4)
+    assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE            # the 16-bit mode that meets the north star (measured 7.6e-4 on this episode; rms over 16 episodes 2.4e-4)
     assert torch.equal(lh[0].argmax(1), torch.from_numpy(g["logits"]).argmax(1))
 
 
@@ -215,7 +234,7 @@ def test_cfg3_four_episodes_per_step():
     lb, _ = run_engine(m, a, sd, tt, te, eps, "bf16")
     assert maxdiff(lb[0], g["logits"]) < LOGITS_TOLERANCE["bf16"]
     lh, _ = run_engine(m, a, sd, tt, te, eps, "fp16")
-    assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE                      # round 4: 2.8e-4 measured (r3's fp16 mode: 1.06e-3)
+    assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE                      # round 4: 4.8e-4 measured (r3's fp16 mode: 1.06e-3)
     l1, _ = run_engine(m, a, sd, tt, te, [eps[2]], "bf16")
     assert maxdiff(lb[2], l1[0]) <= 4e-6
 
@@ -240,9 +259,9 @@ def test_cfg3_cfg4_full_size(name, tol_feat):
     assert maxdiff(lb[0], g["logits"]) < bound(name, "bf16")
     if a.get("kind") != "rn":
         lh, _ = run_engine(m, a, sd, tt, te, [ep], "fp16")
-        # Round 4: the fp16 mode (single-rounding residual add, two-word stream, split QKV / out_proj / c_proj weights) is held to the
-        # NORTH-STAR 1e-3 on every full-size configuration: measured 3.6e-4 (cfg2), 2.8e-4 (cfg3), 5.7e-4 (cfg4) --
-        # profiles/r04_parity_table.md; round 3's fp16 mode measured 5.1e-4 / 1.06e-3 / 1.78e-3.
+        # Round 4: the fp16 mode (single-rounding residual add, two-word stream, per-frame low-word correction of all four GEMMs' weights) is
+        # held to the NORTH-STAR 1e-3 on every full-size configuration: goldens 7.6e-4 (cfg2), 4.8e-4 (cfg3), 3.4e-4 (cfg4); over 16 fresh
+        # episodes each rms 2.4e-4 / 2.2e-4 / 2.5e-4 -- profiles/r04_parity_table.md; round 3's fp16 mode: goldens 5.1e-4 / 1.06e-3 / 1.78e-3.
         assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE, name
     print("%s: fp32 |dlogits| %.2e, bf16 |dlogits| %.3f" % (name, maxdiff(logits[0], g["logits"]), maxdiff(lb[0], g["logits"])))
 

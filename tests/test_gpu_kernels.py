@@ -962,7 +962,7 @@ def test_gemm_residual_wide(hip, M, N, K, two_word, wsplit):
                                        (80, 768, 768, "none"), (12850, 3072, 1024, "gelu")])
 @pytest.mark.parametrize("from_part", [False, True])
 def test_gemm_lnfold_split(hip, M, N, K, act, from_part):
-    """cfsar_gemm_lnfold_split == act(LayerNorm(x) W^T + b) with the weights carried as fp16 hi + lo: against the float64 computation on
+    """cfsar_gemm_lnfold_hp (wsplit) == act(LayerNorm(x) W^T + b) with the weights carried as fp16 hi + lo: against the float64 computation on
     the operands the kernel sees (fp16 x, hi + lo weights) the only error left is the fp16 rounding of the OUTPUT (2^-12) + fp32
     accumulation; the same call with plain fp16 weights (cfsar_gemm_lnfold) must be measurably farther from the fp32-weight reference."""
     if from_part and K % 64 != 0:
@@ -986,9 +986,9 @@ def test_gemm_lnfold_split(hip, M, N, K, act, from_part):
     out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
     if from_part:
         ws = torch.full((M, 4), float("nan"), device="cuda")
-        hip.gemm_lnfold_split(x, Wg2, out, c, d, partial=part, slots=S, rowstats_ws=ws, act=a)
+        hip.gemm_lnfold_hp(x, Wg2, out, c, d, partial=part, slots=S, rowstats_ws=ws, act=a, wsplit=True)
     else:
-        hip.gemm_lnfold_split(x, Wg2, out, c, d, rowstats=rstat, act=a)
+        hip.gemm_lnfold_hp(x, Wg2, out, c, d, rowstats=rstat, act=a, wsplit=True)
     xd = x.double()
     mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
     ref = ((xd - mean) / torch.sqrt(var + 1e-5)) @ Wg32.double().t() + d.double()
@@ -1023,3 +1023,79 @@ def test_copy_rows_strided_and_f16_pair(hip):
     o3 = torch.empty(F_, D, device="cuda")
     hip.f16_pair_to_f32(hi, lo, o3)
     assert torch.equal(o3, hi.float() + lo.float())
+
+
+@pytest.mark.parametrize("frames,tokens,K,norm", [(7, 197, 768, True), (5, 257, 1024, False), (3, 197, 3072, False), (2, 130, 128, True)])
+def test_frame_col_means(hip, frames, tokens, K, norm):
+    g = torch.Generator().manual_seed(41)
+    M = frames * tokens
+    A = (torch.randn(M, K, generator=g) * 2.0 + torch.randn(M, 1, generator=g)).to(torch.float16).cuda()
+    rstat = None
+    ref = A.float()
+    if norm:
+        mu, var = A.float().mean(1, keepdim=True), A.float().var(1, unbiased=False, keepdim=True)
+        rstat = torch.cat([mu, torch.sqrt(var + 1e-5), torch.rsqrt(var + 1e-5), torch.zeros_like(mu)], 1).contiguous()
+        ref = (A.float() - mu) * torch.rsqrt(var + 1e-5)
+    ref = ref.view(frames, tokens, K).mean(1)
+    out = torch.full((frames, K), float("nan"), device="cuda", dtype=torch.bfloat16)
+    hip.frame_col_means(A, out, frames, tokens, rowstats=rstat)
+    assert maxdiff(out.float(), ref) < 2.0 ** -8 * max(1.0, float(ref.abs().max())) + 1e-5          # bf16 output
+
+
+@pytest.mark.parametrize("frames,tokens,N,K", [(6, 197, 768, 768), (40, 197, 768, 3072), (3, 257, 1024, 1024), (80, 197, 768, 768), (1, 197, 768, 768)])
+@pytest.mark.parametrize("two_word", [False, True])
+def test_gemm_residual_wide_per_frame_correction(hip, frames, tokens, N, K, two_word):
+    """corr [frames, N] is added to every row of its frame (rows of a tile belong to at most two frames: both halves of the tail MFMA)."""
+    g = torch.Generator().manual_seed(51)
+    M = frames * tokens
+    A = (torch.randn(M, K, generator=g) * 0.7).to(torch.float16).cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.float16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    corr = (torch.randn(frames, N, generator=g) * 1e-2).cuda()
+    x32 = (torch.randn(M, N, generator=g) * 3.0).cuda()
+    xh = x32.to(torch.float16)
+    xl = (x32 - xh.float()).to(torch.float16) if two_word else None
+    cq = corr.to(torch.float16).double()                                                              # the kernel feeds it as an fp16 factor
+    ref = (xh.double() + (xl.double() if two_word else 0.0)) + A.double() @ W.double().t() + bias.double() + cq.repeat_interleave(tokens, 0)
+    xh2, xl2 = xh.clone(), (xl.clone() if two_word else None)
+    hip.gemm_residual_wide(A, W, xh2, xl2, bias, None, corr=corr, corr_tokens=tokens)
+    got = xh2.double() + (xl2.double() if two_word else 0.0)
+    scale = float(ref.abs().max())
+    tol = 3e-6 * scale if two_word else 2.0 ** -11 * scale
+    assert float((got - ref).abs().max()) < tol, (float((got - ref).abs().max()), scale)
+    # and it is the correction that is being added: without it the result differs by exactly corr (to rounding)
+    xh3, xl3 = xh.clone(), (xl.clone() if two_word else None)
+    hip.gemm_residual_wide(A, W, xh3, xl3, bias, None)
+    d = (got - (xh3.double() + (xl3.double() if two_word else 0.0))).view(frames, tokens, N)
+    assert float((d - cq[:, None, :]).abs().max()) < (1e-5 if two_word else 2.0 ** -10 * scale)
+
+
+@pytest.mark.parametrize("frames,tokens,N,K,act", [(6, 197, 2304, 768, "none"), (40, 197, 3072, 768, "gelu"), (3, 257, 3072, 1024, "gelu"),
+                                                   (80, 197, 2304, 768, "none"), (1, 197, 768, 768, "none")])
+def test_gemm_lnfold_hp_per_frame_correction(hip, frames, tokens, N, K, act):
+    """out = act(LayerNorm(x) Wg^T + d + corr[frame]): the correction enters in normalised units, BEFORE the activation."""
+    g = torch.Generator().manual_seed(61)
+    M = frames * tokens
+    x = (torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 2.0) + torch.randn(M, 1, generator=g)).to(torch.float16).cuda()
+    Wg = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.float16).cuda()
+    c = Wg.double().sum(1).float()
+    d = torch.randn(N, generator=g).cuda()
+    corr = (torch.randn(frames, N, generator=g) * 1e-2).cuda()
+    rstat = torch.empty(M, 4, device="cuda")
+    hip.row_stats(x, rstat, M, K)
+    a = hip.ACT_QUICKGELU if act == "gelu" else hip.ACT_NONE
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
+    hip.gemm_lnfold_hp(x, Wg, out, c, d, rowstats=rstat, act=a, corr=corr, corr_tokens=tokens)
+    xd = x.double()
+    mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    pre = ((xd - mean) / torch.sqrt(var + 1e-5)) @ Wg.double().t() + d.double()
+    ref = pre + corr.double().repeat_interleave(tokens, 0)
+    ref0 = pre
+    if act == "gelu":
+        ref, ref0 = ref * torch.sigmoid(1.702 * ref), ref0 * torch.sigmoid(1.702 * ref0)
+    scale = max(1.0, float(ref.abs().max()))
+    e = float((out.double() - ref).abs().max())
+    e0 = float((out.double() - ref0).abs().max())
+    # tolerance: fp16 output rounding + the fp16 factors of the correction (std x corr: 2^-11 each of a 1e-2-size term)
+    assert e < 6e-4 * scale + 1e-4, (e, scale)
+    assert e0 > 5 * e, (e0, e)            # the uncorrected reference is clearly farther away: the correction is really applied

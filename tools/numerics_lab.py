@@ -122,7 +122,8 @@ def run(case, schemes):
         out = orc.head_forward(ep, sd, tt, te, a, taps=taps, **kw)
         orc.vit_forward = orig
         lg = out["logits"].reshape(-1)
-        print("  %-46s max |dlogits| %.2e   (%.0f s)" % (sch, float((lg - ref).abs().max()), time.time() - t0), flush=True)
+        print("  %-46s max |dlogits| %.2e  rms %.2e  (%.0f s)" % (sch, float((lg - ref).abs().max()), float((lg - ref).pow(2).mean().sqrt()),
+                                                                  time.time() - t0), flush=True)
 
 
 def run_feats(arch_name, nf, schemes, seed=18):
@@ -143,7 +144,30 @@ def run_feats(arch_name, nf, schemes, seed=18):
                                                                           float(d.mean(0).pow(2).mean().sqrt())), flush=True)
 
 
+def run_episode(arch_name, shot, q, T, schemes, seed=18, episode=3):
+    """logits error of each scheme on a FRESH synthetic episode with q queries per class (5 q x 5 logits: a steadier statistic than the
+    goldens' 5 ... 25), against the oracle's fp32 logits of the same episode"""
+    import clip_fsar_amd.synth as synth
+    a = synth.ARCHS[arch_name]
+    sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(arch_name, seed).items()}
+    tt = torch.from_numpy(synth.text_features(64, a["embed"], "train", seed))
+    te = torch.from_numpy(synth.text_features(24, a["embed"], "test", seed))
+    ep = {k: torch.from_numpy(v) for k, v in synth.make_episode(5, shot, q, T, a["res"], 24, episode, seed).items()}
+    orig = orc.vit_forward
+    ref = orc.head_forward(ep, sd, tt, te, a, frames=T)["logits"].reshape(-1)
+    print("%s %d-shot q=%d T=%d: %d logits, spread %.3f" % (arch_name, shot, q, T, ref.numel(), float(ref.max() - ref.min())), flush=True)
+    for sch in schemes:
+        s = dict(kv.split("=") for kv in sch.split(",") if kv)
+        orc.vit_forward = make_tower(s)
+        lg = orc.head_forward(ep, sd, tt, te, a, frames=T)["logits"].reshape(-1)
+        orc.vit_forward = orig
+        print("  %-46s max |dlogits| %.2e  rms %.2e" % (sch, float((lg - ref).abs().max()), float((lg - ref).pow(2).mean().sqrt())), flush=True)
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "episode":        # episode ARCH SHOT Q T scheme...
+        run_episode(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6:])
+        sys.exit(0)
     if sys.argv[1] == "feats":
         run_feats(sys.argv[2], int(sys.argv[3]), sys.argv[4:])
         sys.exit(0)
