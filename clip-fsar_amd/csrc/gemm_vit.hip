@@ -188,6 +188,14 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
     typedef typename Vec2B<TO>::v8 TO8;
     const int lr = lane & 31, hi = lane >> 5;
     const int rr = lane >> 3, Q = lane & 7;
+    // per-frame column sums of the stored output (VitGemmArgs::colsum): the fp16 LN-folded QuickGELU instance only
+    constexpr bool COLSUM = std::is_same<TO, _Float16>::value && ACT == CFSAR_ACT_QUICKGELU && ROWSCALE && !HAS_RES && !HB;
+    typedef _Float16 cs_h8 __attribute__((ext_vector_type(8)));
+    cs_h8 cs0 = {0, 0, 0, 0, 0, 0, 0, 0}, cs1 = {0, 0, 0, 0, 0, 0, 0, 0};
+    int cs_bnd = 0;
+    if constexpr (COLSUM) {
+        if (p.colsum != nullptr) cs_bnd = (mb / p.corr_tokens + 1) * p.corr_tokens - mb;      // rows of this wave tile in its first frame
+    }
     const bool colok = FULL || nb + 64 <= p.N;              // whole-wave predicate (N % 64 == 0)
     const int ncl = colok ? nb : p.N - 64;                  // clamped column base: loads stay in bounds
     char* wr = slab + lr * 128;
@@ -331,6 +339,15 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
         if ((p.dbg & 32) && ((blockIdx.x >> 3) & 1) && x[0] != 0x7fc12345u) return;   // ... on every other workgroup of each XCD only
 #endif
         if (FULL || (rowok && colok)) store16<STORE>(out_addr(mi * 4 + it), x);
+        if constexpr (COLSUM) {
+            if (p.colsum != nullptr) {                       // kernel-uniform
+                const cs_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                const cs_h8 xv = rowok ? __builtin_bit_cast(cs_h8, x) : z;
+                const bool in0 = rr + (mi * 4 + it) * 8 < cs_bnd;
+                cs0 += in0 ? xv : z;
+                cs1 += in0 ? z : xv;
+            }
+        }
     };
 #if CFSAR_EPI_PIPE
     u32x4 dprev[4], rvprev[4];
@@ -379,6 +396,37 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
         for (int it = 0; it < 4; ++it) finish(mi, it, d[it], rv[it]);
     }
 #endif
+    if constexpr (COLSUM) {
+        if (p.colsum != nullptr) {
+            // sum over the 8 row groups rr (lanes differing in bits 3, 4, 5) in packed fp16: row_ror:8, swizzle xor 16, bpermute xor 32
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            u32x4 a0 = __builtin_bit_cast(u32x4, cs0), a1 = __builtin_bit_cast(u32x4, cs1);
+            auto add2 = [](unsigned u, unsigned v) __attribute__((always_inline)) -> unsigned {
+                return __builtin_bit_cast(unsigned, (h2)(__builtin_bit_cast(h2, u) + __builtin_bit_cast(h2, v)));
+            };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] = add2(a0[j], (unsigned)__builtin_amdgcn_update_dpp(0, (int)a0[j], 0x128, 0xF, 0xF, false));
+                a1[j] = add2(a1[j], (unsigned)__builtin_amdgcn_update_dpp(0, (int)a1[j], 0x128, 0xF, 0xF, false));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] = add2(a0[j], (unsigned)__builtin_amdgcn_ds_swizzle((int)a0[j], 0x401F));
+                a1[j] = add2(a1[j], (unsigned)__builtin_amdgcn_ds_swizzle((int)a1[j], 0x401F));
+            }
+            const int partner = (lane ^ 32) << 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] = add2(a0[j], (unsigned)__builtin_amdgcn_ds_bpermute(partner, (int)a0[j]));
+                a1[j] = add2(a1[j], (unsigned)__builtin_amdgcn_ds_bpermute(partner, (int)a1[j]));
+            }
+            if (rr == 0 && colok && mb < p.M) {
+                char* dst = reinterpret_cast<char*>(p.colsum) + (((size_t)(mb / (32 * NMI)) * 2) * p.N + ncl + 8 * Q) * 2;
+                *reinterpret_cast<u32x4*>(dst) = a0;
+                *reinterpret_cast<u32x4*>(dst + (size_t)p.N * 2) = a1;
+            }
+        }
+    }
 }
 
 // ---- MODE 6 epilogue ("wide" residual; the fp16 numerics mode, round 4).  What differs from epilogue_rows<HAS_RES>: the GEMM result is
@@ -1123,6 +1171,9 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     a.res_lo = c.wide ? c.res_lo : nullptr;
     a.corr = c.corr;
     a.corr_tokens = c.corr_tokens;
+    a.colsum = c.colsum;
+    if (c.colsum && !(lnfold && c.act == CFSAR_ACT_QUICKGELU && c.out_dtype == CFSAR_F16 && c.corr_tokens >= 128 && c.hb_tokens == 0))
+        return cfsar_fail("cfsar_gemm_lnfold_hp: per-frame output means exist for the fp16 QuickGELU form with >= 128 tokens per frame");
     if (c.corr && !(c.corr_tokens >= 128 && c.in_dtype == CFSAR_F16 && c.out_dtype == CFSAR_F16 && (lnfold || c.wide) && c.hb_tokens == 0))
         return cfsar_fail("cfsar_gemm (vit): the per-frame correction needs >= 128 tokens per frame and an fp16-mode instance (tokens=%d)", c.corr_tokens);
     a.part = c.part; a.part_slots = c.part_slots; a.part_invD = 1.0f / (float)ka; a.part_eps = c.part_eps;
@@ -1140,6 +1191,7 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     // 62 bands x 9 columns of 256-row tiles are 2.2 rounds on 256 CUs and cost 3; 83 x 9 of 192 rows cost 3 x 0.75)
     a.miw = vit_pick_miw(c.M, a.tiles_n, lnfold ? 2 : ((f16res || bf16res) ? (c.wide ? 6 : 1) : 0), c.opath, c.store, c.K, c.dbg);
     if (c.part && a.miw != 3) return cfsar_fail("cfsar_gemm_lnfold_partials: internal: fused statistics need the 192-row instance");
+    if (c.out_miw) *c.out_miw = a.miw;
     a.ntiles = ((c.M + 64 * a.miw - 1) / (64 * a.miw)) * a.tiles_n;
     a.group = c.group > 0 ? c.group : 8;
     a.colfast = c.colfast;
@@ -1207,11 +1259,28 @@ extern "C" void cfsar_debug_set_vit_dbg(int dbg) { g_force_dbg = dbg; }
 extern "C" void cfsar_debug_set_vit_trace(void* trace, int stagger_unit) { g_trace = static_cast<long long*>(trace); g_stagger_unit = stagger_unit; }
 #endif
 
+namespace {
+// per-frame token means of the GEMM's OUTPUT from the wave tiles' per-frame column sums (VitGemmArgs::colsum): frame f covers rows
+// [f T, (f + 1) T) = the wave tiles b0 .. b1 of `wr` rows; tile b contributes its slot f - (b wr) / T (0 or 1).  Fixed summation order.
+__global__ __launch_bounds__(256) void frame_means_from_colsums_kernel(const _Float16* __restrict__ cs, __bf16* __restrict__ out, int wr,
+                                                                       int tokens, int N) {
+    const int f = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = f * tokens, r1 = r0 + tokens - 1;
+    float s = 0.f;
+    for (int b = r0 / wr; b <= r1 / wr; ++b) {
+        const int j = f - (b * wr) / tokens;
+        if (j == 0 || j == 1) s += (float)cs[((size_t)b * 2 + j) * N + n];
+    }
+    out[(size_t)f * N + n] = (__bf16)(s / (float)tokens);
+}
+}  // namespace
+
 // out = act(LayerNorm(x; gamma, beta) W^T + bias) with the LayerNorm folded into the GEMM (MODE 2 above).  See the header.
 static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
                             const float* rowstats, int M, int N, int K, int lda, int ldw, int ldo, int act, int out_dtype, int hb_tokens,
                             int hb_heads, cfsar_stream_t stream, const float* partial = nullptr, int slots = 0, float eps = 0.f, int wsplit = 0,
-                            const float* corr = nullptr, int corr_tokens = 0) {
+                            const float* corr = nullptr, int corr_tokens = 0, void* colmean_out = nullptr, void* colsum_ws = nullptr) {
     CFSAR_REQUIRE(out_dtype == CFSAR_BF16 || out_dtype == CFSAR_F16, "cfsar_gemm_lnfold: out_dtype must be bf16 or fp16, got %d", out_dtype);
     CFSAR_REQUIRE(x && Wg && out && cvec && dvec && (rowstats || partial), "cfsar_gemm_lnfold: null pointer");
     CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_lnfold: bad shape M=%d N=%d K=%d (K %% 64, N %% 64, K >= 128)", M, N, K);
@@ -1222,6 +1291,8 @@ static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const floa
     VitGemmCall c;
     c.ka = ka_;
     c.corr = corr; c.corr_tokens = corr_tokens;
+    int miw_used = 4;
+    c.colsum = colmean_out ? colsum_ws : nullptr; c.out_miw = &miw_used;
     c.A = x; c.W = Wg; c.out = out; c.bias = dvec; c.res = nullptr; c.rowstats = partial ? nullptr : rowstats; c.cvec = cvec; c.stats_out = nullptr;
     c.part = partial; c.part_slots = slots; c.part_eps = eps;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = 0;
@@ -1232,6 +1303,13 @@ static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const floa
     c.dbg = g_force_dbg;
 #endif
     const int rc = cfsar_gemm_vit_try(c, static_cast<hipStream_t>(stream));
+    if (rc == 0 && colmean_out) {
+        const int frames = (M + corr_tokens - 1) / corr_tokens;
+        hipLaunchKernelGGL(frame_means_from_colsums_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)frames), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), static_cast<const _Float16*>(colsum_ws), static_cast<__bf16*>(colmean_out),
+                           32 * miw_used, corr_tokens, N);
+        return cfsar_check_launch("cfsar_gemm_lnfold_hp(frame means)");
+    }
     return rc == -2 ? cfsar_fail("cfsar_gemm_lnfold: operands too large for 32-bit offsets") : rc;
 }
 
@@ -1257,7 +1335,7 @@ extern "C" int cfsar_gemm_lnfold_heads(const void* x, const void* Wg, void* out,
 static int lnfold_partials_impl(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
                                 const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda,
                                 int ldw, int ldo, int act, int out_dtype, int tokens, int heads, int wsplit, cfsar_stream_t stream,
-                                const float* corr = nullptr, int corr_tokens = 0) {
+                                const float* corr = nullptr, int corr_tokens = 0, void* colmean_out = nullptr, void* colsum_ws = nullptr) {
     CFSAR_REQUIRE(partial != nullptr && rowstats_ws != nullptr, "cfsar_gemm_lnfold_partials: null partials / workspace");
     CFSAR_REQUIRE(slots > 0 && slots * 64 == K, "cfsar_gemm_lnfold_partials: K=%d is not 64 x slots=%d", K, slots);
     int dbg = 0;
@@ -1272,14 +1350,16 @@ static int lnfold_partials_impl(const void* x, const void* Wg, void* out, const 
     if (!fused) {
         if (int rc = cfsar_ln_stats_finalize(partial, rowstats_ws, M, slots, K, eps, stream)) return rc;
         if (tokens > 0) return cfsar_gemm_lnfold_heads(x, Wg, out, cvec, dvec, rowstats_ws, M, N, K, lda, ldw, tokens, heads, stream);
-        return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, nullptr, 0, 0.f, wsplit, corr, corr_tokens);
+        return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, nullptr, 0, 0.f, wsplit, corr, corr_tokens,
+                                colmean_out, colsum_ws);
     }
     if (tokens > 0) {
         CFSAR_REQUIRE(tokens >= 128 && heads > 0 && N == 192 * heads && M % tokens == 0 && act == CFSAR_ACT_NONE && out_dtype == CFSAR_BF16,
                       "cfsar_gemm_lnfold_partials: head-blocked output needs tokens >= 128, N = 192 heads, M a multiple of tokens, act NONE, bf16");
         return gemm_lnfold_impl(x, Wg, out, cvec, dvec, nullptr, M, N, K, lda, ldw, N, act, out_dtype, tokens, heads, stream, partial, slots, eps);
     }
-    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, nullptr, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, partial, slots, eps, wsplit, corr, corr_tokens);
+    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, nullptr, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, partial, slots, eps, wsplit, corr, corr_tokens,
+                            colmean_out, colsum_ws);
 }
 
 extern "C" int cfsar_gemm_lnfold_partials(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec,
@@ -1293,15 +1373,18 @@ extern "C" int cfsar_gemm_lnfold_partials(const void* x, const void* Wg, void* o
 // partials [M, slots, 2] finalized here (rowstats_ws [M, 4] is then the workspace of the two-launch form).
 extern "C" int cfsar_gemm_lnfold_hp(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec, const float* rowstats,
                                     const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda, int ldw,
-                                    int ldo, int act, int out_dtype, int wsplit, const float* corr, int corr_tokens, cfsar_stream_t stream) {
+                                    int ldo, int act, int out_dtype, int wsplit, const float* corr, int corr_tokens, void* colmean_out,
+                                    void* colsum_ws, cfsar_stream_t stream) {
     CFSAR_REQUIRE(out_dtype == CFSAR_F16, "cfsar_gemm_lnfold_hp: fp16 output only (the fp16 numerics mode)");
-    CFSAR_REQUIRE(corr == nullptr || corr_tokens >= 128, "cfsar_gemm_lnfold_hp: the per-frame correction needs >= 128 tokens per frame");
+    CFSAR_REQUIRE((corr == nullptr && colmean_out == nullptr) || corr_tokens >= 128, "cfsar_gemm_lnfold_hp: the per-frame forms need >= 128 tokens per frame");
+    CFSAR_REQUIRE(colmean_out == nullptr || (colsum_ws != nullptr && act == CFSAR_ACT_QUICKGELU), "cfsar_gemm_lnfold_hp: output means need the workspace and act = QUICKGELU");
     if (partial != nullptr) {
         CFSAR_REQUIRE(slots > 0 && slots * 64 == K, "cfsar_gemm_lnfold_hp: K=%d is not 64 x slots=%d", K, slots);
         return lnfold_partials_impl(x, Wg, out, cvec, dvec, partial, slots, eps, rowstats_ws, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, wsplit, stream,
-                                    corr, corr_tokens);
+                                    corr, corr_tokens, colmean_out, colsum_ws);
     }
-    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, nullptr, 0, 0.f, wsplit, corr, corr_tokens);
+    return gemm_lnfold_impl(x, Wg, out, cvec, dvec, rowstats, M, N, K, lda, ldw, ldo, act, out_dtype, 0, 0, stream, nullptr, 0, 0.f, wsplit, corr, corr_tokens,
+                            colmean_out, colsum_ws);
 }
 
 // x = x + A W^T + bias (fp16 residual stream, in place) and, if stats_partial != NULL, the per-row partial LayerNorm

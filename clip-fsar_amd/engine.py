@@ -209,6 +209,7 @@ class HipViT:
         self.prune_last = os.environ.get("CFSAR_FULL_LAST_BLOCK", "0") != "1"
         # LN statistics finalized inside the consuming GEMM (ViT-B / ViT-L widths; CFSAR_FUSE_STATS=0: the separate finalize launches)
         self.fuse_stats = bool(self.fold) and hip.lnfold_partials_ok(self.D, self.D // 64) and os.environ.get("CFSAR_FUSE_STATS", "1") != "0"
+        self.fused_umeans = os.environ.get("CFSAR_FUSED_UMEANS", "1") != "0"      # c_fc emits the hidden's per-frame means (A/B switch)
         if self.mcorr & {"qkv", "fc"}:
             self.fuse_stats = False          # the token means of LayerNorm(x) need the finalized statistics in front of the GEMM
         # band-chunked layer schedule (developer switch; measured in profiles/r04_chunked_schedule.md): CFSAR_CHUNK_FRAMES=k,
@@ -238,6 +239,8 @@ class HipViT:
                 ws["rstat"] = torch.empty(M, 4, device=dev, dtype=torch.float32)            # (mean, std, 1/std, -)
             # class-token rows of the last block (prune_last): [F, .]
             if self.mcorr:
+                ws["colsum"] = torch.empty((M // 96 + 2) * 2 * 4 * D, device=dev, dtype=torch.float16)   # c_fc's per-wave-tile column sums
+                ws["mU"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.bfloat16)         # per-frame token means of the MLP hidden
                 ws["mA"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.bfloat16)         # per-frame token means of a GEMM operand
                 ws["corr"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.float32)        # ... x W_lo^T
             if self.two_word:
@@ -308,23 +311,28 @@ class HipViT:
 
             mcorr = self.mcorr
 
-            def mc(blk, key, A, rs=None, wrows=None):
-                """per-frame low-word correction of GEMM `key` for the full-size launch: token means of the operand x W_lo^T -> [F, N]"""
+            def mc(blk, key, A, rs=None, wrows=None, means=None):
+                """per-frame low-word correction of GEMM `key` for the full-size launch: token means of the operand x W_lo^T -> [F, N]
+                (means: already produced by the GEMM that wrote the operand)"""
                 if key not in mcorr:
                     return None
                 wlo = blk["wlo_" + key] if wrows is None else blk["wlo_" + key][wrows]
                 Kd, Nn = A.shape[1], wlo.shape[0]
-                mA = ws["mA"][:F_ * Kd].view(F_, Kd)
-                hip.frame_col_means(A, mA, F_, N, rowstats=rs)
+                if means is not None:
+                    mA = means
+                else:
+                    mA = ws["mA"][:F_ * Kd].view(F_, Kd)
+                    hip.frame_col_means(A, mA, F_, N, rowstats=rs)
                 cr = ws["corr"][:F_ * Nn].view(F_, Nn)
                 hip.corr_gemm(mA, wlo, cr)
                 return cr
 
-            def fold(xx, wg, out, c, d, pt, rs, act=hip.ACT_NONE, rows=M, from_part=False, heads=False, sp=False, corr=None):
-                if sp or corr is not None:                                            # fp16 numerics mode: split weights [N, 2K] / correction
+            def fold(xx, wg, out, c, d, pt, rs, act=hip.ACT_NONE, rows=M, from_part=False, heads=False, sp=False, corr=None, umeans=None):
+                if sp or corr is not None or umeans is not None:                      # fp16 numerics mode: split weights [N, 2K] / correction
                     hip.gemm_lnfold_hp(xx, wg, out, c, d, rowstats=None if from_part else rs, partial=pt if from_part else None,
                                        slots=S if from_part else 0, rowstats_ws=rs, act=act, M=rows, wsplit=sp, corr=corr,
-                                       corr_tokens=N if corr is not None else 0)
+                                       corr_tokens=N if (corr is not None or umeans is not None) else 0, colmean_out=umeans,
+                                       colsum_ws=ws["colsum"] if umeans is not None else None)
                 elif from_part:
                     hip.gemm_lnfold_partials(xx, wg, out, c, d, pt, S, rs, act=act, M=rows, tokens=N if heads else 0, heads=self.H if heads else 0)
                 elif heads:
@@ -424,12 +432,14 @@ class HipViT:
                     resid(o, b, "out", x, xlo, part, M, corr=mc(b, "out", o))         # x += out_proj(attn); stats of the new x
                 if not fuse:
                     hip.ln_stats_finalize(part, rstat, M, S, D)
+                # c_fc also emits the per-frame token means of the hidden it writes: c_proj's correction needs no pass of its own over u
+                um = ws["mU"][:F_ * 4 * D].view(F_, 4 * D) if ("pr" in mcorr and self.fused_umeans) else None
                 fold(x, b["wg_fc"], u, b["c_fc"], b["d_fc"], part, rstat, act=hip.ACT_QUICKGELU, from_part=fuse, sp="fc" in split,
-                     corr=mc(b, "fc", x, rstat))
+                     corr=mc(b, "fc", x, rstat), umeans=um)
                 if self.head_blocked:
                     hip.gemm_residual_stats(u, b["w_pr"], x, b["b_pr"], part, M=M)
                 else:
-                    resid(u, b, "pr", x, xlo, part, M, corr=mc(b, "pr", u))           # x += c_proj(gelu(c_fc))
+                    resid(u, b, "pr", x, xlo, part, M, corr=mc(b, "pr", u, means=um))  # x += c_proj(gelu(c_fc))
                 if fuse:
                     in_part = True
                 else:
@@ -741,7 +751,9 @@ class ClipFsarEngine:
         # two HIP streams -- with two independent kernel chains the tail of one chain's kernel is filled by the other chain's next
         # kernel (311 vs 304 episodes/s).  One episode (80 frames) runs as ONE chain since the ViT GEMM has its 192-row tile form
         # (csrc/gemm_vit.hip, MIW = 3: 2.9 rounds of 192-row tiles instead of 2.2 rounds of 256-row ones that cost 3): 272 vs 269.
-        self.dual_frames = 160 if os.environ.get("CFSAR_DUAL_STREAM", "1") != "0" else 0
+        # Opt-in since round 4 (CFSAR_DUAL_STREAM=1): the mirrored harness batches 16 episodes per call by default, and a second kernel on the chip
+        # was the condition under which round 2's stale-lanes fault was most frequent (profiles/r04_fault_audit.md).
+        self.dual_frames = 160 if os.environ.get("CFSAR_DUAL_STREAM", "0") == "1" else 0
         self.dual_min_frames = int(os.environ.get("CFSAR_DUAL_MIN_FRAMES", "81"))
         self._side = None
 

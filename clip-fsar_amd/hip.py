@@ -38,7 +38,7 @@ SIGNATURES = {
     "cfsar_gemm_lnfold_heads": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
     "cfsar_gemm_lnfold_partials": [_c_p] * 6 + [_c_int, ctypes.c_float, _c_p] + [_c_int] * 10 + [_c_p],
     "cfsar_gemm_residual_stats_heads": [_c_p] * 5 + [_c_int] * 6 + [_c_p],
-    "cfsar_gemm_lnfold_hp": [_c_p] * 7 + [_c_int, ctypes.c_float, _c_p] + [_c_int] * 9 + [_c_p, _c_int, _c_p],
+    "cfsar_gemm_lnfold_hp": [_c_p] * 7 + [_c_int, ctypes.c_float, _c_p] + [_c_int] * 9 + [_c_p, _c_int, _c_p, _c_p, _c_p],
     "cfsar_gemm_residual_wide": [_c_p] * 6 + [_c_int] * 7 + [_c_p, _c_int, _c_p],
     "cfsar_frame_col_means": [_c_p, _c_int, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_f16_pair_to_f32": [_c_p, _c_p, _c_p, _c_i64, _c_p],
@@ -262,9 +262,9 @@ def gemm_residual_stats(A, W, x, bias, stats_partial=None, M=None):
 
 
 def gemm_lnfold_hp(x, Wg, out, cvec, dvec, rowstats=None, partial=None, slots=0, rowstats_ws=None, act=ACT_NONE, M=None, eps=1e-5,
-                   wsplit=False, corr=None, corr_tokens=0):
+                   wsplit=False, corr=None, corr_tokens=0, colmean_out=None, colsum_ws=None):
     """fp16 numerics mode's LN-folded GEMM (cfsar_gemm_lnfold_hp): split weights Wg [N, 2K] = [hi | lo] (wsplit) and / or the per-frame
-    low-word correction corr [frames, N] fp32."""
+    low-word correction corr [frames, N] fp32; colmean_out [frames, N] bf16 (+ colsum_ws): per-frame token means of the output."""
     M = x.shape[0] if M is None else M
     K = x.shape[1]
     if Wg.shape[1] != (2 * K if wsplit else K) or out.dtype != torch.float16:
@@ -276,7 +276,8 @@ def gemm_lnfold_hp(x, Wg, out, cvec, dvec, rowstats=None, partial=None, slots=0,
                                       _opt(rowstats, torch.float32, "rowstats"), _opt(partial, torch.float32, "partial"), slots, eps,
                                       _opt(rowstats_ws, torch.float32, "rowstats_ws"), M, Wg.shape[0], K, x.shape[1], Wg.shape[1],
                                       out.shape[-1], act, _code(out.dtype), int(bool(wsplit)), _opt(corr, torch.float32, "corr"),
-                                      int(corr_tokens), _stream()), "cfsar_gemm_lnfold_hp")
+                                      int(corr_tokens), _opt(colmean_out, torch.bfloat16, "colmean_out"),
+                                      _opt(colsum_ws, torch.float16, "colsum_ws"), _stream()), "cfsar_gemm_lnfold_hp")
 
 
 def gemm_residual_wide(A, W, x, x_lo, bias, stats_partial=None, M=None, wsplit=False, corr=None, corr_tokens=0):

@@ -315,3 +315,27 @@ def test_forward_is_bit_stable_run_to_run(episodes):
             ref = (lo.clone(), cl.clone())
         else:
             assert torch.equal(lo, ref[0]) and torch.equal(cl, ref[1]), (it, float((lo - ref[0]).abs().max()))
+
+
+def test_two_stream_small_batch_path_is_opt_in_and_bit_identical(monkeypatch):
+    """CFSAR_DUAL_STREAM=1 runs the support and the query frames of a two-episode call as two concurrent tower forwards (+2 %): opt-in since round 4,
+    and its logits are the bits of the default one-chain path (the towers' results do not depend on what shares the chip)."""
+    from clip_fsar_amd.engine import ClipFsarEngine
+    g = load_golden("cfg2_B16_5w1s_T8")
+    m = g["meta"]
+    a, sd, tt, te, ep0 = case_inputs(m)
+    eps = [ep0, case_inputs(m, episode=m["episode"] + 1)[4]]
+    st = lambda k: torch.stack([e[k] for e in eps]).cuda()
+    args = (st("support_set"), st("target_set"), st("support_labels"), st("real_support_labels"))
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CFSAR_DUAL_STREAM", flag)
+        eng = ClipFsarEngine(a, sd, tt, te, precision="bf16", device="cuda")
+        assert (eng.dual_frames > 0) == (flag == "1")
+        lo, cl = eng.forward(*args, way=m["way"], T=m["T"])
+        torch.cuda.synchronize()
+        outs.append((lo.clone(), cl.clone()))
+    monkeypatch.delenv("CFSAR_DUAL_STREAM")
+    assert ClipFsarEngine(a, sd, tt, te, precision="bf16", device="cuda").dual_frames == 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert maxdiff(outs[0][0][0], g["logits"]) < LOGITS_TOLERANCE["bf16"]

@@ -1099,3 +1099,27 @@ def test_gemm_lnfold_hp_per_frame_correction(hip, frames, tokens, N, K, act):
     # tolerance: fp16 output rounding + the fp16 factors of the correction (std x corr: 2^-11 each of a 1e-2-size term)
     assert e < 6e-4 * scale + 1e-4, (e, scale)
     assert e0 > 5 * e, (e0, e)            # the uncorrected reference is clearly farther away: the correction is really applied
+
+
+@pytest.mark.parametrize("frames,tokens,N,K", [(6, 197, 3072, 768), (80, 197, 3072, 768), (3, 257, 4096, 1024), (1, 197, 768, 768), (33, 130, 512, 256)])
+def test_gemm_lnfold_hp_emits_per_frame_output_means(hip, frames, tokens, N, K):
+    """colmean_out[f] = token mean of the rows the GEMM just wrote for frame f (the c_fc GEMM hands c_proj the means of its operand): equal to
+    the mean of the stored fp16 output up to the fp16 partial sums' rounding; the output itself is unchanged by asking for them."""
+    g = torch.Generator().manual_seed(71)
+    M = frames * tokens
+    x = (torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 2.0) + torch.randn(M, 1, generator=g)).to(torch.float16).cuda()
+    Wg = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.float16).cuda()
+    c, d = Wg.double().sum(1).float(), torch.randn(N, generator=g).cuda()
+    rstat = torch.empty(M, 4, device="cuda")
+    hip.row_stats(x, rstat, M, K)
+    out0 = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    hip.gemm_lnfold(x, Wg, out0, c, d, rstat, act=hip.ACT_QUICKGELU)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
+    um = torch.full((frames, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ws = torch.full(((M // 96 + 2) * 2 * N,), float("nan"), device="cuda", dtype=torch.float16)
+    hip.gemm_lnfold_hp(x, Wg, out, c, d, rowstats=rstat, act=hip.ACT_QUICKGELU, corr_tokens=tokens, colmean_out=um, colsum_ws=ws)
+    assert torch.equal(out, out0)
+    ref = out.float().view(frames, tokens, N).mean(1)
+    assert not torch.isnan(um.float()).any()
+    # bf16 output (2^-9) + fp16 partial sums of up to 128 values
+    assert maxdiff(um.float(), ref) < 6e-3 * max(1.0, float(ref.abs().max())), maxdiff(um.float(), ref)

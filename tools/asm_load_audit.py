@@ -70,6 +70,10 @@ def main(path):
                     if re.match(r"(global|buffer|scratch|flat)_(load|store)", t):
                         vmem_since += 1
                     touched = vregs(t) & dst
+                    # benign: v_mad_u64_u32 used as a 32-bit multiply-add reads the HIGH half of its 64-bit addend as a don't-care
+                    m64 = re.match(r"v_mad_[ui]64_[ui]32 v\[\d+:\d+\], \S+ \S+ \S+ v\[(\d+):(\d+)\]", t.replace(",", ", ").replace("  ", " "))
+                    if m64 and touched == {int(m64.group(2))} and int(m64.group(2)) == int(m64.group(1)) + 1:
+                        touched = set()
                     if touched and not re.match(r"global_load_dword(x\d)? v", t):
                         findings[fn] += 1
                         if len(detail) < 40:
