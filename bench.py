@@ -380,7 +380,7 @@ def run(args):
             b = batches[i % len(batches)]
             logits, _ = eng.forward(b["sup"], b["tgt"], b["sl"], b["rl"], way=WAY, T=T, merge_before=MERGE_BEFORE)
             # A17: per-episode top-1 accuracy (metrics.topks_correct semantics, reference utils/metrics.py:100-138)
-            acc_out[i * B:(i + 1) * B] = (logits.argmax(dim=2) == b["tl"].long()).float().mean(dim=1)
+            hip.episode_top1(logits, b["tl"], acc_out[i * B:(i + 1) * B])
             if i % len(batches) == 0:
                 first_logits["v"] = logits                           # batch 0, kept for the post-run parity check
 

@@ -509,6 +509,34 @@ extern "C" int cfsar_text_match_probs(const float* feats, const float* text_test
     return cfsar_check_launch("cfsar_text_match_probs");
 }
 
+namespace {
+// A17: per-episode top-1 accuracy.  One thread per episode: the first maximum of each query's `way` logits (torch.argmax / topk order) against
+// the query's label.
+__global__ __launch_bounds__(64) void episode_top1_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                          float* __restrict__ acc, int episodes, int Q, int way) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= episodes) return;
+    int hit = 0;
+    for (int q = 0; q < Q; ++q) {
+        const float* l = logits + ((size_t)e * Q + q) * way;
+        int best = 0;
+        float bv = l[0];
+        for (int c = 1; c < way; ++c)
+            if (l[c] > bv) { bv = l[c]; best = c; }
+        hit += (best == (int)labels[(size_t)e * Q + q]);
+    }
+    acc[e] = (float)hit / (float)Q;
+}
+}  // namespace
+
+extern "C" int cfsar_episode_top1(const float* logits, const float* target_labels, float* acc, int episodes, int Q, int way,
+                                  cfsar_stream_t stream) {
+    CFSAR_REQUIRE(logits && target_labels && acc && episodes > 0 && Q > 0 && way > 0, "cfsar_episode_top1: bad arguments");
+    hipLaunchKernelGGL(episode_top1_kernel, dim3((unsigned)((episodes + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), logits,
+                       target_labels, acc, episodes, Q, way);
+    return cfsar_check_launch("cfsar_episode_top1");
+}
+
 extern "C" int cfsar_combine_logits(const float* text_probs, const float* visual_logits, float* out, int n_queries, int way,
                                     float text_coff, cfsar_stream_t stream) {
     CFSAR_REQUIRE(text_probs && visual_logits && out && n_queries > 0 && way > 0, "cfsar_combine_logits: bad arguments");

@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (imported first so that torch's libamdhip64.so.7 is the HIP runtime the library binds to)
 
 F32, BF16, F16 = 0, 1, 2
-ABI_VERSION = 4          # CFSAR_ABI_VERSION of include/clipfsar_hip.h this file's SIGNATURES were written against
+ABI_VERSION = 5          # CFSAR_ABI_VERSION of include/clipfsar_hip.h this file's SIGNATURES were written against
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -63,6 +63,7 @@ SIGNATURES = {
     "cfsar_prototypes": [_c_p, _c_p, _c_p] + [_c_int] * 7 + [_c_p],
     "cfsar_text_match_probs": [_c_p] * 6 + [_c_int] * 7 + [_c_p],
     "cfsar_combine_logits": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p],
+    "cfsar_episode_top1": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_cos_otam_logits": [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 5 + [_c_f, _c_int, _c_p],
 }
 
@@ -414,6 +415,13 @@ def cos_otam_logits(Xq, protos, logits, B, Q, way, T, E, lbda=0.5, single_direct
                                        _dev(logits, torch.float32, "logits"), _opt(dists_out, torch.float32, "dists_out"),
                                        B, Q, way, T, E, float(lbda), int(bool(single_direct)), _stream()),
            "cfsar_cos_otam_logits")
+
+
+def episode_top1(logits, target_labels, acc):
+    """acc[e] = top-1 accuracy of episode e (logits [E, Q, way], target_labels [E, Q] float class indices)."""
+    E, Q, way = logits.shape
+    _check(lib().cfsar_episode_top1(_dev(logits, torch.float32, "logits"), _dev(target_labels, torch.float32, "target_labels"),
+                                    _dev(acc, torch.float32, "acc"), E, Q, way, _stream()), "cfsar_episode_top1")
 
 
 def text_match_probs(feats, text_test, support_labels, real_support_labels, scale, probs, B, S, Q, T, E, way):

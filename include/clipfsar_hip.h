@@ -46,7 +46,7 @@ typedef void* cfsar_stream_t;
 int cfsar_version(void);
 /* ABI revision: bumped whenever an exported signature changes or is added; a binding compares it with the CFSAR_ABI_VERSION it was
  * written against at load time (clip-fsar_amd/hip.py does) instead of calling through a stale prototype. */
-#define CFSAR_ABI_VERSION 4
+#define CFSAR_ABI_VERSION 5
 int cfsar_abi_version(void);
 const char* cfsar_last_error(void);
 
@@ -203,6 +203,11 @@ int cfsar_prototypes(const float* Xs, const float* support_labels, float* protos
  * logits [B, Q, way]; dists_out (optional, may be NULL) [B, Q, way, T, T].  T <= 32, E % 4 == 0, E <= 2048. */
 int cfsar_cos_otam_logits(const float* Xq, const float* protos, float* logits, float* dists_out, int B, int Q,
                           int way, int T, int E, float lambda, int single_direct, cfsar_stream_t stream);
+
+/* ---- A17 per-episode top-1 accuracy (utils/metrics.py:100-138 topks_correct with k = 1, per episode as runs/test_net_few_shot.py:120-147
+ * uses it): acc[e] = fraction of episode e's Q queries whose first-maximum class equals target_labels[e, q] (class index as float).
+ * logits [episodes, Q, way] f32, target_labels [episodes, Q] f32, acc [episodes] f32. */
+int cfsar_episode_top1(const float* logits, const float* target_labels, float* acc, int episodes, int Q, int way, cfsar_stream_t stream);
 
 /* ---- A3 + A5/A6 fused: LayerNorm folded into the GEMM that consumes it (few_shot.py:605-611 with :626-628 / :636-640).
  * out[m,n] = act(sum_k LN(x)[m,k] W[n,k] + bias[n]) computed on the RAW fp16 residual stream, without materialising LN(x):

@@ -1123,3 +1123,15 @@ def test_gemm_lnfold_hp_emits_per_frame_output_means(hip, frames, tokens, N, K):
     assert not torch.isnan(um.float()).any()
     # bf16 output (2^-9) + fp16 partial sums of up to 128 values
     assert maxdiff(um.float(), ref) < 6e-3 * max(1.0, float(ref.abs().max())), maxdiff(um.float(), ref)
+
+
+def test_episode_top1(hip):
+    g = torch.Generator().manual_seed(3)
+    E, Q, way = 37, 5, 5
+    logits = torch.randn(E, Q, way, generator=g).cuda()
+    logits[3, 2, :] = 1.0                                   # a tie: the first maximum counts (torch.argmax order)
+    labels = torch.randint(0, way, (E, Q), generator=g).float().cuda()
+    acc = torch.full((E,), float("nan"), device="cuda")
+    hip.episode_top1(logits, labels, acc)
+    ref = (logits.argmax(dim=2) == labels.long()).float().mean(dim=1)
+    assert torch.equal(acc, ref)
