@@ -219,7 +219,7 @@ def golden_parity(logits0, precision):
             "north_star_tolerance": NORTH_STAR_TOLERANCE, "meets_north_star": bool(d < NORTH_STAR_TOLERANCE),
             "tolerance": tol, "within_tolerance": bool(d < tol),
             "tolerance_note": "this mode's own regression bound on the full-size configurations (2 x the measured deviation, "
-                              "profiles/r03_parity_table.md); the north-star bound is 1e-3"}
+                              "profiles/r04_parity_table.md); the north-star bound is 1e-3"}
 
 
 def parse_args(argv=None):

@@ -49,7 +49,7 @@ class HipViT:
         # compute dtype of the 16-bit modes: bf16 = throughput mode; fp16 = the same kernels on IEEE half operands everywhere (weights,
         # patches, q / k / v, attention probabilities and output, MLP hidden): 3 more mantissa bits for ~3-6 % of the throughput (the
         # fp16 multipliers toggle more bits: the chip runs these kernels power-limited) -- the 16-bit mode that meets the 1e-3 logits
-        # tolerance (profiles/r03_parity_table.md).  Range: |x| < 65 504; checked for the weights below, the LN-fold guard covers the
+        # tolerance (profiles/r04_parity_table.md).  Range: |x| < 65 504; checked for the weights below, the LN-fold guard covers the
         # folded vectors, activations of CLIP-scale weights are O(1) ... O(100).
         self.cd = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[precision]
         # residual stream: fp32 in the validation mode.  The bf16 mode keeps it in IEEE fp16, as CLIP's own GPU path does

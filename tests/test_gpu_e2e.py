@@ -338,4 +338,4 @@ def test_two_stream_small_batch_path_is_opt_in_and_bit_identical(monkeypatch):
     monkeypatch.delenv("CFSAR_DUAL_STREAM")
     assert ClipFsarEngine(a, sd, tt, te, precision="bf16", device="cuda").dual_frames == 0
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert maxdiff(outs[0][0][0], g["logits"]) < LOGITS_TOLERANCE["bf16"]
+    assert maxdiff(outs[0][0][0].cpu(), g["logits"]) < LOGITS_TOLERANCE["bf16"]

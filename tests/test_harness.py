@@ -370,7 +370,8 @@ def test_test_epoch_with_pinned_host_inputs_keeps_up_with_resident_inputs():
     runs_host = [timed(_Steps(host)) for _ in range(3)]
     (t_res, r_res), (t_host, r_host) = min(runs_res, key=lambda r: r[0]), min(runs_host, key=lambda r: r[0])   # best of 3 each
     assert r_host["episodes"] == B * steps and abs(r_host["top1_acc"] - r_res["top1_acc"]) < 1e-6
-    assert t_res / t_host >= 0.95, "host-input harness %.1f episodes/s vs resident %.1f" % (B * steps / t_host, B * steps / t_res)
+    # measured 0.970-0.976 (round 3) ... 0.949 (one round-4 box, slower host link): the bound guards the overlap (serial uploads: 0.75), not the box
+    assert t_res / t_host >= 0.92, "host-input harness %.1f episodes/s vs resident %.1f" % (B * steps / t_host, B * steps / t_res)
 
 
 @gpu
