@@ -193,11 +193,47 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
     typedef _Float16 cs_h8 __attribute__((ext_vector_type(8)));
     cs_h8 cs0 = {0, 0, 0, 0, 0, 0, 0, 0}, cs1 = {0, 0, 0, 0, 0, 0, 0, 0};
     int cs_bnd = 0;
-    if constexpr (COLSUM) {
-        if (p.colsum != nullptr) cs_bnd = (mb / p.corr_tokens + 1) * p.corr_tokens - mb;      // rows of this wave tile in its first frame
-    }
     const bool colok = FULL || nb + 64 <= p.N;              // whole-wave predicate (N % 64 == 0)
     const int ncl = colok ? nb : p.N - 64;                  // clamped column base: loads stay in bounds
+    // (sums are emitted per 32-ROW GROUP -- one epilogue pass -- so that they do not depend on the tile form: 96- and 128-row wave tiles are
+    // both whole groups; slot 0 = the frame of the group's first row, slot 1 = the next frame)
+    auto colsum_begin = [&](int mi) __attribute__((always_inline)) {
+        if constexpr (COLSUM) {
+            if (p.colsum != nullptr) {
+                const int g0 = mb + 32 * mi;
+                cs_bnd = (g0 / p.corr_tokens + 1) * p.corr_tokens - g0;
+            }
+        }
+    };
+    auto colsum_flush = [&](int mi) __attribute__((always_inline)) {
+        if constexpr (COLSUM) {
+            if (p.colsum != nullptr) {
+                // sum over the 8 row groups rr (lanes differing in bits 3, 4, 5) in packed fp16: row_ror:8, swizzle xor 16, bpermute xor 32
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                u32x4 a0 = __builtin_bit_cast(u32x4, cs0), a1 = __builtin_bit_cast(u32x4, cs1);
+                auto add2 = [](unsigned u, unsigned v) __attribute__((always_inline)) -> unsigned {
+                    return __builtin_bit_cast(unsigned, (h2)(__builtin_bit_cast(h2, u) + __builtin_bit_cast(h2, v)));
+                };
+                const int partner = (lane ^ 32) << 2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a0[j] = add2(a0[j], (unsigned)__builtin_amdgcn_update_dpp(0, (int)a0[j], 0x128, 0xF, 0xF, false));
+                    a1[j] = add2(a1[j], (unsigned)__builtin_amdgcn_update_dpp(0, (int)a1[j], 0x128, 0xF, 0xF, false));
+                    a0[j] = add2(a0[j], (unsigned)__builtin_amdgcn_ds_swizzle((int)a0[j], 0x401F));
+                    a1[j] = add2(a1[j], (unsigned)__builtin_amdgcn_ds_swizzle((int)a1[j], 0x401F));
+                    a0[j] = add2(a0[j], (unsigned)__builtin_amdgcn_ds_bpermute(partner, (int)a0[j]));
+                    a1[j] = add2(a1[j], (unsigned)__builtin_amdgcn_ds_bpermute(partner, (int)a1[j]));
+                }
+                if (rr == 0 && colok && mb + 32 * mi < p.M) {
+                    char* dst = reinterpret_cast<char*>(p.colsum) + (((size_t)((mb >> 5) + mi) * 2) * p.N + ncl + 8 * Q) * 2;
+                    *reinterpret_cast<u32x4*>(dst) = a0;
+                    *reinterpret_cast<u32x4*>(dst + (size_t)p.N * 2) = a1;
+                }
+                cs0 = cs_h8{0, 0, 0, 0, 0, 0, 0, 0};
+                cs1 = cs_h8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    };
     char* wr = slab + lr * 128;
     const int wsw = lr & 15;
     const bool swap_halves = rr & 1;
@@ -343,7 +379,7 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
             if (p.colsum != nullptr) {                       // kernel-uniform
                 const cs_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                 const cs_h8 xv = rowok ? __builtin_bit_cast(cs_h8, x) : z;
-                const bool in0 = rr + (mi * 4 + it) * 8 < cs_bnd;
+                const bool in0 = rr + it * 8 < cs_bnd;
                 cs0 += in0 ? xv : z;
                 cs1 += in0 ? z : xv;
             }
@@ -392,41 +428,12 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
         for (int q = 0; q < 8; ++q) convert_group(mi, q, gk, gsd);
         u32x4 d[4];
         read_back(d);
+        colsum_begin(mi);
 #pragma unroll
         for (int it = 0; it < 4; ++it) finish(mi, it, d[it], rv[it]);
+        colsum_flush(mi);
     }
 #endif
-    if constexpr (COLSUM) {
-        if (p.colsum != nullptr) {
-            // sum over the 8 row groups rr (lanes differing in bits 3, 4, 5) in packed fp16: row_ror:8, swizzle xor 16, bpermute xor 32
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            u32x4 a0 = __builtin_bit_cast(u32x4, cs0), a1 = __builtin_bit_cast(u32x4, cs1);
-            auto add2 = [](unsigned u, unsigned v) __attribute__((always_inline)) -> unsigned {
-                return __builtin_bit_cast(unsigned, (h2)(__builtin_bit_cast(h2, u) + __builtin_bit_cast(h2, v)));
-            };
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a0[j] = add2(a0[j], (unsigned)__builtin_amdgcn_update_dpp(0, (int)a0[j], 0x128, 0xF, 0xF, false));
-                a1[j] = add2(a1[j], (unsigned)__builtin_amdgcn_update_dpp(0, (int)a1[j], 0x128, 0xF, 0xF, false));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a0[j] = add2(a0[j], (unsigned)__builtin_amdgcn_ds_swizzle((int)a0[j], 0x401F));
-                a1[j] = add2(a1[j], (unsigned)__builtin_amdgcn_ds_swizzle((int)a1[j], 0x401F));
-            }
-            const int partner = (lane ^ 32) << 2;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a0[j] = add2(a0[j], (unsigned)__builtin_amdgcn_ds_bpermute(partner, (int)a0[j]));
-                a1[j] = add2(a1[j], (unsigned)__builtin_amdgcn_ds_bpermute(partner, (int)a1[j]));
-            }
-            if (rr == 0 && colok && mb < p.M) {
-                char* dst = reinterpret_cast<char*>(p.colsum) + (((size_t)(mb / (32 * NMI)) * 2) * p.N + ncl + 8 * Q) * 2;
-                *reinterpret_cast<u32x4*>(dst) = a0;
-                *reinterpret_cast<u32x4*>(dst + (size_t)p.N * 2) = a1;
-            }
-        }
-    }
 }
 
 // ---- MODE 6 epilogue ("wide" residual; the fp16 numerics mode, round 4).  What differs from epilogue_rows<HAS_RES>: the GEMM result is
@@ -631,6 +638,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     constexpr bool CORR = std::is_same<TO, _Float16>::value && std::is_same<TI, _Float16>::value && (MODE == 2 || MODE == 6);
     float tcq[2] = {0.f, 0.f};           // corr[f0 + hi][column 32 ni + lr]
     int corr_bnd = 0;                    // rows of the wave's tile that belong to frame f0 (the others: f0 + 1)
+    int corr_par = 0;                    // parity of f0
     float rscale[4] = {1.f, 1.f, 1.f, 1.f};
     auto asm_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
         float v;
@@ -648,7 +656,10 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                 const int r0 = m0_ + wm * WR;                          // first row of the wave's tile (wave-uniform)
                 const int f0 = r0 / p.corr_tokens;
                 corr_bnd = (f0 + 1) * p.corr_tokens - r0;
-                int f = f0 + hi;
+                corr_par = f0 & 1;
+                // the k slot of the lanes with hi == h serves the frame of PARITY h among {f0, f0 + 1}: which slot a row's correction sits in
+                // depends on the row alone, not on the tile it falls into (192- and 256-row tile forms give the same bits)
+                int f = ((f0 & 1) == hi) ? f0 : f0 + 1;
                 const int fl = (p.M - 1) / p.corr_tokens;
                 f = f < fl ? f : fl;
 #pragma unroll
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             for (int mi = 0; mi < MIW; ++mi) {
                 if constexpr (CORR) {
                     const bool in0 = mi * 32 + lr < corr_bnd;
-                    const TI ind = (TI)((p.corr != nullptr && (hi ? !in0 : in0)) ? 1.f : 0.f);
+                    const TI ind = (TI)((p.corr != nullptr && ((in0 ? corr_par : corr_par ^ 1) == hi)) ? 1.f : 0.f);
                     ones = TI8{one, one, one, ind, 0, 0, 0, 0};
                 }
 #pragma unroll
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                 if constexpr (CORR) {
                     // the accumulator is divided by std in the epilogue: the correction (normalised units) enters multiplied by it
                     const bool in0 = mi * 32 + lr < corr_bnd;
-                    sdh = (_Float16)((p.corr != nullptr && (hi ? !in0 : in0)) ? __builtin_amdgcn_rcpf(tl[6 + mi]) : 0.f);
+                    sdh = (_Float16)((p.corr != nullptr && ((in0 ? corr_par : corr_par ^ 1) == hi)) ? __builtin_amdgcn_rcpf(tl[6 + mi]) : 0.f);
                 }
                 mx[mi] = f16x8{h, l, h, sdh, 0, 0, 0, 0};
                 rscale[mi] = tl[6 + mi];
@@ -1307,7 +1318,7 @@ static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const floa
         const int frames = (M + corr_tokens - 1) / corr_tokens;
         hipLaunchKernelGGL(frame_means_from_colsums_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)frames), dim3(256), 0,
                            static_cast<hipStream_t>(stream), static_cast<const _Float16*>(colsum_ws), static_cast<__bf16*>(colmean_out),
-                           32 * miw_used, corr_tokens, N);
+                           32, corr_tokens, N);
         return cfsar_check_launch("cfsar_gemm_lnfold_hp(frame means)");
     }
     return rc == -2 ? cfsar_fail("cfsar_gemm_lnfold: operands too large for 32-bit offsets") : rc;

@@ -339,3 +339,19 @@ def test_two_stream_small_batch_path_is_opt_in_and_bit_identical(monkeypatch):
     assert ClipFsarEngine(a, sd, tt, te, precision="bf16", device="cuda").dual_frames == 0
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert maxdiff(outs[0][0][0].cpu(), g["logits"]) < LOGITS_TOLERANCE["bf16"]
+
+
+def test_fp16_mode_b16_equals_b1():
+    """An episode's fp16-mode logits do not depend on the batch it is served in: the per-frame correction's k slot is chosen by the FRAME's
+    parity (not by the tile a row falls into) and c_fc's per-frame means are summed per 32-row group (not per wave tile), so the 192- and
+    256-row tile forms the launcher picks by batch size give the same tower bits; the fp32 tail differs by its GEMM's summation order only."""
+    g = load_golden("cfg2_B16_5w1s_T8")
+    m = g["meta"]
+    a, sd, tt, te, ep0 = case_inputs(m)
+    eps = [ep0] + [case_inputs(m, episode=m["episode"] + e)[4] for e in range(1, 16)]
+    l16, c16 = run_engine(m, a, sd, tt, te, eps, "fp16")
+    assert maxdiff(l16[0], g["logits"]) < NORTH_STAR_TOLERANCE
+    for i in (0, 7, 15):
+        l1, c1 = run_engine(m, a, sd, tt, te, [eps[i]], "fp16")
+        assert maxdiff(l16[i], l1[0]) <= 4e-6, (i, maxdiff(l16[i], l1[0]))
+        assert maxdiff(c16[i], c1[0]) <= 4e-6, i

@@ -1116,7 +1116,7 @@ def test_gemm_lnfold_hp_emits_per_frame_output_means(hip, frames, tokens, N, K):
     hip.gemm_lnfold(x, Wg, out0, c, d, rstat, act=hip.ACT_QUICKGELU)
     out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
     um = torch.full((frames, N), float("nan"), device="cuda", dtype=torch.bfloat16)
-    ws = torch.full(((M // 96 + 2) * 2 * N,), float("nan"), device="cuda", dtype=torch.float16)
+    ws = torch.full(((M // 32 + 2) * 2 * N,), float("nan"), device="cuda", dtype=torch.float16)
     hip.gemm_lnfold_hp(x, Wg, out, c, d, rowstats=rstat, act=hip.ACT_QUICKGELU, corr_tokens=tokens, colmean_out=um, colsum_ws=ws)
     assert torch.equal(out, out0)
     ref = out.float().view(frames, tokens, N).mean(1)

@@ -62,6 +62,16 @@ def make_tower(s):
             return A @ Wh.t() + (A.mean(1, keepdim=True) @ (W32 - Wh).half().float().t())
         return A @ rnd(W32, kind).t()
 
+    def mm_ln(xi, mu, var, Wg32, kind):
+        """LN-folded GEMM.  kind 'r': low word applied to the per-frame mean of the RAW stream (what the producer GEMM can emit as column sums),
+        the row mean's share handled exactly:  xhat W_lo ~ (mean_t(x) W_lo - mu_t c_lo) / sigma_t"""
+        sd_ = torch.sqrt(var + 1e-5)
+        if kind == "r":
+            Wh = Wg32.half().float()
+            Wl = (Wg32 - Wh).half().float()
+            return ((xi - mu) / sd_) @ Wh.t() + (xi.mean(1, keepdim=True) @ Wl.t() - mu * Wl.sum(1)) / sd_
+        return mm((xi - mu) / sd_, Wg32, kind)
+
     def tower(frames, sd, arch, prefix="backbone.", chunk=40):
         outs = []
         g = lambda n: sd[prefix + n]
@@ -83,7 +93,7 @@ def make_tower(s):
                 xi = feed(x)
                 gam, bet = g(b + "ln_1.weight"), g(b + "ln_1.bias")
                 mu, var = xi.mean(-1, keepdim=True), xi.var(-1, unbiased=False, keepdim=True)
-                qkv = mm((xi - mu) / torch.sqrt(var + 1e-5), g(b + "attn.in_proj_weight") * gam[None, :], wqkv) + (g(b + "attn.in_proj_weight") @ bet + g(b + "attn.in_proj_bias"))
+                qkv = mm_ln(xi, mu, var, g(b + "attn.in_proj_weight") * gam[None, :], wqkv) + (g(b + "attn.in_proj_weight") @ bet + g(b + "attn.in_proj_bias"))
                 qkv = rnd(qkv, kq)
                 q, k, v = qkv.split(D, -1)
                 q = q.reshape(F_, N, heads, hd).transpose(1, 2); k = k.reshape(F_, N, heads, hd).transpose(1, 2)
@@ -96,7 +106,7 @@ def make_tower(s):
                 xi = feed(x)
                 gam, bet = g(b + "ln_2.weight"), g(b + "ln_2.bias")
                 mu, var = xi.mean(-1, keepdim=True), xi.var(-1, unbiased=False, keepdim=True)
-                u = mm((xi - mu) / torch.sqrt(var + 1e-5), g(b + "mlp.c_fc.weight") * gam[None, :], wfc) + (g(b + "mlp.c_fc.weight") @ bet + g(b + "mlp.c_fc.bias"))
+                u = mm_ln(xi, mu, var, g(b + "mlp.c_fc.weight") * gam[None, :], wfc) + (g(b + "mlp.c_fc.weight") @ bet + g(b + "mlp.c_fc.bias"))
                 u = rnd(orc.quick_gelu(u), ku)
                 x = store(x + delta(mm(u, g(b + "mlp.c_proj.weight"), wpr) + g(b + "mlp.c_proj.bias")))
             c = orc.layer_norm(x[:, 0, :], g("ln_post.weight"), g("ln_post.bias"))
