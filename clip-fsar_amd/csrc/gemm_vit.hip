@@ -190,50 +190,17 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
     const int rr = lane >> 3, Q = lane & 7;
     // per-frame column sums of the stored output (VitGemmArgs::colsum): the fp16 LN-folded QuickGELU instance only
     constexpr bool COLSUM = std::is_same<TO, _Float16>::value && ACT == CFSAR_ACT_QUICKGELU && ROWSCALE && !HAS_RES && !HB;
+    // The sums are taken in FIXED POINT (int32, 2^-12 units; |value| clamped to 1 000): integer addition is associative, so a frame's sum does
+    // not depend on how its rows fall into tiles, wave tiles or lanes -- an episode's result stays bit-identical whatever batch it is served
+    // in (fp16 / fp32 partial sums regroup with the frame's row offset, and ONE flipped bit anywhere re-draws the whole tower's rounding noise).
     typedef _Float16 cs_h8 __attribute__((ext_vector_type(8)));
-    cs_h8 cs0 = {0, 0, 0, 0, 0, 0, 0, 0}, cs1 = {0, 0, 0, 0, 0, 0, 0, 0};
+    int cs0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int cs_bnd = 0;
+    if constexpr (COLSUM) {
+        if (p.colsum != nullptr) cs_bnd = (mb / p.corr_tokens + 1) * p.corr_tokens - mb;      // rows of this wave tile in its first frame
+    }
     const bool colok = FULL || nb + 64 <= p.N;              // whole-wave predicate (N % 64 == 0)
     const int ncl = colok ? nb : p.N - 64;                  // clamped column base: loads stay in bounds
-    // (sums are emitted per 32-ROW GROUP -- one epilogue pass -- so that they do not depend on the tile form: 96- and 128-row wave tiles are
-    // both whole groups; slot 0 = the frame of the group's first row, slot 1 = the next frame)
-    auto colsum_begin = [&](int mi) __attribute__((always_inline)) {
-        if constexpr (COLSUM) {
-            if (p.colsum != nullptr) {
-                const int g0 = mb + 32 * mi;
-                cs_bnd = (g0 / p.corr_tokens + 1) * p.corr_tokens - g0;
-            }
-        }
-    };
-    auto colsum_flush = [&](int mi) __attribute__((always_inline)) {
-        if constexpr (COLSUM) {
-            if (p.colsum != nullptr) {
-                // sum over the 8 row groups rr (lanes differing in bits 3, 4, 5) in packed fp16: row_ror:8, swizzle xor 16, bpermute xor 32
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                u32x4 a0 = __builtin_bit_cast(u32x4, cs0), a1 = __builtin_bit_cast(u32x4, cs1);
-                auto add2 = [](unsigned u, unsigned v) __attribute__((always_inline)) -> unsigned {
-                    return __builtin_bit_cast(unsigned, (h2)(__builtin_bit_cast(h2, u) + __builtin_bit_cast(h2, v)));
-                };
-                const int partner = (lane ^ 32) << 2;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    a0[j] = add2(a0[j], (unsigned)__builtin_amdgcn_update_dpp(0, (int)a0[j], 0x128, 0xF, 0xF, false));
-                    a1[j] = add2(a1[j], (unsigned)__builtin_amdgcn_update_dpp(0, (int)a1[j], 0x128, 0xF, 0xF, false));
-                    a0[j] = add2(a0[j], (unsigned)__builtin_amdgcn_ds_swizzle((int)a0[j], 0x401F));
-                    a1[j] = add2(a1[j], (unsigned)__builtin_amdgcn_ds_swizzle((int)a1[j], 0x401F));
-                    a0[j] = add2(a0[j], (unsigned)__builtin_amdgcn_ds_bpermute(partner, (int)a0[j]));
-                    a1[j] = add2(a1[j], (unsigned)__builtin_amdgcn_ds_bpermute(partner, (int)a1[j]));
-                }
-                if (rr == 0 && colok && mb + 32 * mi < p.M) {
-                    char* dst = reinterpret_cast<char*>(p.colsum) + (((size_t)((mb >> 5) + mi) * 2) * p.N + ncl + 8 * Q) * 2;
-                    *reinterpret_cast<u32x4*>(dst) = a0;
-                    *reinterpret_cast<u32x4*>(dst + (size_t)p.N * 2) = a1;
-                }
-                cs0 = cs_h8{0, 0, 0, 0, 0, 0, 0, 0};
-                cs1 = cs_h8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-        }
-    };
     char* wr = slab + lr * 128;
     const int wsw = lr & 15;
     const bool swap_halves = rr & 1;
@@ -377,11 +344,16 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
         if (FULL || (rowok && colok)) store16<STORE>(out_addr(mi * 4 + it), x);
         if constexpr (COLSUM) {
             if (p.colsum != nullptr) {                       // kernel-uniform
-                const cs_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                const cs_h8 xv = rowok ? __builtin_bit_cast(cs_h8, x) : z;
-                const bool in0 = rr + it * 8 < cs_bnd;
-                cs0 += in0 ? xv : z;
-                cs1 += in0 ? z : xv;
+                const cs_h8 xv = __builtin_bit_cast(cs_h8, x);
+                const bool in0 = rr + (mi * 4 + it) * 8 < cs_bnd;
+                constexpr float kMagic = 1.5f * 2048.0f;             // ulp of (v + 1.5 x 2^11) = 2^-12 for |v| < 2^10: its low mantissa bits ARE v in fixed point
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = __builtin_amdgcn_fmed3f((float)xv[j], -1000.0f, 1000.0f);
+                    const int q = rowok ? __builtin_bit_cast(int, v + kMagic) - __builtin_bit_cast(int, kMagic) : 0;
+                    cs0[j] += in0 ? q : 0;
+                    cs1[j] += in0 ? 0 : q;
+                }
             }
         }
     };
@@ -428,12 +400,32 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
         for (int q = 0; q < 8; ++q) convert_group(mi, q, gk, gsd);
         u32x4 d[4];
         read_back(d);
-        colsum_begin(mi);
 #pragma unroll
         for (int it = 0; it < 4; ++it) finish(mi, it, d[it], rv[it]);
-        colsum_flush(mi);
     }
 #endif
+    if constexpr (COLSUM) {
+        if (p.colsum != nullptr) {
+            // sum over the 8 row groups rr (lanes differing in bits 3, 4, 5): row_ror:8, swizzle xor 16, bpermute xor 32 (integer adds: any order)
+            const int partner = (lane ^ 32) << 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                cs0[j] += __builtin_amdgcn_update_dpp(0, cs0[j], 0x128, 0xF, 0xF, false);
+                cs1[j] += __builtin_amdgcn_update_dpp(0, cs1[j], 0x128, 0xF, 0xF, false);
+                cs0[j] += __builtin_amdgcn_ds_swizzle(cs0[j], 0x401F);
+                cs1[j] += __builtin_amdgcn_ds_swizzle(cs1[j], 0x401F);
+                cs0[j] += __builtin_amdgcn_ds_bpermute(partner, cs0[j]);
+                cs1[j] += __builtin_amdgcn_ds_bpermute(partner, cs1[j]);
+            }
+            if (rr == 0 && colok && mb < p.M) {
+                int* dst = reinterpret_cast<int*>(p.colsum) + ((size_t)(mb / (32 * NMI)) * 2) * p.N + ncl + 8 * Q;
+                *reinterpret_cast<u32x4*>(dst) = u32x4{(unsigned)cs0[0], (unsigned)cs0[1], (unsigned)cs0[2], (unsigned)cs0[3]};
+                *reinterpret_cast<u32x4*>(dst + 4) = u32x4{(unsigned)cs0[4], (unsigned)cs0[5], (unsigned)cs0[6], (unsigned)cs0[7]};
+                *reinterpret_cast<u32x4*>(dst + p.N) = u32x4{(unsigned)cs1[0], (unsigned)cs1[1], (unsigned)cs1[2], (unsigned)cs1[3]};
+                *reinterpret_cast<u32x4*>(dst + p.N + 4) = u32x4{(unsigned)cs1[4], (unsigned)cs1[5], (unsigned)cs1[6], (unsigned)cs1[7]};
+            }
+        }
+    }
 }
 
 // ---- MODE 6 epilogue ("wide" residual; the fp16 numerics mode, round 4).  What differs from epilogue_rows<HAS_RES>: the GEMM result is
@@ -1271,19 +1263,19 @@ extern "C" void cfsar_debug_set_vit_trace(void* trace, int stagger_unit) { g_tra
 #endif
 
 namespace {
-// per-frame token means of the GEMM's OUTPUT from the wave tiles' per-frame column sums (VitGemmArgs::colsum): frame f covers rows
-// [f T, (f + 1) T) = the wave tiles b0 .. b1 of `wr` rows; tile b contributes its slot f - (b wr) / T (0 or 1).  Fixed summation order.
-__global__ __launch_bounds__(256) void frame_means_from_colsums_kernel(const _Float16* __restrict__ cs, __bf16* __restrict__ out, int wr,
+// per-frame token means of the GEMM's OUTPUT from the wave tiles' per-frame column sums (VitGemmArgs::colsum, int32 fixed point): frame f
+// covers rows [f T, (f + 1) T) = the wave tiles b0 .. b1 of `wr` rows; tile b contributes its slot f - (b wr) / T (0 or 1).
+__global__ __launch_bounds__(256) void frame_means_from_colsums_kernel(const int* __restrict__ cs, __bf16* __restrict__ out, int wr,
                                                                        int tokens, int N) {
     const int f = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const int r0 = f * tokens, r1 = r0 + tokens - 1;
-    float s = 0.f;
+    long long s = 0;                                        // fixed point, 2^-12 units: exact, order-free
     for (int b = r0 / wr; b <= r1 / wr; ++b) {
         const int j = f - (b * wr) / tokens;
-        if (j == 0 || j == 1) s += (float)cs[((size_t)b * 2 + j) * N + n];
+        if (j == 0 || j == 1) s += cs[((size_t)b * 2 + j) * N + n];
     }
-    out[(size_t)f * N + n] = (__bf16)(s / (float)tokens);
+    out[(size_t)f * N + n] = (__bf16)((float)s * (1.0f / 4096.0f) / (float)tokens);
 }
 }  // namespace
 
@@ -1317,8 +1309,8 @@ static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const floa
     if (rc == 0 && colmean_out) {
         const int frames = (M + corr_tokens - 1) / corr_tokens;
         hipLaunchKernelGGL(frame_means_from_colsums_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)frames), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), static_cast<const _Float16*>(colsum_ws), static_cast<__bf16*>(colmean_out),
-                           32, corr_tokens, N);
+                           static_cast<hipStream_t>(stream), static_cast<const int*>(colsum_ws), static_cast<__bf16*>(colmean_out),
+                           32 * miw_used, corr_tokens, N);
         return cfsar_check_launch("cfsar_gemm_lnfold_hp(frame means)");
     }
     return rc == -2 ? cfsar_fail("cfsar_gemm_lnfold: operands too large for 32-bit offsets") : rc;

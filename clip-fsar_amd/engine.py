@@ -239,7 +239,7 @@ class HipViT:
                 ws["rstat"] = torch.empty(M, 4, device=dev, dtype=torch.float32)            # (mean, std, 1/std, -)
             # class-token rows of the last block (prune_last): [F, .]
             if self.mcorr:
-                ws["colsum"] = torch.empty((M // 32 + 2) * 2 * 4 * D, device=dev, dtype=torch.float16)   # c_fc's per-32-row-group column sums
+                ws["colsum"] = torch.empty((M // 96 + 2) * 2 * 4 * D, device=dev, dtype=torch.int32)   # c_fc's per-wave-tile column sums (fixed point)
                 ws["mU"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.bfloat16)         # per-frame token means of the MLP hidden
                 ws["mA"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.bfloat16)         # per-frame token means of a GEMM operand
                 ws["corr"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.float32)        # ... x W_lo^T

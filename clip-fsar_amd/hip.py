@@ -278,7 +278,7 @@ def gemm_lnfold_hp(x, Wg, out, cvec, dvec, rowstats=None, partial=None, slots=0,
                                       _opt(rowstats_ws, torch.float32, "rowstats_ws"), M, Wg.shape[0], K, x.shape[1], Wg.shape[1],
                                       out.shape[-1], act, _code(out.dtype), int(bool(wsplit)), _opt(corr, torch.float32, "corr"),
                                       int(corr_tokens), _opt(colmean_out, torch.bfloat16, "colmean_out"),
-                                      _opt(colsum_ws, torch.float16, "colsum_ws"), _stream()), "cfsar_gemm_lnfold_hp")
+                                      _opt(colsum_ws, torch.int32, "colsum_ws"), _stream()), "cfsar_gemm_lnfold_hp")
 
 
 def gemm_residual_wide(A, W, x, x_lo, bias, stats_partial=None, M=None, wsplit=False, corr=None, corr_tokens=0):

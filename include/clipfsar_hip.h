@@ -267,7 +267,8 @@ int cfsar_gemm_residual_stats_heads(const void* A, const void* W, void* x, const
  * either finalized (rowstats [M, 4], partial = NULL) or the producer's partials (partial [M, slots, 2], rowstats = NULL, rowstats_ws
  * [M, 4] as in cfsar_gemm_lnfold_partials).  corr [ceil(M / corr_tokens), N] fp32 or NULL.  colmean_out (act = QUICKGELU only; NULL = off):
  * receives the per-frame token means of the OUTPUT, [ceil(M / corr_tokens), N] bf16 -- the c_fc GEMM hands the next GEMM (c_proj) the
- * means its own correction needs without another pass over the hidden; colsum_ws: workspace of (M / 32 + 2) x 2 x N fp16.
+ * means its own correction needs without another pass over the hidden; colsum_ws: workspace of (M / 96 + 2) x 2 x N int32 (the sums are taken in fixed point: an episode's
+ * result does not depend on the batch it is served in).
  * cfsar_gemm_residual_wide: x = x + A W^T + bias, A [M, lda] fp16, W [N, ldw] fp16 (wsplit = 0) or [N, ldw >= 2 K] split (wsplit = 1),
  * x_hi [M, ldx] fp16 in place, x_lo [M, ldx] fp16 in place or NULL; stats_partial as in cfsar_gemm_residual_stats (of the new x_hi);
  * corr as above. */

@@ -1116,13 +1116,13 @@ def test_gemm_lnfold_hp_emits_per_frame_output_means(hip, frames, tokens, N, K):
     hip.gemm_lnfold(x, Wg, out0, c, d, rstat, act=hip.ACT_QUICKGELU)
     out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
     um = torch.full((frames, N), float("nan"), device="cuda", dtype=torch.bfloat16)
-    ws = torch.full(((M // 32 + 2) * 2 * N,), float("nan"), device="cuda", dtype=torch.float16)
+    ws = torch.full(((M // 96 + 2) * 2 * N,), -2 ** 30, device="cuda", dtype=torch.int32)
     hip.gemm_lnfold_hp(x, Wg, out, c, d, rowstats=rstat, act=hip.ACT_QUICKGELU, corr_tokens=tokens, colmean_out=um, colsum_ws=ws)
     assert torch.equal(out, out0)
     ref = out.float().view(frames, tokens, N).mean(1)
     assert not torch.isnan(um.float()).any()
-    # bf16 output (2^-9) + fp16 partial sums of up to 128 values
-    assert maxdiff(um.float(), ref) < 6e-3 * max(1.0, float(ref.abs().max())), maxdiff(um.float(), ref)
+    # bf16 output (2^-9) + the fixed-point resolution of the sums (2^-12 per value)
+    assert maxdiff(um.float(), ref) < 4.5e-3 * max(1.0, float(ref.abs().max())), maxdiff(um.float(), ref)
 
 
 def test_episode_top1(hip):
