@@ -105,7 +105,10 @@ def test_hot_kernels_use_no_scratch():
     hot = {  # substring of the mangled name -> max scratch bytes per lane
         "vit_attn_bf16_kernelIDF16bLi7ELi13ELi4ELi3E": 0, "vit_attn_bf16_kernelIDF16bLi9ELi17E": 0,
         "vit_attn_bf16_kernelIDF16_Li7ELi13ELi4ELi3E": 0, "vit_attn_bf16_kernelIDF16_Li9ELi17E": 0,      # the fp16 numerics mode
-        "vit_gemm_kernelIDF16_DF16_Li0ELi1ELi2E": 0, "vit_gemm_kernelIDF16_DF16_Li0ELi2ELi2E": 0, "vit_gemm_kernelIDF16_DF16_Li1ELi2ELi2E": 0, "layernorm_kernel": 0,
+        "vit_gemm_kernelIDF16_DF16_Li0ELi1ELi2E": 0, "vit_gemm_kernelIDF16_DF16_Li0ELi2ELi2E": 0, "layernorm_kernel": 0,
+        # fp16 c_fc (LN-fold + QuickGELU + per-frame fixed-point column sums, round 4): its 192-row form spills ONE epilogue register; what a
+        # spill must never touch -- the destination of a compiler-invisible load before its wait -- is checked by tests/test_asm_audit.py
+        "vit_gemm_kernelIDF16_DF16_Li1ELi2ELi2E": 16,
         # the persistent ViT GEMM (gemm_vit.hip): the LDS-DMA instances keep (nearly) everything in registers -- an LN-folded build
         # with 12 spilled registers returned stale lanes under a concurrent second stream (tests/test_gpu_kernels.py::
         # test_vit_gemms_are_bit_stable_under_a_second_stream), so these limits are tight on purpose; the register-staged long-K
