@@ -248,9 +248,10 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     inv = __builtin_amdgcn_rcpf(osum[0]);                       // every row of the ones product is the query's sum over all keys
 }
 
-template <typename T, int NKB, int NTV, int NW, int WPS, int KPFK = 0>
+template <typename T, int NKB, int NTV, int NW, int WPS, int KPFK = 0, bool MEANS = false>
 __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                                     int ntok, int D, float scale_log2e, int dbg) {
+                                                                     int ntok, int D, float scale_log2e, int dbg,
+                                                                     __bf16* __restrict__ omean = nullptr) {
     constexpr int NT = NKB * 2;                                    // 16-key tiles
     constexpr int nt_valid = NTV > 0 ? NTV : NT;                   // tiles that are computed
     constexpr int KROWS = nt_valid * 16;                           // rows of K and of V kept in LDS
@@ -314,6 +315,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const T* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const AttLane L(lane);
+    // omean != NULL (round 4, fp16 numerics mode): the per-frame TOKEN MEAN of this head's output, omean[f][64 h + d] -- out_proj's per-frame
+    // low-word correction needs it, and this workgroup is the one place that sees all of a (frame, head)'s output rows: no pass over `out`.
+    // Fixed summation order per (frame, head): the result does not depend on the batch the frame is served in.
+    f32x4 osum[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int qt = wave; qt < nqt; qt += NW) {
         int qrow = qt * 16 + q16;
         const bool qvalid = qrow < ntok;
@@ -337,8 +342,44 @@ __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const T* __
         attn_tile<T, NKB, NTV, ((KPFK > 0) ? KPFK : ((NKB >= 9 && WPS > 2) ? 1 : 2))>(sK, sV, L, qf, ntok, scale_log2e, o, inv);
         // O^T[d][q]: lane owns query q16, d = 16 dt + 4 g + r
         store_o_tile<T>(o, inv, qvalid, out + ((size_t)f * ntok + qrow) * D + h * 64, g);
+        if constexpr (MEANS) {
+            const float w = qvalid ? inv : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) osum[dt][r] = __builtin_fmaf(o[dt][r], w, osum[dt][r]);
+        }
         qf[0] = qn[0];
         qf[1] = qn[1];
+    }
+    if constexpr (MEANS) {
+        // sum over the 16 queries of a lane row (q16 = lane & 15: one DPP row), then over the waves through the (now idle) K tile
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = osum[dt][r];
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));   // row_ror:8
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));   // row_ror:4
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false));   // row_ror:2
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));   // row_ror:1
+                osum[dt][r] = v;
+            }
+        __syncthreads();                                             // every wave is done with sK / sV
+        float* red = reinterpret_cast<float*>(smem);
+        if (q16 == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * 64 + 16 * dt + 4 * g + r] = osum[dt][r];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += red[w * 64 + tid];
+            omean[(size_t)f * D + h * 64 + tid] = (__bf16)(sum / (float)ntok);
+        }
     }
 }
 
@@ -694,13 +735,21 @@ static inline int attn_dbg() {
 }
 
 template <int NKB, int NTV, int NW, int WPS, int KPFK = 0, typename T = __bf16>
-int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s) {
+int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s, void* omean = nullptr) {
     constexpr int KROWS = (NTV > 0 ? NTV : NKB * 2) * 16;
     constexpr int LDS = 2 * KROWS * 128;
-    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<T, NKB, NTV, NW, WPS, KPFK>), LDS, "cfsar_vit_attention")) return rc;
     const float scale_log2e = 0.125f * 1.4426950408889634f;
+    if constexpr (std::is_same<T, _Float16>::value) {
+        if (omean != nullptr) {                   // the fp16 numerics mode's form that also emits the output's per-frame token means
+            if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<T, NKB, NTV, NW, WPS, KPFK, true>), LDS, "cfsar_vit_attention")) return rc;
+            hipLaunchKernelGGL((vit_attn_bf16_kernel<T, NKB, NTV, NW, WPS, KPFK, true>), dim3(heads, F), dim3(NW * 64), LDS, s,
+                               static_cast<const T*>(qkv), static_cast<T*>(out), ntok, D, scale_log2e, attn_dbg(), static_cast<__bf16*>(omean));
+            return cfsar_check_launch("cfsar_vit_attention_means");
+        }
+    }
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<T, NKB, NTV, NW, WPS, KPFK>), LDS, "cfsar_vit_attention")) return rc;
     hipLaunchKernelGGL((vit_attn_bf16_kernel<T, NKB, NTV, NW, WPS, KPFK>), dim3(heads, F), dim3(NW * 64), LDS, s,
-                       static_cast<const T*>(qkv), static_cast<T*>(out), ntok, D, scale_log2e, attn_dbg());
+                       static_cast<const T*>(qkv), static_cast<T*>(out), ntok, D, scale_log2e, attn_dbg(), static_cast<__bf16*>(nullptr));
     return cfsar_check_launch("cfsar_vit_attention(16-bit)");
 }
 
@@ -736,8 +785,21 @@ static int g_attn_variant = 0;
 extern "C" void cfsar_debug_set_attn_variant(int v) { g_attn_variant = v & 255; g_attn_dbg = v >> 8; }
 #endif
 
+static int vit_attention_impl(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads, void* omean, cfsar_stream_t stream);
+
 extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads,
                                    cfsar_stream_t stream) {
+    return vit_attention_impl(qkv, out, dtype, F, ntok, D, heads, nullptr, stream);
+}
+
+// cfsar_vit_attention (fp16) that also writes the per-frame token means of its output, omean [F, D] bf16 (see the header).
+extern "C" int cfsar_vit_attention_means(const void* qkv, void* out, void* omean, int F, int ntok, int D, int heads,
+                                         cfsar_stream_t stream) {
+    CFSAR_REQUIRE(omean != nullptr, "cfsar_vit_attention_means: null pointer");
+    return vit_attention_impl(qkv, out, CFSAR_F16, F, ntok, D, heads, omean, stream);
+}
+
+static int vit_attention_impl(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads, void* omean, cfsar_stream_t stream) {
     CFSAR_REQUIRE(qkv && out, "cfsar_vit_attention: null pointer");
     CFSAR_REQUIRE(F > 0 && ntok > 0 && heads > 0 && D == heads * 64, "cfsar_vit_attention: need D == heads*64 (D=%d heads=%d)",
                   D, heads);
@@ -798,10 +860,10 @@ extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F,
     }
     if (dtype == CFSAR_F16) {                    // the fp16 numerics mode: the same kernel on fp16 q / k / v, P rounded to fp16
         CFSAR_REQUIRE(ntok <= 288, "cfsar_vit_attention: ntok=%d > 288", ntok);
-        if (ntok == 197) return launch_bf16<7, 13, 4, 3, 0, _Float16>(qkv, out, F, ntok, D, heads, s);
-        if (ntok == 257) return launch_bf16<9, 17, 4, 2, 5, _Float16>(qkv, out, F, ntok, D, heads, s);
-        if (ntok > 224) return launch_bf16<9, 0, 4, 2, 0, _Float16>(qkv, out, F, ntok, D, heads, s);
-        return launch_bf16<7, 0, 7, 4, 0, _Float16>(qkv, out, F, ntok, D, heads, s);
+        if (ntok == 197) return launch_bf16<7, 13, 4, 3, 0, _Float16>(qkv, out, F, ntok, D, heads, s, omean);
+        if (ntok == 257) return launch_bf16<9, 17, 4, 2, 5, _Float16>(qkv, out, F, ntok, D, heads, s, omean);
+        if (ntok > 224) return launch_bf16<9, 0, 4, 2, 0, _Float16>(qkv, out, F, ntok, D, heads, s, omean);
+        return launch_bf16<7, 0, 7, 4, 0, _Float16>(qkv, out, F, ntok, D, heads, s, omean);
     }
     if (dtype == CFSAR_F32) {
         const int lds = ntok * 64 * 4 * 2;

@@ -210,6 +210,7 @@ class HipViT:
         # LN statistics finalized inside the consuming GEMM (ViT-B / ViT-L widths; CFSAR_FUSE_STATS=0: the separate finalize launches)
         self.fuse_stats = bool(self.fold) and hip.lnfold_partials_ok(self.D, self.D // 64) and os.environ.get("CFSAR_FUSE_STATS", "1") != "0"
         self.fused_umeans = os.environ.get("CFSAR_FUSED_UMEANS", "1") != "0"      # c_fc emits the hidden's per-frame means (A/B switch)
+        self.fused_omeans = os.environ.get("CFSAR_FUSED_OMEANS", "1") != "0"      # the attention kernel emits its output's per-frame means
         if self.mcorr & {"qkv", "fc"}:
             self.fuse_stats = False          # the token means of LayerNorm(x) need the finalized statistics in front of the GEMM
         # band-chunked layer schedule (developer switch; measured in profiles/r04_chunked_schedule.md): CFSAR_CHUNK_FRAMES=k,
@@ -241,6 +242,7 @@ class HipViT:
             if self.mcorr:
                 ws["colsum"] = torch.empty((M // 96 + 2) * 2 * 4 * D, device=dev, dtype=torch.int32)   # c_fc's per-wave-tile column sums (fixed point)
                 ws["mU"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.bfloat16)         # per-frame token means of the MLP hidden
+                ws["mX"] = torch.empty(F_, D, device=dev, dtype=torch.bfloat16)              # ... of the attention output
                 ws["mA"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.bfloat16)         # per-frame token means of a GEMM operand
                 ws["corr"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.float32)        # ... x W_lo^T
             if self.two_word:
@@ -428,8 +430,13 @@ class HipViT:
                 else:
                     fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, sp="qkv" in split,
                          corr=mc(b, "qkv", x, rstat))
-                    hip.vit_attention(qkv, o, F_, N, D, self.H)
-                    resid(o, b, "out", x, xlo, part, M, corr=mc(b, "out", o))         # x += out_proj(attn); stats of the new x
+                    if "out" in mcorr and self.fused_omeans:                           # the attention kernel emits its output's per-frame means
+                        mO = ws["mX"][:F_]
+                        hip.vit_attention_means(qkv, o, mO, F_, N, D, self.H)
+                    else:
+                        mO = None
+                        hip.vit_attention(qkv, o, F_, N, D, self.H)
+                    resid(o, b, "out", x, xlo, part, M, corr=mc(b, "out", o, means=mO))   # x += out_proj(attn); stats of the new x
                 if not fuse:
                     hip.ln_stats_finalize(part, rstat, M, S, D)
                 # c_fc also emits the per-frame token means of the hidden it writes: c_proj's correction needs no pass of its own over u

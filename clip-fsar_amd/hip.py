@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (imported first so that torch's libamdhip64.so.7 is the HIP runtime the library binds to)
 
 F32, BF16, F16 = 0, 1, 2
-ABI_VERSION = 5          # CFSAR_ABI_VERSION of include/clipfsar_hip.h this file's SIGNATURES were written against
+ABI_VERSION = 6          # CFSAR_ABI_VERSION of include/clipfsar_hip.h this file's SIGNATURES were written against
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -54,6 +54,7 @@ SIGNATURES = {
     "cfsar_attnpool_attend": [_c_p, _c_p, _c_p] + [_c_int] * 4 + [ctypes.c_float, _c_p],
     "cfsar_stem_conv3x3_s2": [_c_p] * 4 + [_c_int] * 6 + [_c_p],
     "cfsar_vit_attention": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_vit_attention_means": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_vit_attention_cls": [_c_p, _c_i64, _c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_class_text_logits": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_build_sequences": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p],
@@ -347,6 +348,12 @@ def vit_attention(qkv, out, F_, ntok, D, heads):
         raise RuntimeError("vit_attention: qkv/out dtype mismatch")
     _check(lib().cfsar_vit_attention(_dev(qkv, None, "qkv"), _dev(out, None, "out"), _code(qkv.dtype), F_, ntok, D,
                                      heads, _stream()), "cfsar_vit_attention")
+
+
+def vit_attention_means(qkv, out, omean, F_, ntok, D, heads):
+    """vit_attention (fp16) + omean [F, D] bf16: the per-frame token means of the attention output (cfsar_vit_attention_means)."""
+    _check(lib().cfsar_vit_attention_means(_dev(qkv, torch.float16, "qkv"), _dev(out, torch.float16, "out"), _dev(omean, torch.bfloat16, "omean"),
+                                           F_, ntok, D, heads, _stream()), "cfsar_vit_attention_means")
 
 
 def vit_attention_cls(qkv, out, F_, ntok, D, heads, q=None, kv=None):

@@ -46,7 +46,7 @@ typedef void* cfsar_stream_t;
 int cfsar_version(void);
 /* ABI revision: bumped whenever an exported signature changes or is added; a binding compares it with the CFSAR_ABI_VERSION it was
  * written against at load time (clip-fsar_amd/hip.py does) instead of calling through a stale prototype. */
-#define CFSAR_ABI_VERSION 5
+#define CFSAR_ABI_VERSION 6
 int cfsar_abi_version(void);
 const char* cfsar_last_error(void);
 
@@ -279,6 +279,10 @@ int cfsar_gemm_lnfold_hp(const void* x, const void* Wg, void* out, const float* 
 int cfsar_gemm_residual_wide(const void* A, const void* W, void* x_hi, void* x_lo, const float* bias, float* stats_partial, int M,
                              int N, int K, int wsplit, int lda, int ldw, int ldx, const float* corr, int corr_tokens,
                              cfsar_stream_t stream);
+/* cfsar_vit_attention on fp16 q / k / v that ALSO writes the per-frame token means of its output, omean [F, D] bf16 (omean[f][64 h + d] =
+ * mean over the frame's tokens of out[f tokens + t][64 h + d]): what out_proj's per-frame correction needs, from the one workgroup that sees
+ * all output rows of a (frame, head) -- no pass over `out`. */
+int cfsar_vit_attention_means(const void* qkv, void* out, void* omean, int F, int ntok, int D, int heads, cfsar_stream_t stream);
 /* out[f][k] = mean over the frame's tokens t of w_t (A[f tokens + t][k] - mu_t), (mu_t, w_t) = (mean, 1 / std) of row t from rowstats
  * [frames tokens, 4] (the token mean of LayerNorm(x) before its affine, few_shot.py:605-611) or (0, 1) when rowstats == NULL.
  * A [frames tokens, lda] fp16, out [frames, K] bf16. */

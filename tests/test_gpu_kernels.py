@@ -1135,3 +1135,21 @@ def test_episode_top1(hip):
     hip.episode_top1(logits, labels, acc)
     ref = (logits.argmax(dim=2) == labels.long()).float().mean(dim=1)
     assert torch.equal(acc, ref)
+
+
+@pytest.mark.parametrize("F_,ntok,H", [(7, 197, 12), (3, 257, 16), (5, 130, 4), (4, 17, 2)])
+def test_vit_attention_means(hip, F_, ntok, H):
+    """cfsar_vit_attention_means: the same output bits as cfsar_vit_attention, plus the per-frame token means of that output (bf16)."""
+    D = 64 * H
+    g = torch.Generator().manual_seed(17)
+    qkv = (torch.randn(F_ * ntok, 3 * D, generator=g)).to(torch.float16).cuda()
+    o0 = torch.empty(F_ * ntok, D, device="cuda", dtype=torch.float16)
+    hip.vit_attention(qkv, o0, F_, ntok, D, H)
+    o1 = torch.full((F_ * ntok, D), float("nan"), device="cuda", dtype=torch.float16)
+    om = torch.full((F_, D), float("nan"), device="cuda", dtype=torch.bfloat16)
+    hip.vit_attention_means(qkv, o1, om, F_, ntok, D, H)
+    assert torch.equal(o0, o1)
+    ref = o1.float().view(F_, ntok, D).mean(1)
+    assert not torch.isnan(om.float()).any()
+    # bf16 output + the means are taken of the unrounded fp32 rows (fp16 rounding noise of the stored rows averages out)
+    assert maxdiff(om.float(), ref) < 2.0 ** -8 * max(0.05, float(ref.abs().max())) + 2e-4, maxdiff(om.float(), ref)
