@@ -63,18 +63,24 @@ def _stale(lib=LIB) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
-    LIB_OUT = DEV_LIB if dev else LIB
+# `python clip-fsar_amd/build.py --packed`: the PRODUCT sources and flags minus the fence, i.e. WITH packed-fp32 VALU instructions, as
+# libclipfsar_hip_packed.so -- the build in which tools/asm_load_audit.py finds a compiler spill of a hidden load's destination before its
+# wait (profiles/r04_fault_audit.md).  Loaded only through CFSAR_LIB_PATH (clip_fsar_amd.hip); exists to reproduce that finding on hardware.
+PACKED_LIB = os.path.join(HERE, "libclipfsar_hip_packed.so")
+
+
+def build(force: bool = False, verbose: bool = True, dev: bool = False, packed: bool = False) -> str:
+    LIB_OUT = PACKED_LIB if packed else (DEV_LIB if dev else LIB)
     if not force and not _stale(LIB_OUT):
         return LIB_OUT
     objs = []
     procs = []
-    bdir = os.path.join(HERE, "build", "dev") if dev else os.path.join(HERE, "build")
+    bdir = os.path.join(HERE, "build", "packed") if packed else (os.path.join(HERE, "build", "dev") if dev else os.path.join(HERE, "build"))
     os.makedirs(bdir, exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         extra = os.environ.get("CFSAR_BUILD_DEFS", "").split() if dev else []      # developer A/B builds only
-        if "-DCFSAR_PACKED_FP32" in extra:                                          # A/B: compile with the packed instructions
+        if packed or "-DCFSAR_PACKED_FP32" in extra:                                # A/B: compile with the packed instructions
             extra = [e for e in extra if e != "-DCFSAR_PACKED_FP32"]
         else:
             extra = extra + SOURCE_FLAGS.get(src, [])
@@ -93,7 +99,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
         if verbose and rest.strip():
             print(rest)
     import json
-    with open(USAGE if not dev else os.path.join(bdir, "resource_usage.json"), "w") as f:
+    with open(USAGE if not (dev or packed) else os.path.join(bdir, "resource_usage.json"), "w") as f:
         json.dump(usage, f, indent=0, sort_keys=True)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_OUT] + objs
     if verbose:
@@ -103,4 +109,4 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv))
+    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv, packed="--packed" in sys.argv))

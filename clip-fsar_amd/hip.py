@@ -18,6 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CFSAR_DEV_LIB=1 (developer tools only): the -DCFSAR_DEV build with the cfsar_debug_* hooks (clip-fsar_amd/build.py --dev)
 DEV_LIB = os.environ.get("CFSAR_DEV_LIB", "0") == "1"
 LIB_PATH = os.path.join(_HERE, "libclipfsar_hip_dev.so" if DEV_LIB else "libclipfsar_hip.so")
+if os.environ.get("CFSAR_LIB_PATH"):       # developer A/B only (e.g. build.py --packed: profiles/r04_fault_audit.md); same ABI check as the product
+    LIB_PATH = os.path.abspath(os.environ["CFSAR_LIB_PATH"])
 _lib = None
 
 _c_int, _c_p, _c_f, _c_i64 = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_int64
