@@ -69,17 +69,18 @@ def _stale(lib=LIB) -> bool:
 PACKED_LIB = os.path.join(HERE, "libclipfsar_hip_packed.so")
 
 
-def build(force: bool = False, verbose: bool = True, dev: bool = False, packed: bool = False) -> str:
-    LIB_OUT = PACKED_LIB if packed else (DEV_LIB if dev else LIB)
+def build(force: bool = False, verbose: bool = True, dev: bool = False, packed: bool = False, variant: str = "", defs=()) -> str:
+    """variant / defs (developer A/B): the product build with extra -D flags as libclipfsar_hip_<variant>.so (loaded through CFSAR_LIB_PATH)"""
+    LIB_OUT = os.path.join(HERE, "libclipfsar_hip_%s.so" % variant) if variant else (PACKED_LIB if packed else (DEV_LIB if dev else LIB))
     if not force and not _stale(LIB_OUT):
         return LIB_OUT
     objs = []
     procs = []
-    bdir = os.path.join(HERE, "build", "packed") if packed else (os.path.join(HERE, "build", "dev") if dev else os.path.join(HERE, "build"))
+    bdir = os.path.join(HERE, "build", variant or "packed") if (packed or variant) else (os.path.join(HERE, "build", "dev") if dev else os.path.join(HERE, "build"))
     os.makedirs(bdir, exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
-        extra = os.environ.get("CFSAR_BUILD_DEFS", "").split() if dev else []      # developer A/B builds only
+        extra = (os.environ.get("CFSAR_BUILD_DEFS", "").split() if dev else []) + list(defs)      # developer A/B builds only
         if packed or "-DCFSAR_PACKED_FP32" in extra:                                # A/B: compile with the packed instructions
             extra = [e for e in extra if e != "-DCFSAR_PACKED_FP32"]
         else:
@@ -99,7 +100,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False, packed: 
         if verbose and rest.strip():
             print(rest)
     import json
-    with open(USAGE if not (dev or packed) else os.path.join(bdir, "resource_usage.json"), "w") as f:
+    with open(USAGE if not (dev or packed or variant) else os.path.join(bdir, "resource_usage.json"), "w") as f:
         json.dump(usage, f, indent=0, sort_keys=True)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_OUT] + objs
     if verbose:
@@ -109,4 +110,6 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False, packed: 
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv, packed="--packed" in sys.argv))
+    _v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    _d = [a for a in sys.argv[1:] if a.startswith("-D")]
+    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv, packed="--packed" in sys.argv, variant=_v, defs=_d))

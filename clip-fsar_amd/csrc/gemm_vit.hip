@@ -632,10 +632,17 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     int corr_bnd = 0;                    // rows of the wave's tile that belong to frame f0 (the others: f0 + 1)
     int corr_par = 0;                    // parity of f0
     float rscale[4] = {1.f, 1.f, 1.f, 1.f};
+    // CFSAR_VISIBLE_TAIL_LOADS (A/B, round 4): the same loads as plain, compiler-VISIBLE loads -- hipcc then counts them in its own s_waitcnt
+    // bookkeeping, so a spill or a copy of their destination can never run ahead of the data (profiles/r04_fault_audit.md); the price is that the
+    // compiler's waits also cover every LDS-DMA piece in flight at the place where it decides to touch the value.
     auto asm_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
+#ifdef CFSAR_VISIBLE_TAIL_LOADS
+        return *reinterpret_cast<const volatile float*>(ptr);
+#else
         float v;
         asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
         return v;
+#endif
     };
     auto tail_loads = [&](int m0_, int n0_) __attribute__((always_inline)) {
         int nb_ = n0_ + wn * 64;
@@ -919,6 +926,11 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (j == 1 && sync) {
                 if constexpr (OPATH >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+#ifdef CFSAR_VISIBLE_TAIL_LOADS
+                // last K step of the tile: the tail operands (loaded one step earlier) are consumed HERE, right behind the wait that covers
+                // them and before this step issues the next tile's DMA pieces -- the compiler's own wait for them finds the counter at zero
+                if constexpr (!frags && OPATH >= 1) tail_pin();
+#endif
                 __syncthreads();                                        // (register path: hipcc adds lgkmcnt(0) for the ds_writes)
                 __builtin_amdgcn_sched_barrier(0);
             }
