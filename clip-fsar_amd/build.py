@@ -27,7 +27,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
 # round-2 microtests nor round 3's tools/ubench/pk_trans_waw.hip (transcendental -> packed WAW / RAW under a transcendental- or
 # MFMA-heavy partner wave) reproduce it, so it is FENCED, not explained: with scalar fp32 VALU code it has not been seen (0 of 1 500
 # stress launches against 44 of 150), and the fence now covers gemm.hip, attention.hip, tail.hip, conv.hip and rowops.hip as well (the same
-# epilogue patterns live there).  Same-box A/B: no measurable cost (profiles/r03_gemm_anatomy.md); MI355X_MICROARCH.md lists packed fp32
+# epilogue patterns live there).  Round 4 found one mechanism of this class -- the compiler spilling / reusing the destination of an inline-asm
+# load before its data had landed, in exactly such a packed build -- and made those loads compiler-visible (profiles/r04_fault_audit.md);
+# the fence stays because it costs nothing.  Same-box A/B: no measurable cost (profiles/r03_gemm_anatomy.md); MI355X_MICROARCH.md lists packed fp32
 # beside MFMAs as an anti-lever anyway.  `-DCFSAR_PACKED_FP32` in CFSAR_BUILD_DEFS (developer builds) switches the instructions back on.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 SOURCE_FLAGS = {src: NO_PACKED_FP32 for src in SOURCES}

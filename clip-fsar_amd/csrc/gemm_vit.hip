@@ -632,12 +632,16 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
     int corr_bnd = 0;                    // rows of the wave's tile that belong to frame f0 (the others: f0 + 1)
     int corr_par = 0;                    // parity of f0
     float rscale[4] = {1.f, 1.f, 1.f, 1.f};
-    // CFSAR_VISIBLE_TAIL_LOADS (A/B, round 4): the same loads as plain, compiler-VISIBLE loads -- hipcc then counts them in its own s_waitcnt
-    // bookkeeping, so a spill or a copy of their destination can never run ahead of the data (profiles/r04_fault_audit.md); the price is that the
-    // compiler's waits also cover every LDS-DMA piece in flight at the place where it decides to touch the value.
+    // Round 4: these loads are plain, compiler-VISIBLE loads.  Rounds 2-3 issued them from inline asm (hidden from hipcc's s_waitcnt bookkeeping, so
+    // that no compiler wait would also cover the LDS-DMA pieces in flight); hipcc treats an asm load's destination as written when the statement
+    // ends, and a build with packed-fp32 instructions spilled / reused such a destination before its data had landed -> wrong lanes, a memory
+    // fault (profiles/r04_fault_audit.md).  Visible loads cannot do that: the compiler waits before it touches the value.  They cost nothing
+    // because the tail operands are consumed (tail_pin) right behind the last K step's own vmcnt(0), before that step issues the next tile's
+    // DMA pieces -- the compiler's wait finds the counter at zero; the "memory"-clobbering asm statements of the step keep the loads at this
+    // program point.  NOT volatile: hipcc waits for every volatile load on the spot (-2 % / -3.5 %).  -DCFSAR_HIDDEN_TAIL_LOADS: the asm form (A/B).
     auto asm_load = [&](const float* ptr) __attribute__((always_inline)) -> float {
-#ifdef CFSAR_VISIBLE_TAIL_LOADS
-        return *reinterpret_cast<const volatile float*>(ptr);
+#ifndef CFSAR_HIDDEN_TAIL_LOADS
+        return *ptr;
 #else
         float v;
         asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
@@ -766,12 +770,21 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         const char* src = reinterpret_cast<const char*>(p.part) + ((size_t)m * p.part_slots + (hi ? 8 : 0)) * 8;
         sp[2] = u32x4{0u, 0u, 0u, 0u};
         sp[3] = u32x4{0u, 0u, 0u, 0u};
+#ifndef CFSAR_HIDDEN_TAIL_LOADS
+        sp[0] = *reinterpret_cast<const u32x4*>(src);
+        sp[1] = *reinterpret_cast<const u32x4*>(src + 16);
+        if (p.part_slots == 16 || hi == 0) {
+            sp[2] = *reinterpret_cast<const u32x4*>(src + 32);
+            sp[3] = *reinterpret_cast<const u32x4*>(src + 48);
+        }
+#else
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sp[0]) : "v"(src) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(sp[1]) : "v"(src) : "memory");
         if (p.part_slots == 16 || hi == 0) {
             asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "+v"(sp[2]) : "v"(src) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "+v"(sp[3]) : "v"(src) : "memory");
         }
+#endif
     };
     auto stat_consume = [&](auto MI_) __attribute__((always_inline)) {
         constexpr int mi = decltype(MI_)::value;
@@ -926,7 +939,7 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (j == 1 && sync) {
                 if constexpr (OPATH >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
-#ifdef CFSAR_VISIBLE_TAIL_LOADS
+#ifndef CFSAR_HIDDEN_TAIL_LOADS
                 // last K step of the tile: the tail operands (loaded one step earlier) are consumed HERE, right behind the wait that covers
                 // them and before this step issues the next tile's DMA pieces -- the compiler's own wait for them finds the counter at zero
                 if constexpr (!frags && OPATH >= 1) tail_pin();

@@ -83,6 +83,7 @@ def main(path):
                 findings[fn] += 1
                 detail.append((fn[-70:], i + 1, l, -1, "no covering wait found", ""))
         i += 1
+    main.last_count = n_loads
     print("%s: %d compiler-invisible VGPR loads audited" % (path, n_loads))
     if not findings:
         print("  no instruction touches a destination register between its load and the wait that covers it")
