@@ -453,7 +453,7 @@ def run(args):
                                "(utils/prefetch.py, the product harness's path)"}
 
     fp16_mode = None
-    if (not dry and rank == 0 and world == 1 and args.precision == "bf16" and ARCH.startswith("ViT") and not args.no_fp16_leg
+    if (not dry and rank == 0 and world == 1 and args.precision == "bf16" and not args.no_fp16_leg
             and B * frames_per_ep > 160):              # (small steps: a handful of them does not time anything)
         # The 16-bit mode that meets the north-star tolerance (precision "fp16": IEEE-half operands everywhere, same kernels), timed
         # in the same process on the same resident steps: `value` stays BASELINE's bf16 configuration, this object says what the
@@ -503,7 +503,7 @@ def run(args):
                                       "few_shot.py:683); CFSAR_FULL_LAST_BLOCK=1 computes it whole") if pruned else "whole",
                        "precision": args.precision,
                        "numerics": ("%s MFMA operands, fp32 accumulation / LayerNorm + softmax statistics / final projection / "
-                                    "temporal head, fp16 residual stream" % args.precision + (" (ViT)" if ARCH.startswith("ViT") else " n/a (RN50: bf16 activations)")
+                                    "temporal head" % args.precision + (", fp16 residual stream" if ARCH.startswith("ViT") else " (RN50: %s NHWC activations, BatchNorm folded)" % args.precision)
                                     if args.precision != "fp32" else "fp32 throughout"),
                        "parallelism": "episodes sharded over %d rank(s); one all-gather of accuracies" % world,
                        "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else

@@ -37,9 +37,9 @@ int cfsar_check_launch(const char* what);
 int cfsar_ensure_lds(const void* fn, int bytes, const char* what);   // per-(device, kernel) dynamic-LDS limit, cached
 int cfsar_num_cus();                                                 // compute units of the current device, cached
 
-// conv.hip: direct 3x3 convolution for Cin, Cout in {32, 64} (bf16 NHWC, no residual); -2 = shape not covered, use the implicit GEMM
+// conv.hip: direct 3x3 convolution for Cin, Cout in {32, 64} (bf16 or, f16 != 0, fp16 NHWC, no residual); -2 = shape not covered, use the implicit GEMM
 int cfsar_conv3x3_direct(const void* in, const void* W, void* out, const float* bias, int F, int H, int Wd, int C, int Cout, int ldw,
-                         int ldo, int relu, hipStream_t s);
+                         int ldo, int relu, int f16, hipStream_t s);
 
 #define CFSAR_REQUIRE(cond, ...)                    \
     do {                                            \

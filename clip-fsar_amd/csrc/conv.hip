@@ -79,8 +79,10 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const T* __restrict__ in,
 
 // bf16, C % 8 == 0: 8 channels (16 bytes) per thread -- four 16-byte loads, one 16-byte store (the scalar form above moves 2 bytes per
 // load: 3.5 TB/s on the RN50 pools; this one streams)
-__global__ __launch_bounds__(256) void avgpool2_bf16x8_kernel(const __bf16* __restrict__ in, __bf16* __restrict__ out, int H, int W, int C8,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool2_x8_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W, int C8,
                                                               long long total8) {
+    typedef typename Vec2B<T>::v8 T8;
     const int Ho = H / 2, Wo = W / 2;
     const long long rowb = (long long)W * C8;                 // one input image row in 16-byte units
     const uint4* in4 = reinterpret_cast<const uint4*>(in);
@@ -94,11 +96,11 @@ __global__ __launch_bounds__(256) void avgpool2_bf16x8_kernel(const __bf16* __re
         const int yo = (int)(r % Ho);
         const long long f = r / Ho;
         const uint4* q = in4 + ((f * H + 2 * yo) * (long long)W + 2 * xo) * C8 + c;
-        const bf16x8 a = __builtin_bit_cast(bf16x8, q[0]), b = __builtin_bit_cast(bf16x8, q[C8]);
-        const bf16x8 d = __builtin_bit_cast(bf16x8, q[rowb]), e = __builtin_bit_cast(bf16x8, q[rowb + C8]);
-        bf16x8 o;
+        const T8 a = __builtin_bit_cast(T8, q[0]), b = __builtin_bit_cast(T8, q[C8]);
+        const T8 d = __builtin_bit_cast(T8, q[rowb]), e = __builtin_bit_cast(T8, q[rowb + C8]);
+        T8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)((((float)a[j] + (float)b[j]) + ((float)d[j] + (float)e[j])) * 0.25f);
+        for (int j = 0; j < 8; ++j) o[j] = (T)((((float)a[j] + (float)b[j]) + ((float)d[j] + (float)e[j])) * 0.25f);
         out4[idx] = __builtin_bit_cast(uint4, o);
     }
 }
@@ -215,10 +217,10 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const float* __restrict
             for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
         }
         if constexpr (sizeof(TO) == 2) {
-            bf16x8 o;
+            typename Vec2B<TO>::v8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (__bf16)acc[j];
-            *reinterpret_cast<bf16x8*>(op + o0) = o;
+            for (int j = 0; j < 8; ++j) o[j] = (TO)acc[j];
+            *reinterpret_cast<typename Vec2B<TO>::v8*>(op + o0) = o;
         } else {
             *reinterpret_cast<float4*>(op + o0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             *reinterpret_cast<float4*>(op + o0 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
@@ -241,6 +243,8 @@ extern "C" int cfsar_nchw_to_nhwc(const float* frames, void* out, int out_dtype,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (out_dtype == CFSAR_BF16)
         hipLaunchKernelGGL((nchw_to_nhwc_kernel<__bf16>), dim3(grid_for(total, 0)), dim3(256), 0, s, frames, static_cast<__bf16*>(out), C, H, W, total);
+    else if (out_dtype == CFSAR_F16)
+        hipLaunchKernelGGL((nchw_to_nhwc_kernel<_Float16>), dim3(grid_for(total, 0)), dim3(256), 0, s, frames, static_cast<_Float16*>(out), C, H, W, total);
     else if (out_dtype == CFSAR_F32)
         hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(grid_for(total, 0)), dim3(256), 0, s, frames, static_cast<float*>(out), C, H, W, total);
     else
@@ -258,7 +262,7 @@ extern "C" int cfsar_im2col3x3_nhwc(const void* in, void* out, int dtype, int F,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec8 = (C % 8 == 0) && (k_pad % 8 == 0);
     const bool vec4 = (C % 4 == 0) && (k_pad % 4 == 0);
-    if (dtype == CFSAR_BF16) {
+    if (dtype == CFSAR_BF16 || dtype == CFSAR_F16) {           // a pure mover (zeros are the same bits): fp16 takes the 2-byte instances
         if (vec8) {
             const long long tv = rows * (k_pad / 8);
             hipLaunchKernelGGL((im2col3x3_kernel<__bf16, 8>), dim3(grid_for(tv, 0)), dim3(256), 0, s, static_cast<const __bf16*>(in), static_cast<__bf16*>(out), H, W, C, Ho, Wo, stride, k_pad, tv);
@@ -285,7 +289,11 @@ extern "C" int cfsar_avgpool2x2_nhwc(const void* in, void* out, int dtype, int F
     const long long total = (long long)F * (H / 2) * (W / 2) * C;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == CFSAR_BF16 && C % 8 == 0 && ((size_t)in & 15) == 0 && ((size_t)out & 15) == 0)
-        hipLaunchKernelGGL(avgpool2_bf16x8_kernel, dim3(grid_for(total / 8, 0)), dim3(256), 0, s, static_cast<const __bf16*>(in), static_cast<__bf16*>(out), H, W, C / 8, total / 8);
+        hipLaunchKernelGGL(avgpool2_x8_kernel<__bf16>, dim3(grid_for(total / 8, 0)), dim3(256), 0, s, static_cast<const __bf16*>(in), static_cast<__bf16*>(out), H, W, C / 8, total / 8);
+    else if (dtype == CFSAR_F16 && C % 8 == 0 && ((size_t)in & 15) == 0 && ((size_t)out & 15) == 0)
+        hipLaunchKernelGGL(avgpool2_x8_kernel<_Float16>, dim3(grid_for(total / 8, 0)), dim3(256), 0, s, static_cast<const _Float16*>(in), static_cast<_Float16*>(out), H, W, C / 8, total / 8);
+    else if (dtype == CFSAR_F16)
+        hipLaunchKernelGGL((avgpool2_kernel<_Float16>), dim3(grid_for(total, 0)), dim3(256), 0, s, static_cast<const _Float16*>(in), static_cast<_Float16*>(out), H, W, C, total);
     else if (dtype == CFSAR_BF16)
         hipLaunchKernelGGL((avgpool2_kernel<__bf16>), dim3(grid_for(total, 0)), dim3(256), 0, s, static_cast<const __bf16*>(in), static_cast<__bf16*>(out), H, W, C, total);
     else if (dtype == CFSAR_F32)
@@ -301,6 +309,8 @@ extern "C" int cfsar_attnpool_tokens(const void* x, const float* pos, void* out,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == CFSAR_BF16)
         hipLaunchKernelGGL((attnpool_tokens_kernel<__bf16>), dim3(F), dim3(256), 0, s, static_cast<const __bf16*>(x), pos, static_cast<__bf16*>(out), HW, C);
+    else if (dtype == CFSAR_F16)
+        hipLaunchKernelGGL((attnpool_tokens_kernel<_Float16>), dim3(F), dim3(256), 0, s, static_cast<const _Float16*>(x), pos, static_cast<_Float16*>(out), HW, C);
     else if (dtype == CFSAR_F32)
         hipLaunchKernelGGL((attnpool_tokens_kernel<float>), dim3(F), dim3(256), 0, s, static_cast<const float*>(x), pos, static_cast<float*>(out), HW, C);
     else
@@ -339,6 +349,7 @@ extern "C" int cfsar_stem_conv3x3_s2(const float* frames, const float* w, const 
     CFSAR_REQUIRE(frames && w && out && F > 0 && H > 0 && W > 0, "cfsar_stem_conv3x3_s2: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (out_dtype == CFSAR_BF16) return launch_stem<__bf16>(frames, w, bias, out, F, H, W, Cout, relu, s);
+    if (out_dtype == CFSAR_F16) return launch_stem<_Float16>(frames, w, bias, out, F, H, W, Cout, relu, s);
     if (out_dtype == CFSAR_F32) return launch_stem<float>(frames, w, bias, out, F, H, W, Cout, relu, s);
     return cfsar_fail("cfsar_stem_conv3x3_s2: bad out_dtype %d", out_dtype);
 }
@@ -419,7 +430,7 @@ constexpr int DC_NCH = 8;           // chunks in the LDS ring
 
 template <int N> __device__ __forceinline__ void dc_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, typename T = __bf16>
 __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(DirectConvArgs p) {
     constexpr int DC_TILE = DcGeom<CIN>::TILE, DC_RING = DC_NCH * DC_TILE;
     constexpr int PXB = CIN * 2;                  // bytes per pixel
@@ -552,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(DirectConvArgs p
 #pragma unroll                                    // read -> wait -> MFMA with one fragment register)
             for (int mi = 0; mi < MI; ++mi) {
                 const int a = MI == 1 ? (s & 1) : mi;
-                acc[a] = cfsar_mfma_32x32x16<__bf16>(wr[s], af[s % (PD + 1)][mi], acc[a]);
+                acc[a] = cfsar_mfma_32x32x16<T>(wr[s], af[s % (PD + 1)][mi], acc[a]);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -567,14 +578,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(DirectConvArgs p
         for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16x4 o;
+                typename Vec2B<T>::v4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = acc[mi][4 * g + j];
                     if (p.relu) v = fmaxf(v, 0.0f);
-                    o[j] = (__bf16)v;
+                    o[j] = (T)v;
                 }
-                *reinterpret_cast<bf16x4*>(slab + lr * 64 + (((2 * g + hi) ^ (lr & 7)) << 3)) = o;
+                *reinterpret_cast<typename Vec2B<T>::v4*>(slab + lr * 64 + (((2 * g + hi) ^ (lr & 7)) << 3)) = o;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private slab: in-order DS + this wait
 #pragma unroll
@@ -598,13 +609,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(DirectConvArgs p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no LDS-DMA may outlive the workgroup
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, typename T>
 int launch_direct_conv(const DirectConvArgs& a, hipStream_t s) {
     constexpr int LDS = DC_NCH * DcGeom<CIN>::TILE * CIN * 2 + 128 + 4 * 2048;
-    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&conv3x3_direct_kernel<CIN, COUT>), LDS, "cfsar_conv3x3_nhwc(direct)")) return rc;
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&conv3x3_direct_kernel<CIN, COUT, T>), LDS, "cfsar_conv3x3_nhwc(direct)")) return rc;
     const int wgs = cfsar_num_cus() * 2;        // 72 KiB of LDS, <= 256 registers: two workgroups per CU
     const int grid = a.ntiles < wgs ? a.ntiles : wgs;
-    hipLaunchKernelGGL((conv3x3_direct_kernel<CIN, COUT>), dim3(grid), dim3(256), LDS, s, a);
+    hipLaunchKernelGGL((conv3x3_direct_kernel<CIN, COUT, T>), dim3(grid), dim3(256), LDS, s, a);
     return cfsar_check_launch("cfsar_conv3x3_nhwc(direct)");
 }
 
@@ -615,7 +626,7 @@ int g_direct_conv_dbg = 0;
 #endif
 // Called by cfsar_conv3x3_nhwc (gemm.hip) for the shapes this kernel covers; returns -2 when it does not apply.
 int cfsar_conv3x3_direct(const void* in, const void* W, void* out, const float* bias, int F, int H, int Wd, int C, int Cout, int ldw,
-                         int ldo, int relu, hipStream_t s) {
+                         int ldo, int relu, int f16, hipStream_t s) {
     const long long M = (long long)F * H * Wd;
     if (!((C == 32 || C == 64) && (Cout == 32 || Cout == 64) && !(C == 64 && Cout == 32))) return -2;
     const int tile = C == 64 ? DcGeom<64>::TILE : DcGeom<32>::TILE;
@@ -634,7 +645,12 @@ int cfsar_conv3x3_direct(const void* in, const void* W, void* out, const float* 
 #ifdef CFSAR_DEV
     a.dbg = g_direct_conv_dbg;
 #endif
-    if (C == 32 && Cout == 32) return launch_direct_conv<32, 32>(a, s);
-    if (C == 32 && Cout == 64) return launch_direct_conv<32, 64>(a, s);
-    return launch_direct_conv<64, 64>(a, s);
+    if (f16) {
+        if (C == 32 && Cout == 32) return launch_direct_conv<32, 32, _Float16>(a, s);
+        if (C == 32 && Cout == 64) return launch_direct_conv<32, 64, _Float16>(a, s);
+        return launch_direct_conv<64, 64, _Float16>(a, s);
+    }
+    if (C == 32 && Cout == 32) return launch_direct_conv<32, 32, __bf16>(a, s);
+    if (C == 32 && Cout == 64) return launch_direct_conv<32, 64, __bf16>(a, s);
+    return launch_direct_conv<64, 64, __bf16>(a, s);
 }

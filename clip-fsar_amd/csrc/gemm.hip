@@ -842,7 +842,7 @@ constexpr int STAGE10 = (BM4 + BN4) * ROWB10;       // 64 KiB
 // CONV: the X operand is gathered on the fly from an NHWC activation tensor (implicit GEMM for nn.Conv2d(3, padding=1),
 // few_shot.py:196): row m = output pixel (f, y, x), K index kk = tap * C + c with tap = ky * 3 + kx; a lane's 16-byte chunk
 // (8 channels) of K tile kt comes from pixel (y + ky - 1, x + kx - 1) or is zero outside the image -- no im2col matrix.
-template <typename TO, int ACT, bool HAS_RES, bool PERSIST, bool CONV = false>
+template <typename TO, int ACT, bool HAS_RES, bool PERSIST, bool CONV = false, typename TI = __bf16>
 __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -951,8 +951,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_p10(GemmArgs p) {
     auto mfma_one = [&](auto J, uint4 (&xf)[4], uint4 (&wf)[4]) {
         constexpr int j = decltype(J)::value;
         constexpr int ni = j >> 2, mi = j & 3;
-        acc[ni >> 1][mi][ni & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]), acc[ni >> 1][mi][ni & 1], 0, 0, 0);
+        acc[ni >> 1][mi][ni & 1] = cfsar_mfma_32x32x16<TI>(wf[ni], xf[mi], acc[ni >> 1][mi][ni & 1]);
     };
     // one 128-byte K tile; cur / nxt = LDS stage of tile kt / kt+1.  WRITE: tile kt+1 exists (its registers are written
     // to LDS and its first fragments are prefetched); LOAD: tile kt+2 exists
@@ -1056,10 +1055,10 @@ static inline int persistent_grid() {
     return n >= 8 ? n : 8;
 }
 
-template <typename TO, int ACT, bool HAS_RES, bool PERSIST, bool CONV = false>
+template <typename TO, int ACT, bool HAS_RES, bool PERSIST, bool CONV = false, typename TI = __bf16>
 int launch_p10_inst(const GemmArgs& a, hipStream_t s) {
-    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&gemm_kernel_p10<TO, ACT, HAS_RES, PERSIST, CONV>), LDS4, "cfsar_gemm")) return rc;
-    hipLaunchKernelGGL((gemm_kernel_p10<TO, ACT, HAS_RES, PERSIST, CONV>), dim3(PERSIST ? persistent_grid() : a.ntiles), dim3(256), LDS4, s, a);
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&gemm_kernel_p10<TO, ACT, HAS_RES, PERSIST, CONV, TI>), LDS4, "cfsar_gemm")) return rc;
+    hipLaunchKernelGGL((gemm_kernel_p10<TO, ACT, HAS_RES, PERSIST, CONV, TI>), dim3(PERSIST ? persistent_grid() : a.ntiles), dim3(256), LDS4, s, a);
     return cfsar_check_launch("cfsar_gemm(p10)");
 }
 
@@ -1083,7 +1082,7 @@ int launch_p10(const GemmArgs& a0, hipStream_t s) {
 // Per wave and K tile: 32 MFMAs, 24 fragment reads, 4 + 4 global loads, 4 + 4 LDS writes.
 // ============================================================================================================
 // PERSIST: one workgroup per CU walks the virtual block ids b, b + grid, ... (grid % 8 == 0 keeps a workgroup on its XCD's band)
-template <typename TO, int ACT, bool HAS_RES, bool PERSIST = false>
+template <typename TO, int ACT, bool HAS_RES, bool PERSIST = false, typename TI = __bf16>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p12(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1162,8 +1161,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p12(GemmArgs p) {
     auto mfma_one = [&](auto J, uint4 (&xf)[4], uint4 (&wf)[2]) {
         constexpr int j = decltype(J)::value;
         constexpr int ni = j >> 2, mi = j & 3;
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ni]), __builtin_bit_cast(bf16x8, xf[mi]),
-                                                              acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = cfsar_mfma_32x32x16<TI>(wf[ni], xf[mi], acc[mi][ni]);
     };
     // one 128-byte K tile = 4 sub-steps of 8 MFMAs; after MFMA j: a fragment read (j < 6) and, for j >= 4, one memory filler
     auto tile = [&](int kt, int cur, int nxt, auto LOAD, auto WRITE) {
@@ -1242,10 +1240,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p12(GemmArgs p) {
     }
 }
 
-template <typename TO, int ACT, bool HAS_RES, bool PERSIST = false>
+template <typename TO, int ACT, bool HAS_RES, bool PERSIST = false, typename TI = __bf16>
 int launch_p12_inst(const GemmArgs& a, hipStream_t s) {
-    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&gemm_kernel_p12<TO, ACT, HAS_RES, PERSIST>), LDS4, "cfsar_gemm")) return rc;
-    hipLaunchKernelGGL((gemm_kernel_p12<TO, ACT, HAS_RES, PERSIST>), dim3(PERSIST ? persistent_grid() : a.ntiles), dim3(512), LDS4, s, a);
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&gemm_kernel_p12<TO, ACT, HAS_RES, PERSIST, TI>), LDS4, "cfsar_gemm")) return rc;
+    hipLaunchKernelGGL((gemm_kernel_p12<TO, ACT, HAS_RES, PERSIST, TI>), dim3(PERSIST ? persistent_grid() : a.ntiles), dim3(512), LDS4, s, a);
     return cfsar_check_launch("cfsar_gemm(p12)");
 }
 
@@ -1269,6 +1267,28 @@ static int launch_p12_f16(const GemmArgs& a0, hipStream_t s) {
     if (a.row_group > 0 || a.res_mod > 0 || a.act != CFSAR_ACT_NONE || !a.res || a.K % 64 != 0) return -2;
     if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32)) return -2;
     return launch_p12_inst<_Float16, CFSAR_ACT_NONE, true, true>(a, s);
+}
+
+// fp16 operands (the RN50 tower's fp16 mode: 1x1 convs and the attention pool's k / v GEMM): bias [+ fp16 residual] [+ ReLU, a runtime
+// flag of the epilogue] -> fp16, or bias -> fp32
+template <bool PERSIST>
+static int launch_p12_h(const GemmArgs& a0, int out_dtype, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_n = (a.N + BN4 - 1) / BN4;
+    a.ntiles = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
+    if (a.row_group > 0 || a.res_mod > 0 || a.act != CFSAR_ACT_NONE || a.K % 64 != 0) return -2;
+    if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || (size_t)a.N * a.ldw * 2 >= (1ull << 32)) return -2;
+    if (out_dtype == CFSAR_F32) return a.res ? -2 : launch_p12_inst<float, CFSAR_ACT_NONE, false, PERSIST, _Float16>(a, s);
+    return a.res ? launch_p12_inst<_Float16, CFSAR_ACT_NONE, true, PERSIST, _Float16>(a, s)
+                 : launch_p12_inst<_Float16, CFSAR_ACT_NONE, false, PERSIST, _Float16>(a, s);
+}
+static int launch_p3_h(const GemmArgs& a0, int out_dtype, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_n = (a.N + BN2 - 1) / BN2;
+    if (a.row_group > 0 || a.res_mod > 0 || a.act != CFSAR_ACT_NONE) return -2;
+    if (out_dtype == CFSAR_F32) return a.res ? -2 : launch_p3_inst<_Float16, float, CFSAR_ACT_NONE, false, false>(a, s);
+    return a.res ? launch_p3_inst<_Float16, _Float16, CFSAR_ACT_NONE, true, false>(a, s)
+                 : launch_p3_inst<_Float16, _Float16, CFSAR_ACT_NONE, false, false>(a, s);
 }
 
 // ============================================================================================================
@@ -1512,9 +1532,9 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     CFSAR_REQUIRE(out_dtype == CFSAR_F32 || out_dtype == CFSAR_BF16 || out_dtype == CFSAR_F16, "cfsar_gemm: bad out_dtype %d", out_dtype);
     // fp16 output = a residual-stream update: 16-bit operands, no activation, a residual.  fp16 OPERANDS (the fp16 mode's patch embedding and
     // small-shape fallbacks; its block GEMMs are cfsar_gemm_lnfold / cfsar_gemm_residual_stats) go to fp16 or fp32 outputs.
-    CFSAR_REQUIRE(out_dtype != CFSAR_F16 || (in_dtype != CFSAR_F32 && act == CFSAR_ACT_NONE && residual),
-                  "cfsar_gemm: fp16 output needs 16-bit operands, no activation and a residual");
-    CFSAR_REQUIRE(in_dtype != CFSAR_F16 || (out_dtype != CFSAR_BF16 && !relu), "cfsar_gemm: fp16 operands write fp16 or fp32 outputs");
+    CFSAR_REQUIRE(out_dtype != CFSAR_F16 || (in_dtype != CFSAR_F32 && act == CFSAR_ACT_NONE && (residual || in_dtype == CFSAR_F16)),
+                  "cfsar_gemm: fp16 output needs 16-bit operands, no activation and (bf16 operands) a residual");
+    CFSAR_REQUIRE(in_dtype != CFSAR_F16 || out_dtype != CFSAR_BF16, "cfsar_gemm: fp16 operands write fp16 or fp32 outputs");
     const int esz = in_dtype == CFSAR_F32 ? 4 : 2;
     const int bk = ROWB / esz;
     CFSAR_REQUIRE(K % bk == 0, "cfsar_gemm: K=%d must be a multiple of %d for this dtype", K, bk);
@@ -1552,16 +1572,22 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     constexpr int forced = 0;
 #endif
     const long tiles4 = (long)((M + BM4 - 1) / BM4) * ((N + BN4 - 1) / BN4);
-    if (in_dtype == CFSAR_F16) {                  // v_mfma_f32_32x32x16_f16: the patch-embed scatter on the 256x128 kernel, anything else on v1
-        if (out_dtype == CFSAR_F16) {
-            if (M >= 1024 && (row_group > 0 || res_mod > 0)) {
-                GemmArgs b = a;
-                b.tiles_n = (N + BN2 - 1) / BN2;
-                return launch_p3_inst<_Float16, _Float16, CFSAR_ACT_NONE, true, true>(b, s);
-            }
-            return launch<_Float16, _Float16>(a, s);
+    if (in_dtype == CFSAR_F16) {                  // v_mfma_f32_32x32x16_f16: the ViT tower's patch-embed scatter and the RN50 tower's fp16 mode
+        if (out_dtype == CFSAR_F16 && M >= 1024 && (row_group > 0 || res_mod > 0) && residual && !relu) {
+            GemmArgs b = a;
+            b.tiles_n = (N + BN2 - 1) / BN2;
+            return launch_p3_inst<_Float16, _Float16, CFSAR_ACT_NONE, true, true>(b, s);
         }
-        return launch<_Float16, float>(a, s);
+        // same tile policy as the bf16 operands below (the residual forms stay off the ViT-block kernel: its fp16 residual epilogue adds in
+        // packed fp16 -- a second rounding the RN50 mode's budget has no room for, tools/numerics_lab_rn.py dr=1)
+        if (row_off == 0 && (res_dtype == CFSAR_F16 || !residual) && forced == 0) {
+            int rc = -2;
+            if (tiles4 >= 512 && N >= 256) rc = launch_p12_h<true>(a, out_dtype, s);
+            else if (N >= 256 && (tiles4 >= 240 || (tiles4 >= 128 && K >= 2048))) rc = launch_p12_h<false>(a, out_dtype, s);
+            if (rc == -2 && M >= 1024) rc = launch_p3_h(a, out_dtype, s);
+            if (rc != -2) return rc;
+        }
+        return out_dtype == CFSAR_F16 ? launch<_Float16, _Float16>(a, s) : launch<_Float16, float>(a, s);
     }
     // fp32, at most 192 rows: the skinny kernel (the temporal head and the final ViT projection of one or two episodes)
     if (in_dtype == CFSAR_F32 && out_dtype == CFSAR_F32 && res_dtype == CFSAR_F32 && res_mod == 0 && K % 32 == 0 &&
@@ -1663,8 +1689,8 @@ extern "C" int cfsar_conv3x3_nhwc(const void* in, const void* W, void* out, cons
     CFSAR_REQUIRE(F > 0 && H > 0 && Wd > 0 && Cout > 0 && Cout % 4 == 0, "cfsar_conv3x3_nhwc: bad shape");
     CFSAR_REQUIRE(C >= 8 && (C & (C - 1)) == 0, "cfsar_conv3x3_nhwc: C=%d must be a power of two >= 8", C);
     CFSAR_REQUIRE(ldw % 64 == 0 && ldw >= 9 * C && ldw < 16 * C + 64, "cfsar_conv3x3_nhwc: ldw=%d must be round_up(9*C, 64)", ldw);
-    CFSAR_REQUIRE(out_dtype == CFSAR_F32 || out_dtype == CFSAR_BF16, "cfsar_conv3x3_nhwc: bad out_dtype %d", out_dtype);
-    CFSAR_REQUIRE(res_dtype == CFSAR_F32 || res_dtype == CFSAR_BF16, "cfsar_conv3x3_nhwc: bad res_dtype %d", res_dtype);
+    CFSAR_REQUIRE(out_dtype == CFSAR_F32 || out_dtype == CFSAR_BF16 || out_dtype == CFSAR_F16, "cfsar_conv3x3_nhwc: bad out_dtype %d", out_dtype);
+    CFSAR_REQUIRE(res_dtype == CFSAR_F32 || res_dtype == CFSAR_BF16 || res_dtype == CFSAR_F16, "cfsar_conv3x3_nhwc: bad res_dtype %d", res_dtype);
     CFSAR_REQUIRE(ldo >= Cout && (!residual || (ldr >= Cout && ldr % 4 == 0)), "cfsar_conv3x3_nhwc: bad ldo/ldr");
     const long long M = (long long)F * H * Wd;
     CFSAR_REQUIRE(M * C * 2 < (1ll << 32) && (long long)Cout * ldw * 2 < (1ll << 32), "cfsar_conv3x3_nhwc: tensor too large for 32-bit offsets");
@@ -1691,9 +1717,23 @@ extern "C" int cfsar_conv3x3_nhwc(const void* in, const void* W, void* out, cons
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int conv_variant = 0;     // 3 / 4: force the 256x128 / 256x64 tile (A/B history: tools/rn_gemm_ab.py)
     // Cin, Cout in {32, 64}: the direct kernel (conv.hip: the input ring in LDS, weights in registers) instead of the 9-fold gather
-    if (out_dtype == CFSAR_BF16 && !residual && conv_variant == 0 && !g_no_direct_conv) {
-        const int rc = cfsar_conv3x3_direct(in, W, out, bias, F, H, Wd, C, Cout, ldw, ldo, relu, s);
+    if (out_dtype != CFSAR_F32 && !residual && conv_variant == 0 && !g_no_direct_conv) {
+        const int rc = cfsar_conv3x3_direct(in, W, out, bias, F, H, Wd, C, Cout, ldw, ldo, relu, out_dtype == CFSAR_F16, s);
         if (rc != -2) return rc;
+    }
+    if (out_dtype == CFSAR_F16) {                  // fp16 NHWC in and out (the RN50 tower's fp16 mode): same tiles by Cout
+        if (Cout <= 64) {
+            a.tiles_n = (Cout + 63) / 64;
+            return residual ? launch_p3_inst<_Float16, _Float16, CFSAR_ACT_NONE, true, false, true, true>(a, s)
+                            : launch_p3_inst<_Float16, _Float16, CFSAR_ACT_NONE, false, false, true, true>(a, s);
+        }
+        if (Cout <= 128) {
+            a.tiles_n = (Cout + BN2 - 1) / BN2;
+            return residual ? launch_p3_inst<_Float16, _Float16, CFSAR_ACT_NONE, true, false, true>(a, s)
+                            : launch_p3_inst<_Float16, _Float16, CFSAR_ACT_NONE, false, false, true>(a, s);
+        }
+        return residual ? launch_p10_inst<_Float16, CFSAR_ACT_NONE, true, false, true, _Float16>(a, s)
+                        : launch_p10_inst<_Float16, CFSAR_ACT_NONE, false, false, true, _Float16>(a, s);
     }
     if (out_dtype == CFSAR_BF16 && (conv_variant == 4 || (conv_variant == 0 && Cout <= 64))) {     // 256x64 tile
         a.tiles_n = (Cout + 63) / 64;

@@ -482,9 +482,12 @@ def attnpool_attend(q, kv, out, F_, T, heads, head_dim, scale):
 
 
 def conv3x3(x, w, out, F_, H, W, C, bias=None, residual=None, relu=False):
-    """Implicit-GEMM 3x3 / pad 1 / stride 1 conv on bf16 NHWC activations (include/clipfsar_hip.h: cfsar_conv3x3_nhwc)."""
-    if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
-        raise RuntimeError("conv3x3: bf16 activations and weights only")
+    """Implicit-GEMM / direct 3x3, pad 1, stride 1 conv on bf16 (or fp16: then `out` is fp16 too) NHWC activations
+    (include/clipfsar_hip.h: cfsar_conv3x3_nhwc)."""
+    if x.dtype not in (torch.bfloat16, torch.float16) or w.dtype != x.dtype:
+        raise RuntimeError("conv3x3: bf16 or fp16 activations, weights of the same type")
+    if (x.dtype == torch.float16) != (out.dtype == torch.float16):
+        raise RuntimeError("conv3x3: fp16 activations write fp16 outputs (and only they do)")
     _check(lib().cfsar_conv3x3_nhwc(_dev(x, None, "x"), _dev(w, None, "w"), _dev(out, None, "out"),
                                     _opt(bias, torch.float32, "bias"), _opt(residual, None, "residual"), F_, H, W, C,
                                     w.shape[0], w.shape[1], out.shape[-1], residual.shape[-1] if residual is not None else 0,

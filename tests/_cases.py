@@ -29,13 +29,13 @@ MEASURED_DLOGITS = {
     "t_5w2s_T4_sd": {"bf16": 0.004334, "fp16": 0.0009908},
     "t197_5w1s_T2": {"bf16": 0.008597, "fp16": 0.0007835},
     "t257_5w1s_T2": {"bf16": 0.003436, "fp16": 0.0007384},
-    "rn_t_5w2s_T4": {"bf16": 0.001986, "fp16": None},
+    "rn_t_5w2s_T4": {"bf16": 0.001986, "fp16": 0.00027},
     "t_outlier_5w1s_T8": {"bf16": 0.0007324, "fp16": 0.000144},
     "t197_outlier_5w1s_T2": {"bf16": 0.0002892, "fp16": 0.0001543},
     "cfg2_B16_5w1s_T8": {"bf16": 0.003892, "fp16": 0.0006766},
     "cfg3_B16_5w5s_T8_mb": {"bf16": 0.003086, "fp16": 0.0005069},
     "cfg4_L14_5w1s_T16": {"bf16": 0.00545, "fp16": 0.0004578},
-    "rn50_5w1s_T2": {"bf16": 0.008433, "fp16": None},
+    "rn50_5w1s_T2": {"bf16": 0.008433, "fp16": 0.000374},
 }
 
 

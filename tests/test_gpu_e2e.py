@@ -100,9 +100,10 @@ def test_small_cases_bf16_bounded(name):
     assert torch.equal(logits[0].argmax(1)[clear], ref.argmax(1)[clear])
 
 
-@pytest.mark.parametrize("name", [n for n in SMALL_CASES if not n.startswith("rn")])
+@pytest.mark.parametrize("name", SMALL_CASES)
 def test_small_cases_fp16_bounded(name):
-    """precision "fp16" (IEEE-half operands everywhere) on the small ViT cases: about 4 x closer to the reference than bf16."""
+    """precision "fp16" (IEEE-half operands everywhere) on the small cases (ViT and, round 4, the RN tower): about 4-8 x closer to the
+    reference than bf16."""
     g = load_golden(name)
     m = g["meta"]
     a, sd, tt, te, ep = case_inputs(m)
@@ -155,12 +156,47 @@ def test_fp16_mode_steady_parity_statistic():
 
 
 def test_fp16_mode_refuses_what_it_cannot_represent():
-    """The RN50 tower has no fp16 path; the engine says so instead of silently running bf16."""
+    """A checkpoint whose BatchNorm-folded conv weights leave the fp16 range cannot run the RN tower's fp16 mode; the engine says so
+    instead of producing infinities."""
     g = load_golden("rn_t_5w2s_T4")
     m = g["meta"]
     a, sd, tt, te, ep = case_inputs(m)
-    with pytest.raises(ValueError, match="precision"):
+    sd = dict(sd)
+    sd["backbone.layer1.0.bn2.weight"] = sd["backbone.layer1.0.bn2.weight"] * 1e7
+    with pytest.raises(ValueError, match="fp16 range"):
         run_engine(m, a, sd, tt, te, [ep], "fp16")
+    run_engine(m, a, sd, tt, te, [ep], "bf16")
+
+
+@pytest.mark.parametrize("lowfreq", [0.0, 2.0])
+def test_rn50_fp16_mode_steady_parity_statistic(lowfreq):
+    """CLIP RN50 tower, precision "fp16" (IEEE-half activations and weights, fp32 accumulation, one rounding per stored tensor) against the fp32
+    validation mode on 8 fresh 8-frame episodes (200 logits).  The tower's features carry a relative error of 8e-4 (bf16: 6e-3; hardware =
+    the CPU model tools/numerics_lab_rn.py to three digits, tools/rn_fp16_probe.py); what that is in the logits depends on the episodes' contrast:
+      lowfreq 0 (white-noise frames, the bench's synthetic episodes; logits spread 0.1): 1.7e-4 max (bf16: 1.2e-3) -- inside the north-star 1e-3;
+      lowfreq 2 (smooth frames as in the RN goldens; spread 1.5): rms 8e-4, max 2.5e-3 (bf16: 6e-3 / 1.7e-2) -- NOT inside 1e-3 (the 2-frame golden is: 3.7e-4);
+    three comparable sources (block outputs, inner activations, weights: 4-5e-4 each), so nothing short of more than 11 bits per stored
+    activation closes it: precision "fp32" is the RN50 mode for a 1e-3 contract on such inputs.  Bounds: 2 x measured."""
+    g = load_golden("rn50_5w1s_T2")
+    m = dict(g["meta"])
+    m["T"] = 8
+    m["lowfreq"] = lowfreq
+    eps = []
+    for e in range(8):
+        a, sd, tt, te, ep = case_inputs(m, episode=100 + e)
+        eps.append(ep)
+    l32, _ = run_engine(m, a, sd, tt, te, eps, "fp32")
+    l16, _ = run_engine(m, a, sd, tt, te, eps, "fp16")
+    lb, _ = run_engine(m, a, sd, tt, te, eps, "bf16")
+    d, db = l16 - l32, lb - l32
+    rms, rms_b = float(d.pow(2).mean().sqrt()), float(db.pow(2).mean().sqrt())
+    print("RN50 lowfreq %.0f, 8 episodes: fp16 vs fp32 rms %.2e max %.2e; bf16 rms %.2e max %.2e; spread %.2f" % (
+        lowfreq, rms, float(d.abs().max()), rms_b, float(db.abs().max()), float(l32.max() - l32.min())))
+    assert rms < rms_b / 4.0, (rms, rms_b)                          # three more mantissa bits: 8 x in the features
+    if lowfreq == 0.0:
+        assert float(d.abs().max()) < 0.5 * NORTH_STAR_TOLERANCE, float(d.abs().max())
+    else:
+        assert rms < 1.6e-3 and float(d.abs().max()) < 5e-3, (rms, float(d.abs().max()))
 
 
 def test_batched_episodes_match_single(tmp_path):
@@ -257,7 +293,7 @@ def test_cfg3_cfg4_full_size(name, tol_feat):
     assert maxdiff(cl[0], g["class_logits"]) < 1e-3
     lb, _ = run_engine(m, a, sd, tt, te, [ep], "bf16")
     assert maxdiff(lb[0], g["logits"]) < bound(name, "bf16")
-    if a.get("kind") != "rn":
+    if True:                                                       # every tower has its fp16 mode (RN50: round 4)
         lh, _ = run_engine(m, a, sd, tt, te, [ep], "fp16")
         # Round 4: the fp16 mode (single-rounding residual add, two-word stream, per-frame low-word correction of all four GEMMs' weights) is
         # held to the NORTH-STAR 1e-3 on every full-size configuration: goldens 6.1e-4 (cfg2), 3.7e-4 (cfg3), 3.0e-4 (cfg4); over 16 fresh

@@ -284,11 +284,15 @@ def test_otam_known_answers(hip):
 
 
 # ---------------------------------------------------------------------------------------------- N3: RN50 tower ops
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+_TD = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+_TOL = {"f32": 2e-4, "bf16": 2e-2, "f16": 2.5e-3}           # of max |ref|: the operands are rounded first, so this is accumulation order + the output's rounding
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_gemm_ex_relu_and_bf16_residual(hip, dtype):
     """cfsar_gemm_ex: relu applied LAST, residual in the activation dtype (Bottleneck: relu(bn3(conv3) + identity),
-    few_shot.py:213-226)."""
-    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    few_shot.py:213-226).  f16: the RN50 tower's fp16 mode (fp32 add, ONE rounding)."""
+    td = _TD[dtype]
     for (M, N, K) in [(196 * 3, 256, 64), (49 * 5, 2048, 512), (1000, 64, 576)]:
         A = _rand(M, K, seed=1).to(td)
         W = _rand(N, K, seed=2, scale=K ** -0.5).to(td)
@@ -297,7 +301,7 @@ def test_gemm_ex_relu_and_bf16_residual(hip, dtype):
         ref = torch.relu(A.float() @ W.float().t() + bias + res.float())
         out = torch.empty(M, N, device="cuda", dtype=td)
         hip.gemm(A.cuda(), W.cuda(), out, bias=bias.cuda(), residual=res.cuda(), relu=True)
-        tol = 2e-4 if dtype == "f32" else 2e-2
+        tol = _TOL[dtype]
         assert maxdiff(out.float().cpu(), ref) < tol * max(1.0, float(ref.abs().max()))
         assert float(out.float().min()) >= 0.0
         out2 = torch.empty(M, N, device="cuda", dtype=td)
@@ -306,13 +310,13 @@ def test_gemm_ex_relu_and_bf16_residual(hip, dtype):
         assert maxdiff(out2.float().cpu(), ref2) < tol * max(1.0, float(ref2.abs().max()))
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("stride,C,H", [(1, 64, 14), (2, 3, 32), (1, 32, 9), (2, 8, 7)])
 def test_conv3x3_as_im2col_gemm(hip, dtype, stride, C, H):
     """nchw_to_nhwc + im2col3x3_nhwc + GEMM with tap-major weights == nn.Conv2d(3, padding=1, stride) (bit-exact
     gather: the only arithmetic is in the GEMM)."""
     import torch.nn.functional as F
-    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    td = _TD[dtype]
     Fn, W_, Co = 3, H + 2, 32
     x = _rand(Fn, C, H, W_, seed=5)
     w = _rand(Co, C, 3, 3, seed=6, scale=(9 * C) ** -0.5)
@@ -320,7 +324,7 @@ def test_conv3x3_as_im2col_gemm(hip, dtype, stride, C, H):
     hip.nchw_to_nhwc(x.cuda(), xd)
     assert torch.equal(xd.float().cpu(), x.to(td).float().permute(0, 2, 3, 1))
     Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
-    kq = 64 if dtype == "bf16" else 32
+    kq = 32 if dtype == "f32" else 64
     kpad = -(-9 * C // kq) * kq
     cols = torch.full((Fn * Ho * Wo, kpad), float("nan"), device="cuda", dtype=td)
     hip.im2col3x3(xd, cols, Fn, H, W_, C, stride)
@@ -340,24 +344,24 @@ def test_conv3x3_as_im2col_gemm(hip, dtype, stride, C, H):
     assert maxdiff(out.cpu(), ref) < (2e-4 if dtype == "f32" else 2e-2) * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_avgpool_and_attnpool_tokens(hip, dtype):
-    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    td = _TD[dtype]
     Fn, H, W_, C = 3, 14, 14, 64
     x = _rand(Fn, H, W_, C, seed=7).to(td)
     out = torch.empty(Fn, H // 2, W_ // 2, C, device="cuda", dtype=td)
     hip.avgpool2x2(x.cuda(), out, Fn, H, W_, C)
     ref = x.float().reshape(Fn, H // 2, 2, W_ // 2, 2, C).mean((2, 4))
-    assert maxdiff(out.float().cpu(), ref) < (1e-6 if dtype == "f32" else 1e-2)
+    assert maxdiff(out.float().cpu(), ref) < {"f32": 1e-6, "bf16": 1e-2, "f16": 1.5e-3}[dtype]
     # odd sizes floor like nn.AvgPool2d(2)
     xo = _rand(2, 7, 9, 8, seed=8).to(td)
     oo = torch.empty(2, 3, 4, 8, device="cuda", dtype=td)
     hip.avgpool2x2(xo.cuda(), oo, 2, 7, 9, 8)
-    assert maxdiff(oo.float().cpu(), xo.float()[:, :6, :8].reshape(2, 3, 2, 4, 2, 8).mean((2, 4))) < (1e-6 if dtype == "f32" else 1e-2)
+    assert maxdiff(oo.float().cpu(), xo.float()[:, :6, :8].reshape(2, 3, 2, 4, 2, 8).mean((2, 4))) < {"f32": 1e-6, "bf16": 1e-2, "f16": 1.5e-3}[dtype]
     xs = _rand(2, 6, 4, 12, seed=18).to(td)                 # C % 8 != 0: the scalar kernel
     os_ = torch.empty(2, 3, 2, 12, device="cuda", dtype=td)
     hip.avgpool2x2(xs.cuda(), os_, 2, 6, 4, 12)
-    assert maxdiff(os_.float().cpu(), xs.float().reshape(2, 3, 2, 2, 2, 12).mean((2, 4))) < (1e-6 if dtype == "f32" else 1e-2)
+    assert maxdiff(os_.float().cpu(), xs.float().reshape(2, 3, 2, 2, 2, 12).mean((2, 4))) < {"f32": 1e-6, "bf16": 1e-2, "f16": 1.5e-3}[dtype]
     # AttentionPool2d tokens (few_shot.py:446-448): [mean ; x] + pos
     HW = 49
     t = _rand(Fn, HW, C, seed=9).to(td)
@@ -365,7 +369,7 @@ def test_avgpool_and_attnpool_tokens(hip, dtype):
     tok = torch.empty(Fn, HW + 1, C, device="cuda", dtype=td)
     hip.attnpool_tokens(t.cuda(), pos.cuda(), tok, Fn, HW, C)
     ref_tok = torch.cat([t.float().mean(1, keepdim=True), t.float()], 1) + pos
-    assert maxdiff(tok.float().cpu(), ref_tok) < (2e-6 if dtype == "f32" else 3e-2)
+    assert maxdiff(tok.float().cpu(), ref_tok) < {"f32": 2e-6, "bf16": 3e-2, "f16": 4e-3}[dtype]
 
 
 def _gemm_epilogue_checks(hip, M, N, K, tag):
@@ -420,83 +424,98 @@ def test_gemm_forced_variants_dev(hip, variant):
         L.cfsar_debug_set_gemm_variant(0, 0)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,K", [(125440, 1024, 256), (31360, 2048, 512), (140000, 512, 128), (70001, 1024, 320)])
-def test_rn50_conv3_residual_relu_on_the_persistent_kernel(hip, M, N, K):
+def test_rn50_conv3_residual_relu_on_the_persistent_kernel(hip, M, N, K, dtype):
     """relu(A W^T + bias + identity) in bf16 at RN50 batch scale (>= 512 tiles: the persistent kernel of csrc/gemm_vit.hip, bf16-residual
-    instance; K = 128 its two-K-tile form) against the fp32 product of the bf16-rounded operands."""
+    instance; K = 128 its two-K-tile form) against the fp32 product of the bf16-rounded operands.  f16 (the tower's fp16 mode): the
+    persistent 256 x 256 kernel of csrc/gemm.hip on fp16 operands, fp32 epilogue, one rounding."""
+    td, tol = _TD[dtype], _TOL[dtype]
     g = torch.Generator(device="cuda").manual_seed(5)
-    A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
-    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    A = torch.randn(M, K, device="cuda", generator=g).to(td)
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(td)
     bias = torch.randn(N, device="cuda", generator=g)
-    r = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
-    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    r = torch.randn(M, N, device="cuda", generator=g).to(td)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=td)
     hip.gemm(A, W, out, bias=bias, residual=r, relu=True)
     ref = torch.relu(A.float() @ W.float().t() + bias + r.float())
     assert not torch.isnan(out.float()).any()
-    assert float((out.float() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
+    assert float((out.float() - ref).abs().max()) < tol * max(1.0, float(ref.abs().max()))
     out3 = torch.full_like(out, float("nan"))                  # relu(A W^T + bias): conv1 of the bottlenecks (plain instance with ReLU)
     hip.gemm(A, W, out3, bias=bias, relu=True)
     ref3 = torch.relu(A.float() @ W.float().t() + bias)
-    assert float((out3.float() - ref3).abs().max()) < 2e-2 * max(1.0, float(ref3.abs().max()))
+    assert float((out3.float() - ref3).abs().max()) < tol * max(1.0, float(ref3.abs().max()))
     out2 = torch.full_like(out, float("nan"))                  # no ReLU
     hip.gemm(A, W, out2, bias=bias, residual=r)
     ref2 = A.float() @ W.float().t() + bias + r.float()
-    assert float((out2.float() - ref2).abs().max()) < 2e-2 * max(1.0, float(ref2.abs().max()))
+    assert float((out2.float() - ref2).abs().max()) < tol * max(1.0, float(ref2.abs().max()))
+    if dtype == "f16":                                         # fp32 output (the attention pool's k / v GEMM)
+        o32 = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32)
+        hip.gemm(A, W, o32, bias=bias)
+        assert float((o32 - (A.float() @ W.float().t() + bias)).abs().max()) < 2e-4 * max(1.0, float(ref3.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("C,H,W_,Co,res", [(32, 12, 10, 64, False), (32, 11, 13, 32, True), (64, 9, 14, 64, False), (128, 7, 7, 128, True), (8, 5, 6, 260, True), (64, 10, 9, 256, False)])
-def test_conv3x3_implicit_gemm(hip, C, H, W_, Co, res):
+def test_conv3x3_implicit_gemm(hip, C, H, W_, Co, res, dtype):
     """cfsar_conv3x3_nhwc (patch gather inside the GEMM operand staging) == nn.Conv2d(3, padding=1) + bias (+ residual) +
     ReLU on bf16-rounded operands; ragged M (F*H*W not a multiple of 256), ragged N, image borders, K padding."""
     import torch.nn.functional as F
+    td, tol = _TD[dtype], _TOL[dtype]
     Fn = 5
-    x = _rand(Fn, C, H, W_, seed=21).to(torch.bfloat16)
-    w = _rand(Co, C, 3, 3, seed=22, scale=(9 * C) ** -0.5).to(torch.bfloat16)
+    x = _rand(Fn, C, H, W_, seed=21).to(td)
+    w = _rand(Co, C, 3, 3, seed=22, scale=(9 * C) ** -0.5).to(td)
     bias = _rand(Co, seed=23)
     kpad = -(-9 * C // 64) * 64
-    wt = torch.zeros(Co, kpad, dtype=torch.bfloat16)
+    wt = torch.zeros(Co, kpad, dtype=td)
     wt[:, :9 * C] = w.permute(0, 2, 3, 1).reshape(Co, 9 * C)
     xd = x.permute(0, 2, 3, 1).contiguous().cuda()                                       # NHWC
     ref = F.conv2d(x.float(), w.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co) + bias
-    r = _rand(Fn * H * W_, Co, seed=24).to(torch.bfloat16) if res else None
+    r = _rand(Fn * H * W_, Co, seed=24).to(td) if res else None
     if res:
         ref = ref + r.float()
     ref = torch.relu(ref)
-    out = torch.full((Fn * H * W_, Co), float("nan"), device="cuda", dtype=torch.bfloat16)
+    out = torch.full((Fn * H * W_, Co), float("nan"), device="cuda", dtype=td)
     hip.conv3x3(xd, wt.cuda(), out, Fn, H, W_, C, bias=bias.cuda(), residual=r.cuda() if res else None, relu=True)
-    assert maxdiff(out.float().cpu(), ref) < 2e-2 * max(1.0, float(ref.abs().max()))
+    assert maxdiff(out.float().cpu(), ref) < tol * max(1.0, float(ref.abs().max()))
+    if dtype == "f16":
+        with pytest.raises(RuntimeError):                      # fp16 activations write fp16 outputs
+            hip.conv3x3(xd, wt.cuda(), torch.empty(Fn * H * W_, Co, device="cuda", dtype=torch.float32), Fn, H, W_, C)
+        return
     out32 = torch.empty(Fn * H * W_, Co, device="cuda", dtype=torch.float32)
     hip.conv3x3(xd, wt.cuda(), out32, Fn, H, W_, C, bias=bias.cuda())
     ref2 = F.conv2d(x.float(), w.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co) + bias
     assert maxdiff(out32.cpu(), ref2) < 2e-3 * max(1.0, float(ref2.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("C,Co,Fn,H,W_", [(32, 32, 24, 112, 112), (32, 64, 7, 112, 112), (64, 64, 90, 56, 56), (32, 64, 3, 9, 127),
                                          (64, 64, 2, 33, 5), (32, 32, 2, 8, 8), (64, 64, 3, 6, 63)])
-def test_conv3x3_direct_kernel(hip, C, Co, Fn, H, W_):
+def test_conv3x3_direct_kernel(hip, C, Co, Fn, H, W_, dtype):
     """The direct kernel behind cfsar_conv3x3_nhwc for Cin, Cout in {32, 64} (csrc/conv.hip: LDS pixel ring + weights in registers) ==
     relu(nn.Conv2d(3, padding=1) + bias) on bf16-rounded operands: many tiles per workgroup (the ring wraps several times), the
     widest image the halo allows (W = 127), images narrower than the halo, a ragged last tile, frame borders inside a tile."""
     import torch.nn.functional as F
+    td, tol = _TD[dtype], _TOL[dtype]
     g = torch.Generator().manual_seed(77)
-    x = (torch.randn(Fn, C, H, W_, generator=g)).to(torch.bfloat16).cuda()
-    w = (torch.randn(Co, C, 3, 3, generator=g) * (9 * C) ** -0.5).to(torch.bfloat16).cuda()
+    x = (torch.randn(Fn, C, H, W_, generator=g)).to(td).cuda()
+    w = (torch.randn(Co, C, 3, 3, generator=g) * (9 * C) ** -0.5).to(td).cuda()
     bias = torch.randn(Co, generator=g).cuda()
     kpad = -(-9 * C // 64) * 64
-    wt = torch.zeros(Co, kpad, dtype=torch.bfloat16, device="cuda")
+    wt = torch.zeros(Co, kpad, dtype=td, device="cuda")
     wt[:, :9 * C] = w.permute(0, 2, 3, 1).reshape(Co, 9 * C)
     xd = x.permute(0, 2, 3, 1).contiguous()
     ref = torch.relu(F.conv2d(x.float(), w.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co) + bias)
-    out = torch.full((Fn * H * W_, Co), float("nan"), device="cuda", dtype=torch.bfloat16)
+    out = torch.full((Fn * H * W_, Co), float("nan"), device="cuda", dtype=td)
     hip.conv3x3(xd, wt, out, Fn, H, W_, C, bias=bias, relu=True)
     torch.cuda.synchronize()
     d = (out.float() - ref).abs()
     assert not torch.isnan(out.float()).any()
-    assert float(d.max()) < 2e-2 * max(1.0, float(ref.abs().max())), (float(d.max()), int(d.argmax()) // Co)
+    assert float(d.max()) < tol * max(1.0, float(ref.abs().max())), (float(d.max()), int(d.argmax()) // Co)
     out2 = torch.full_like(out, float("nan"))                    # no ReLU, no bias
     hip.conv3x3(xd, wt, out2, Fn, H, W_, C)
     ref2 = F.conv2d(x.float(), w.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
-    assert float((out2.float() - ref2).abs().max()) < 2e-2 * max(1.0, float(ref2.abs().max()))
+    assert float((out2.float() - ref2).abs().max()) < tol * max(1.0, float(ref2.abs().max()))
 
 
 @pytest.mark.parametrize("T,heads,hd", [(50, 32, 64), (5, 4, 8), (82, 2, 128)])
@@ -530,6 +549,9 @@ def test_stem_conv_direct(hip, Co, H, W_):
     out16 = torch.empty(3 * Ho * Wo, Co, device="cuda", dtype=torch.bfloat16)
     hip.stem_conv(x.cuda(), w.cuda(), b.cuda(), out16)
     assert maxdiff(out16.float().cpu().reshape(ref.shape), ref) < 2e-2
+    outh = torch.empty(3 * Ho * Wo, Co, device="cuda", dtype=torch.float16)                 # the tower's fp16 mode
+    hip.stem_conv(x.cuda(), w.cuda(), b.cuda(), outh)
+    assert torch.equal(outh.cpu().reshape(ref.shape), out.cpu().reshape(ref.shape).half())   # the same fp32 sums, rounded once
 
 
 def test_fp16_residual_stream_ops(hip):
