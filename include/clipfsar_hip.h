@@ -93,13 +93,16 @@ int cfsar_gemm(const void* A, const void* W, void* out, const float* bias, const
                int K, int lda, int ldw, int ldo, int ldr, int in_dtype, int out_dtype, int act, int row_group,
                int row_gap, int row_off, int res_mod, int res_off, cfsar_stream_t stream);
 
-/* Same as cfsar_gemm with two extras used by the RN50 tower (N3): the residual may be bf16 (res_dtype) and, when
- * relu != 0, max(.,0) is applied LAST (after bias, activation and residual): conv+BN(+identity)+ReLU, few_shot.py:213-226. */
+/* Same as cfsar_gemm with two extras used by the RN50 tower (N3): the residual may be bf16 / fp16 (res_dtype) and, when
+ * relu != 0, max(.,0) is applied LAST (after bias, activation and residual): conv+BN(+identity)+ReLU, few_shot.py:213-226.
+ * fp16 operands (in_dtype CFSAR_F16: the tower's fp16 numerics mode) write fp16 or fp32 outputs; bias, residual and ReLU are
+ * applied to the fp32 accumulator and the result is rounded ONCE. */
 int cfsar_gemm_ex(const void* A, const void* W, void* out, const float* bias, const void* residual, int M, int N,
                   int K, int lda, int ldw, int ldo, int ldr, int in_dtype, int out_dtype, int act, int row_group,
                   int row_gap, int row_off, int res_mod, int res_off, int res_dtype, int relu, cfsar_stream_t stream);
 
-/* ---- N3 ModifiedResNet ("RN50") tower helpers (few_shot.py:182-227, 542-602); activations are NHWC.
+/* ---- N3 ModifiedResNet ("RN50") tower helpers (few_shot.py:182-227, 542-602); activations are NHWC; dtype / out_dtype is
+ * CFSAR_BF16, CFSAR_F16 (the tower's fp16 numerics mode) or CFSAR_F32 (validation mode) on every one of them.
  * cfsar_nchw_to_nhwc: frames [F,C,H,W] f32 -> [F,H,W,C] (out_dtype).
  * cfsar_im2col3x3_nhwc: 3x3 / pad 1 / stride 1|2 gather, in [F,H,W,C] -> out [F*Ho*Wo, k_pad], column (ky*3+kx)*C + c,
  *   zeros outside the image and in pad columns (nn.Conv2d(k=3, padding=1) as a GEMM with tap-major weights).
@@ -126,10 +129,12 @@ int cfsar_attnpool_attend(const float* q, const float* kv, float* out, int F, in
                           cfsar_stream_t stream);
 
 /* nn.Conv2d(C, Cout, 3, padding=1, bias=False) + folded BatchNorm (+ identity) + ReLU of the RN50 tower (few_shot.py:196,
- * 213-226) as ONE implicit-GEMM launch on bf16 NHWC activations: the 3x3 patches are gathered inside the GEMM's operand
- * staging (no im2col matrix in HBM).  in [F,H,W,C] bf16, C a power of two >= 8; W [Cout, ldw] bf16, tap-major columns
- * (ky*3+kx)*C + c, zero-padded to ldw = round_up(9*C, 64); out [F*H*W, ldo] (out_dtype); bias fp32 [Cout] or NULL;
- * residual [F*H*W, ldr] (res_dtype) or NULL; relu != 0 applies max(., 0) last. */
+ * 213-226) as ONE launch on 16-bit NHWC activations: the 3x3 patches are gathered inside the GEMM's operand staging (no
+ * im2col matrix in HBM), or, for Cin, Cout in {32, 64}, read from an LDS ring of the pixel stream (csrc/conv.hip).
+ * in [F,H,W,C] bf16, C a power of two >= 8; W [Cout, ldw] bf16, tap-major columns (ky*3+kx)*C + c, zero-padded to
+ * ldw = round_up(9*C, 64); out [F*H*W, ldo] (out_dtype bf16 or fp32); bias fp32 [Cout] or NULL; residual [F*H*W, ldr]
+ * (res_dtype) or NULL; relu != 0 applies max(., 0) last.  out_dtype CFSAR_F16 selects the fp16 form: `in` and W are IEEE
+ * half too (the tower's fp16 numerics mode). */
 int cfsar_conv3x3_nhwc(const void* in, const void* W, void* out, const float* bias, const void* residual, int F, int H,
                        int Wd, int C, int Cout, int ldw, int ldo, int ldr, int out_dtype, int res_dtype, int relu,
                        cfsar_stream_t stream);
