@@ -6,7 +6,7 @@ AND cfg4 inside 1e-3 (<= 7e-4 wanted)?
 
 usage: python tools/numerics_lab.py CASE [scheme ...]        CASE e.g. cfg2_B16_5w1s_T8, cfg4_L14_5w1s_T16, t_5w1s_T8
 Scheme grammar: comma-separated key=value over
-  stream = f16 | f32 | hilo      residual stream storage (hilo: fp16 hi + fp16 lo, the consumer GEMMs read hi only)
+  stream = f16 | f32 | hilo | hi8 residual stream storage (hilo: fp16 hi + fp16 lo, the consumer GEMMs read hi only; hi8: lo as e5m2)
   wres   = f16 | x               out_proj / c_proj weights (x = exact, i.e. a hi + lo split pair)
   wfold  = f16 | x               LN-folded QKV / c_fc weights
   wqkv, wfc, wout, wpr           one GEMM's weights (override wfold / wres)
@@ -49,6 +49,9 @@ def make_tower(s):
         if stream == "hilo":
             hi = x.half().float()
             return hi + (x - hi).half().float()
+        if stream == "hi8":          # second word kept as e5m2 (the high byte of the fp16 low word, rounded): ~14 bits instead of ~22
+            hi = x.half().float()
+            return hi + (x - hi).half().to(torch.float8_e5m2).float()
         return x
 
     def feed(x):             # what a consumer GEMM reads of the stream (16-bit operand)
