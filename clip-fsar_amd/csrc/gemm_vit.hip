@@ -181,6 +181,15 @@ __device__ __forceinline__ void tile_of(int lin, int tiles_m, int tiles_n, int g
 // before the activation.  STATS (residual producer): per row, the sum and the sum of squares of the 64 STORED (rounded) values of
 // this wave are written to stats_out[row][slot = column / 64] -- the LayerNorm statistics of the next LN-folded GEMM come from
 // these partials (cfsar_ln_stats_finalize), so the residual stream is never re-read for them.
+// (float)pair.half + c in one fp32 VALU instruction (v_fma_mix_f32 reads the fp16 half of the dword directly; HALF = 0 low, 1 high)
+template <int HALF>
+__device__ __forceinline__ float half_plus(unsigned pair, float c) {
+    float r;
+    if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(c));
+    return r;
+}
+
 template <typename TO, int ACT, bool HAS_RES, int STORE, bool FULL, bool ROWSCALE = false, bool PRE = false, bool HB = false, int NMI = 4>
 __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGemmArgs& p, int mb, int nb, int lane, char* slab,
                                               const float (&rscale)[4], const u32x4 (&rv0)[4]) {
@@ -344,15 +353,26 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
         if (FULL || (rowok && colok)) store16<STORE>(out_addr(mi * 4 + it), x);
         if constexpr (COLSUM) {
             if (p.colsum != nullptr) {                       // kernel-uniform
-                const cs_h8 xv = __builtin_bit_cast(cs_h8, x);
-                const bool in0 = rr + (mi * 4 + it) * 8 < cs_bnd;
+                // cs1 collects ALL rows of the wave tile, cs0 those of its first frame (the second frame's sums are cs1 - cs0 at the end): per element
+                // a packed fp16 clamp, one v_fma_mix_f32 (half + magic), an integer subtract and two 24-bit multiply-adds by 0 / 1 row masks
+                // (5 VALU slots; the fp32 clamp + selects form took 9).  Same integers, same sums.
+                typedef _Float16 cs_h2 __attribute__((ext_vector_type(2)));
+                const int m_row = (FULL || rowok) ? 1 : 0;
+                const int m_in0 = (rr + (mi * 4 + it) * 8 < cs_bnd) ? m_row : 0;
                 constexpr float kMagic = 1.5f * 2048.0f;             // ulp of (v + 1.5 x 2^11) = 2^-12 for |v| < 2^10: its low mantissa bits ARE v in fixed point
+                const cs_h2 lim = {(_Float16)1000.0f, (_Float16)1000.0f};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = __builtin_amdgcn_fmed3f((float)xv[j], -1000.0f, 1000.0f);
-                    const int q = rowok ? __builtin_bit_cast(int, v + kMagic) - __builtin_bit_cast(int, kMagic) : 0;
-                    cs0[j] += in0 ? q : 0;
-                    cs1[j] += in0 ? 0 : q;
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned xw = x[k];                             // (a scalar copy first: __builtin_bit_cast straight from the vector ELEMENT x[k] reads element 0 for every k -- hipcc 7.2)
+                    cs_h2 hv = __builtin_bit_cast(cs_h2, xw);
+                    hv = __builtin_elementwise_min(__builtin_elementwise_max(hv, -lim), lim);
+                    const unsigned cw = __builtin_bit_cast(unsigned, hv);
+                    const int q0 = __builtin_bit_cast(int, half_plus<0>(cw, kMagic)) - __builtin_bit_cast(int, kMagic);
+                    const int q1 = __builtin_bit_cast(int, half_plus<1>(cw, kMagic)) - __builtin_bit_cast(int, kMagic);
+                    cs1[2 * k] += __mul24(q0, m_row);
+                    cs1[2 * k + 1] += __mul24(q1, m_row);
+                    cs0[2 * k] += __mul24(q0, m_in0);
+                    cs0[2 * k + 1] += __mul24(q1, m_in0);
                 }
             }
         }
@@ -410,6 +430,7 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
             const int partner = (lane ^ 32) << 2;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                cs1[j] -= cs0[j];                                    // all rows - first frame's rows = second frame's rows
                 cs0[j] += __builtin_amdgcn_update_dpp(0, cs0[j], 0x128, 0xF, 0xF, false);
                 cs1[j] += __builtin_amdgcn_update_dpp(0, cs1[j], 0x128, 0xF, 0xF, false);
                 cs0[j] += __builtin_amdgcn_ds_swizzle(cs0[j], 0x401F);
@@ -437,6 +458,24 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
 // ds_read_b128, 2 x (16 B hi [+ 16 B lo] in, 16 B [+ 16 B] out) per lane; 4 lanes own the 64 contiguous bytes of a row's half.
 // 16-byte slot s of row r sits at physical slot s ^ sw(r), sw(r) = ((r >> 1) & 7) ^ ((r & 1) << 2): distinct over 8 consecutive rows (the
 // 8-lane groups of ds_write_b128) and over the row sets of ds_read_b128's 16-lane groups (MI355X_MICROARCH.md, LDS table).
+// hi + lo and c - h on fp16 HALVES of packed dwords (HALF = 0: the low, 1: the high half) in ONE fp32 VALU instruction each: v_fma_mix_f32 reads
+// the halves directly (op_sel picks them), so the packed stream words need no conversion instructions.  Pure register arithmetic: nothing for
+// the compiler to mis-schedule (no memory operands; cf. profiles/r04_fault_audit.md on the asm loads).
+template <int HALF>
+__device__ __forceinline__ float mix_sum(unsigned a, unsigned b) {          // (float)a.half + (float)b.half: exact in fp32 for hi + remainder
+    float r;
+    if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int HALF>
+__device__ __forceinline__ float mix_sub(unsigned pair, float c) {
+    float r;
+    if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(c));
+    return r;
+}
+
 template <int STORE, bool FULL, int NMI>
 __device__ __forceinline__ void epilogue_rows_wide(f32x16 (&acc)[NMI][2], const VitGemmArgs& p, int mb, int nb, int lane, char* slab) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -484,6 +523,7 @@ __device__ __forceinline__ void epilogue_rows_wide(f32x16 (&acc)[NMI][2], const 
         for (int it = 0; it < 2; ++it) {
             const f4 a = *reinterpret_cast<const f4*>(rd + it * 2048 + (((2 * Q) ^ rsw) << 4));
             const f4 b = *reinterpret_cast<const f4*>(rd + it * 2048 + (((2 * Q + 1) ^ rsw) << 4));
+#ifdef CFSAR_WIDE_PLAIN_C                                  // the plain C form (A/B: `python clip-fsar_amd/build.py --variant plainc -DCFSAR_WIDE_PLAIN_C`)
             const h8 xh = __builtin_bit_cast(h8, rh[it]), xl = __builtin_bit_cast(h8, rl[it]);
             h8 oh, ol;
 #pragma unroll
@@ -494,6 +534,24 @@ __device__ __forceinline__ void epilogue_rows_wide(f32x16 (&acc)[NMI][2], const 
                 oh[j] = h;
                 ol[j] = (_Float16)(sum - (float)h);
             }
+#else
+            // Per pair of elements: the stream's words enter the fp32 sum straight from their packed halves (v_fma_mix_f32: no fp16 -> fp32
+            // conversion instructions), hi = one packed conversion, remainder = sum - hi again through v_fma_mix_f32 on the packed hi:
+            // 4 VALU instructions per element where the plain C form compiled to 8, bit-identical results (the epilogue is VALU-bound: profiles/r04_gemm_plateau.md)
+            u32x4 ohw, olw;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d0 = k < 2 ? a[2 * k] : b[2 * k - 4], d1 = k < 2 ? a[2 * k + 1] : b[2 * k - 3];
+                const float s0 = d0 + mix_sum<0>(rh[it][k], rl[it][k]);                  // hi + lo is exact in fp32
+                const float s1 = d1 + mix_sum<1>(rh[it][k], rl[it][k]);
+                const h2 hp = {(_Float16)s0, (_Float16)s1};
+                const unsigned hb = __builtin_bit_cast(unsigned, hp);
+                const h2 lp = {(_Float16)mix_sub<0>(hb, s0), (_Float16)mix_sub<1>(hb, s1)};
+                ohw[k] = hb;
+                olw[k] = __builtin_bit_cast(unsigned, lp);
+            }
+            const h8 oh = __builtin_bit_cast(h8, ohw), ol = __builtin_bit_cast(h8, olw);
+#endif
             const int step = mi * 2 + it;
             const bool rowok = FULL || mb + rr + step * 16 < p.M;
             if (p.stats_out) {                               // wave-uniform: statistics of the STORED hi words (what the consumer reads)
