@@ -126,6 +126,11 @@ def test_hot_kernels_use_no_scratch():
         "gemm_kernel_p12IDF16_Li0ELb1E": 128,              # fp16 residual stream (out_proj / c_proj of the bf16 mode)
         "gemm_kernel_p10IDF16bLi0ELb0ELb0ELb0E": 0, "gemm_kernel_p10IfLi0ELb1ELb0ELb0E": 0,
         "gemm_kernel_p3IDF16bDF16bLi0ELb0ELb0ELb1ELb0E": 0, "gemm_kernel_p3IDF16bDF16bLi0ELb0ELb0ELb1ELb1E": 0,   # RN50 implicit convs
+        # the RN50 tower's fp16 mode (round 4): the same kernels on IEEE-half operands keep the bf16 instances' budgets
+        "gemm_kernel_p3IDF16_DF16_Li0ELb0ELb0ELb1ELb0E": 0, "gemm_kernel_p3IDF16_DF16_Li0ELb0ELb0ELb1ELb1E": 0,
+        "gemm_kernel_p3IDF16_DF16_Li0ELb0ELb0ELb0ELb0E": 0, "gemm_kernel_p3IDF16_DF16_Li0ELb1ELb0ELb0ELb0E": 0,
+        "gemm_kernel_p12IDF16_Li0ELb0ELb1EDF16_E": 96, "gemm_kernel_p12IDF16_Li0ELb1ELb1EDF16_E": 128, "gemm_kernel_p12IfLi0ELb0ELb1EDF16_E": 128,
+        "gemm_kernel_p10IDF16_Li0ELb0ELb0ELb1EDF16_E": 16, "avgpool2_x8_kernelIDF16_E": 0, "stem_conv1_kernelIDF16_": 0,
         "stem_conv1_kernel": 0,
         "conv3x3_direct_kernelILi32ELi32E": 0, "conv3x3_direct_kernelILi32ELi64E": 0, "conv3x3_direct_kernelILi64ELi64E": 0,   # weights in registers
         "cos_otam_kernel": 0,                              # OTAM DP rows in registers (T = 8 / 16) or LDS (run-time T)
