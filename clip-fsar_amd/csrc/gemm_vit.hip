@@ -203,10 +203,18 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
     // not depend on how its rows fall into tiles, wave tiles or lanes -- an episode's result stays bit-identical whatever batch it is served
     // in (fp16 / fp32 partial sums regroup with the frame's row offset, and ONE flipped bit anywhere re-draws the whole tower's rounding noise).
     typedef _Float16 cs_h8 __attribute__((ext_vector_type(8)));
-    int cs0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int cs_bnd = 0;
+    // cs1: running sum over ALL row steps so far (raw bit patterns of value + magic: the constant's share is taken out once, at the end; all
+    // arithmetic mod 2^32); cs0: its snapshot at the lane's first row of the tile's SECOND frame.  A lane's rows are rr + 8 j, j = 0 .. 4 NMI - 1,
+    // so the snapshot step jb is one of two consecutive values over the wave (cs_jb0, cs_jb0 + 1): only those steps pay for it.
+    unsigned cs0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int cs_bnd = 0, cs_jb = 0, cs_jb0 = 0;
     if constexpr (COLSUM) {
-        if (p.colsum != nullptr) cs_bnd = (mb / p.corr_tokens + 1) * p.corr_tokens - mb;      // rows of this wave tile in its first frame
+        if (p.colsum != nullptr) {
+            cs_bnd = (mb / p.corr_tokens + 1) * p.corr_tokens - mb;      // rows of this wave tile in its first frame
+            const int jb = (cs_bnd - rr + 7) >> 3;                        // steps of this lane inside the first frame
+            cs_jb = jb < 4 * NMI ? jb : 4 * NMI;
+            cs_jb0 = __builtin_amdgcn_readfirstlane(cs_bnd >> 3);         // the smallest jb of the wave (rr = 7)
+        }
     }
     const bool colok = FULL || nb + 64 <= p.N;              // whole-wave predicate (N % 64 == 0)
     const int ncl = colok ? nb : p.N - 64;                  // clamped column base: loads stay in bounds
@@ -353,12 +361,14 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
         if (FULL || (rowok && colok)) store16<STORE>(out_addr(mi * 4 + it), x);
         if constexpr (COLSUM) {
             if (p.colsum != nullptr) {                       // kernel-uniform
-                // cs1 collects ALL rows of the wave tile, cs0 those of its first frame (the second frame's sums are cs1 - cs0 at the end): per element
-                // a packed fp16 clamp, one v_fma_mix_f32 (half + magic), an integer subtract and two 24-bit multiply-adds by 0 / 1 row masks
-                // (5 VALU slots; the fp32 clamp + selects form took 9).  Same integers, same sums.
+                // per element: a packed fp16 clamp, one v_fma_mix_f32 (half + magic) and ONE integer add of the raw bits (2.5 VALU slots; the
+                // fp32 clamp + selects form took 9, the masked two-accumulator form 5: the epilogue is instruction bound, tools/r04_runs/s23.sh)
                 typedef _Float16 cs_h2 __attribute__((ext_vector_type(2)));
-                const int m_row = (FULL || rowok) ? 1 : 0;
-                const int m_in0 = (rr + (mi * 4 + it) * 8 < cs_bnd) ? m_row : 0;
+                const int j_ = mi * 4 + it;
+                if (j_ == cs_jb0 || j_ == cs_jb0 + 1) {               // wave-uniform: a lane of this wave may enter the second frame at this step
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cs0[e] = (j_ == cs_jb) ? cs1[e] : cs0[e];
+                }
                 constexpr float kMagic = 1.5f * 2048.0f;             // ulp of (v + 1.5 x 2^11) = 2^-12 for |v| < 2^10: its low mantissa bits ARE v in fixed point
                 const cs_h2 lim = {(_Float16)1000.0f, (_Float16)1000.0f};
 #pragma unroll
@@ -367,12 +377,9 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
                     cs_h2 hv = __builtin_bit_cast(cs_h2, xw);
                     hv = __builtin_elementwise_min(__builtin_elementwise_max(hv, -lim), lim);
                     const unsigned cw = __builtin_bit_cast(unsigned, hv);
-                    const int q0 = __builtin_bit_cast(int, half_plus<0>(cw, kMagic)) - __builtin_bit_cast(int, kMagic);
-                    const int q1 = __builtin_bit_cast(int, half_plus<1>(cw, kMagic)) - __builtin_bit_cast(int, kMagic);
-                    cs1[2 * k] += __mul24(q0, m_row);
-                    cs1[2 * k + 1] += __mul24(q1, m_row);
-                    cs0[2 * k] += __mul24(q0, m_in0);
-                    cs0[2 * k + 1] += __mul24(q1, m_in0);
+                    const unsigned b0 = __builtin_bit_cast(unsigned, half_plus<0>(cw, kMagic)), b1 = __builtin_bit_cast(unsigned, half_plus<1>(cw, kMagic));
+                    cs1[2 * k] += (FULL || rowok) ? b0 : __builtin_bit_cast(unsigned, kMagic);          // a row past M counts as 0
+                    cs1[2 * k + 1] += (FULL || rowok) ? b1 : __builtin_bit_cast(unsigned, kMagic);
                 }
             }
         }
@@ -428,22 +435,27 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
         if (p.colsum != nullptr) {
             // sum over the 8 row groups rr (lanes differing in bits 3, 4, 5): row_ror:8, swizzle xor 16, bpermute xor 32 (integer adds: any order)
             const int partner = (lane ^ 32) << 2;
+            constexpr unsigned kbits = 0x45400000u;                  // bits of 1.5 x 2^11 (kMagic above)
+            static_assert(__builtin_bit_cast(unsigned, 1.5f * 2048.0f) == kbits, "magic constant");
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                cs1[j] -= cs0[j];                                    // all rows - first frame's rows = second frame's rows
-                cs0[j] += __builtin_amdgcn_update_dpp(0, cs0[j], 0x128, 0xF, 0xF, false);
-                cs1[j] += __builtin_amdgcn_update_dpp(0, cs1[j], 0x128, 0xF, 0xF, false);
-                cs0[j] += __builtin_amdgcn_ds_swizzle(cs0[j], 0x401F);
-                cs1[j] += __builtin_amdgcn_ds_swizzle(cs1[j], 0x401F);
-                cs0[j] += __builtin_amdgcn_ds_bpermute(partner, cs0[j]);
-                cs1[j] += __builtin_amdgcn_ds_bpermute(partner, cs1[j]);
+                int a0 = (int)((cs_jb >= 4 * NMI ? cs1[j] : cs0[j]) - (unsigned)cs_jb * kbits);     // the first frame's rows (all of them if the lane never left it)
+                int a1 = (int)(cs1[j] - (unsigned)(4 * NMI) * kbits) - a0;                         // all rows - first frame's rows = second frame's rows
+                a0 += __builtin_amdgcn_update_dpp(0, a0, 0x128, 0xF, 0xF, false);
+                a1 += __builtin_amdgcn_update_dpp(0, a1, 0x128, 0xF, 0xF, false);
+                a0 += __builtin_amdgcn_ds_swizzle(a0, 0x401F);
+                a1 += __builtin_amdgcn_ds_swizzle(a1, 0x401F);
+                a0 += __builtin_amdgcn_ds_bpermute(partner, a0);
+                a1 += __builtin_amdgcn_ds_bpermute(partner, a1);
+                cs0[j] = (unsigned)a0;
+                cs1[j] = (unsigned)a1;
             }
             if (rr == 0 && colok && mb < p.M) {
                 int* dst = reinterpret_cast<int*>(p.colsum) + ((size_t)(mb / (32 * NMI)) * 2) * p.N + ncl + 8 * Q;
-                *reinterpret_cast<u32x4*>(dst) = u32x4{(unsigned)cs0[0], (unsigned)cs0[1], (unsigned)cs0[2], (unsigned)cs0[3]};
-                *reinterpret_cast<u32x4*>(dst + 4) = u32x4{(unsigned)cs0[4], (unsigned)cs0[5], (unsigned)cs0[6], (unsigned)cs0[7]};
-                *reinterpret_cast<u32x4*>(dst + p.N) = u32x4{(unsigned)cs1[0], (unsigned)cs1[1], (unsigned)cs1[2], (unsigned)cs1[3]};
-                *reinterpret_cast<u32x4*>(dst + p.N + 4) = u32x4{(unsigned)cs1[4], (unsigned)cs1[5], (unsigned)cs1[6], (unsigned)cs1[7]};
+                *reinterpret_cast<u32x4*>(dst) = u32x4{cs0[0], cs0[1], cs0[2], cs0[3]};
+                *reinterpret_cast<u32x4*>(dst + 4) = u32x4{cs0[4], cs0[5], cs0[6], cs0[7]};
+                *reinterpret_cast<u32x4*>(dst + p.N) = u32x4{cs1[0], cs1[1], cs1[2], cs1[3]};
+                *reinterpret_cast<u32x4*>(dst + p.N + 4) = u32x4{cs1[4], cs1[5], cs1[6], cs1[7]};
             }
         }
     }
