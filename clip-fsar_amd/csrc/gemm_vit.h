@@ -42,6 +42,7 @@ struct VitGemmArgs {          // kernel argument block
     // (corr_tokens >= rows of a wave's tile: a tile spans at most two frames).  NULL = off.
     const float* corr;
     int corr_tokens;
+    int corr_raw;             // LN-folded instances: 1 = corr is in RAW-stream units (added before the division by the row's std), 0 = normalised units
     // Per-frame column sums of the OUTPUT (the fp16 LN-folded QuickGELU instance = c_fc, whose output is c_proj's operand: its per-frame
     // token means feed c_proj's correction without another pass over the 1.5 GB hidden).  colsum [ceil(M / rows of a wave tile), 2, N] fp16:
     // for the wave tile starting at row r0, slot 0 = sum over its rows in frame f0 = r0 / corr_tokens, slot 1 = those in f0 + 1.  NULL = off.
@@ -77,6 +78,7 @@ struct VitGemmCall {          // host-side request
     void* res_lo = nullptr;
     const float* corr = nullptr;    // see VitGemmArgs
     int corr_tokens = 0;
+    int corr_raw = 0;
     void* colsum = nullptr;
     int* out_miw = nullptr;         // receives the tile form the launcher picked (4: 128-row wave tiles, 3: 96-row)
 };

@@ -809,7 +809,8 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
                 if constexpr (CORR) {
                     // the accumulator is divided by std in the epilogue: the correction (normalised units) enters multiplied by it
                     const bool in0 = mi * 32 + lr < corr_bnd;
-                    sdh = (_Float16)((p.corr != nullptr && ((in0 ? corr_par : corr_par ^ 1) == hi)) ? __builtin_amdgcn_rcpf(tl[6 + mi]) : 0.f);
+                    // (corr_raw: the correction is already in raw-stream units -- xbar W_lo^T, the row's 1 / std applies to it like to everything else)
+                    sdh = (_Float16)((p.corr != nullptr && ((in0 ? corr_par : corr_par ^ 1) == hi)) ? (p.corr_raw ? 1.0f : __builtin_amdgcn_rcpf(tl[6 + mi])) : 0.f);
                 }
                 mx[mi] = f16x8{h, l, h, sdh, 0, 0, 0, 0};
                 rscale[mi] = tl[6 + mi];
@@ -1269,6 +1270,7 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     a.res_lo = c.wide ? c.res_lo : nullptr;
     a.corr = c.corr;
     a.corr_tokens = c.corr_tokens;
+    a.corr_raw = c.corr_raw;
     a.colsum = c.colsum;
     if (c.colsum && !(lnfold && c.act == CFSAR_ACT_QUICKGELU && c.out_dtype == CFSAR_F16 && c.corr_tokens >= 128 && c.hb_tokens == 0))
         return cfsar_fail("cfsar_gemm_lnfold_hp: per-frame output means exist for the fp16 QuickGELU form with >= 128 tokens per frame");
@@ -1388,6 +1390,8 @@ static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const floa
     if (wsplit) K = 2 * K;                            // split weights [N, 2 ka] = [hi | lo]: see VitGemmArgs::nka
     VitGemmCall c;
     c.ka = ka_;
+    c.corr_raw = corr_tokens < 0;                     // cfsar_gemm_lnfold_hp: corr_tokens < 0 selects the raw-stream form
+    if (corr_tokens < 0) corr_tokens = -corr_tokens;
     c.corr = corr; c.corr_tokens = corr_tokens;
     int miw_used = 4;
     c.colsum = colmean_out ? colsum_ws : nullptr; c.out_miw = &miw_used;
@@ -1474,7 +1478,8 @@ extern "C" int cfsar_gemm_lnfold_hp(const void* x, const void* Wg, void* out, co
                                     int ldo, int act, int out_dtype, int wsplit, const float* corr, int corr_tokens, void* colmean_out,
                                     void* colsum_ws, cfsar_stream_t stream) {
     CFSAR_REQUIRE(out_dtype == CFSAR_F16, "cfsar_gemm_lnfold_hp: fp16 output only (the fp16 numerics mode)");
-    CFSAR_REQUIRE((corr == nullptr && colmean_out == nullptr) || corr_tokens >= 128, "cfsar_gemm_lnfold_hp: the per-frame forms need >= 128 tokens per frame");
+    CFSAR_REQUIRE((corr == nullptr && colmean_out == nullptr) || corr_tokens >= 128 || corr_tokens <= -128, "cfsar_gemm_lnfold_hp: the per-frame forms need >= 128 tokens per frame");
+    CFSAR_REQUIRE(corr_tokens >= 0 || corr != nullptr, "cfsar_gemm_lnfold_hp: corr_tokens < 0 (raw-stream form of the correction) needs corr");
     CFSAR_REQUIRE(colmean_out == nullptr || (colsum_ws != nullptr && act == CFSAR_ACT_QUICKGELU), "cfsar_gemm_lnfold_hp: output means need the workspace and act = QUICKGELU");
     if (partial != nullptr) {
         CFSAR_REQUIRE(slots > 0 && slots * 64 == K, "cfsar_gemm_lnfold_hp: K=%d is not 64 x slots=%d", K, slots);

@@ -178,6 +178,7 @@ class HipViT:
                             blk["cs_" + tag] = Ws.double().sum(1).float().contiguous()
                     blk["wg_" + tag] = Wg
                     blk["c_" + tag] = Wg.double().sum(1).float().contiguous()          # of the ROUNDED folded weights (hi + lo when split)
+                    blk["cx_" + tag] = (W * gamma[None, :]).double().sum(1).float().contiguous()   # of the exact ones (raw-stream correction)
                     blk["d_" + tag] = (W.double() @ beta.double() + g(b + bname).double()).float().contiguous()
             # the kernel feeds c, d, mean and std to the matrix pipe as fp16 hi + lo pairs and the folded weights as fp16: a checkpoint
             # whose folded quantities leave the fp16 range cannot use the folded block (CLIP's are O(1) ... O(10))
@@ -211,6 +212,16 @@ class HipViT:
         self.fuse_stats = bool(self.fold) and hip.lnfold_partials_ok(self.D, self.D // 64) and os.environ.get("CFSAR_FUSE_STATS", "1") != "0"
         self.fused_umeans = os.environ.get("CFSAR_FUSED_UMEANS", "1") != "0"      # c_fc emits the hidden's per-frame means (A/B switch)
         self.fused_omeans = os.environ.get("CFSAR_FUSED_OMEANS", "1") != "0"      # the attention kernel emits its output's per-frame means
+        # The LN-folded GEMMs' correction in its RAW-STREAM form: corr = xbar W_lo^T with xbar the per-frame token mean of the raw stream (the row
+        # mean's share rides in cvec = the exact column sums of W gamma).  xbar needs no pass over x: the stream's update x += A W^T + b is linear
+        # in the frame's token mean, so xbar += mean_t(A) W^T + b from the operand means the residual GEMMs' own corrections already have.
+        self.rawmeans = (os.environ.get("CFSAR_FP16_RAWMEANS", "1") != "0" and self.fused_umeans and self.fused_omeans
+                         and all(k in self.mcorr for k in ("qkv", "out", "fc", "pr")))
+        if self.rawmeans:
+            for i, blk in enumerate(self.blocks):
+                bb = "transformer.resblocks.%d." % i
+                blk["wb_out"] = g(bb + "attn.out_proj.weight").to(torch.bfloat16).contiguous()
+                blk["wb_pr"] = g(bb + "mlp.c_proj.weight").to(torch.bfloat16).contiguous()
         if self.mcorr & {"qkv", "fc"}:
             self.fuse_stats = False          # the token means of LayerNorm(x) need the finalized statistics in front of the GEMM
         # band-chunked layer schedule (developer switch; measured in profiles/r04_chunked_schedule.md): CFSAR_CHUNK_FRAMES=k,
@@ -243,6 +254,7 @@ class HipViT:
                 ws["colsum"] = torch.empty((M // 96 + 2) * 2 * 4 * D, device=dev, dtype=torch.int32)   # c_fc's per-wave-tile column sums (fixed point)
                 ws["mU"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.bfloat16)         # per-frame token means of the MLP hidden
                 ws["mX"] = torch.empty(F_, D, device=dev, dtype=torch.bfloat16)              # ... of the attention output
+                ws["xbar"] = torch.empty(F_, D, device=dev, dtype=torch.bfloat16)            # ... of the residual stream (raw), kept current by mean_update_gemm
                 ws["mA"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.bfloat16)         # per-frame token means of a GEMM operand
                 ws["corr"] = torch.empty(F_ * 4 * D, device=dev, dtype=torch.float32)        # ... x W_lo^T
             if self.two_word:
@@ -312,6 +324,10 @@ class HipViT:
             split = self.split
 
             mcorr = self.mcorr
+            raw = self.rawmeans and bool(mcorr)
+            xbar = ws["xbar"][:F_] if raw else None
+            if raw:
+                hip.frame_col_means(x, xbar, F_, N)                                   # the one pass: the stream as it enters the blocks
 
             def mc(blk, key, A, rs=None, wrows=None, means=None):
                 """per-frame low-word correction of GEMM `key` for the full-size launch: token means of the operand x W_lo^T -> [F, N]
@@ -320,7 +336,9 @@ class HipViT:
                     return None
                 wlo = blk["wlo_" + key] if wrows is None else blk["wlo_" + key][wrows]
                 Kd, Nn = A.shape[1], wlo.shape[0]
-                if means is not None:
+                if raw and key in ("qkv", "fc"):
+                    mA = xbar                                                         # raw-stream form: no pass over x
+                elif means is not None:
                     mA = means
                 else:
                     mA = ws["mA"][:F_ * Kd].view(F_, Kd)
@@ -329,12 +347,13 @@ class HipViT:
                 hip.corr_gemm(mA, wlo, cr)
                 return cr
 
-            def fold(xx, wg, out, c, d, pt, rs, act=hip.ACT_NONE, rows=M, from_part=False, heads=False, sp=False, corr=None, umeans=None):
+            def fold(xx, wg, out, c, d, pt, rs, act=hip.ACT_NONE, rows=M, from_part=False, heads=False, sp=False, corr=None, umeans=None,
+                     corr_raw=False):
                 if sp or corr is not None or umeans is not None:                      # fp16 numerics mode: split weights [N, 2K] / correction
                     hip.gemm_lnfold_hp(xx, wg, out, c, d, rowstats=None if from_part else rs, partial=pt if from_part else None,
                                        slots=S if from_part else 0, rowstats_ws=rs, act=act, M=rows, wsplit=sp, corr=corr,
                                        corr_tokens=N if (corr is not None or umeans is not None) else 0, colmean_out=umeans,
-                                       colsum_ws=ws["colsum"] if umeans is not None else None)
+                                       colsum_ws=ws["colsum"] if umeans is not None else None, corr_raw=corr_raw and corr is not None)
                 elif from_part:
                     hip.gemm_lnfold_partials(xx, wg, out, c, d, pt, S, rs, act=act, M=rows, tokens=N if heads else 0, heads=self.H if heads else 0)
                 elif heads:
@@ -359,8 +378,8 @@ class HipViT:
                     xlc = ws["xlc"][:F_] if xlo is not None else None
                     # ... and of q only the class-token rows: K | V for all M rows (N = 2 D: two thirds of the QKV GEMM), q for F rows
                     kv = qkv.view(-1)[:M * 2 * D].view(M, 2 * D)
-                    fold(x, b["wg_qkv"][D:], kv, b["c_qkv"][D:], b["d_qkv"][D:], part, rstat, from_part=in_part, sp="qkv" in split,
-                         corr=mc(b, "qkv", x, rstat, wrows=slice(D, 3 * D)))
+                    fold(x, b["wg_qkv"][D:], kv, b["cx_qkv" if raw else "c_qkv"][D:], b["d_qkv"][D:], part, rstat, from_part=in_part, sp="qkv" in split,
+                         corr=mc(b, "qkv", x, rstat, wrows=slice(D, 3 * D)), corr_raw=raw)
                     class_rows(x, xc, D, es)                                          # class-token rows of the stream
                     if xlo is not None:
                         class_rows(xlo, xlc, D, 2)
@@ -428,8 +447,8 @@ class HipViT:
                         taps["block%d" % i] = x[:M].clone()
                     continue
                 else:
-                    fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, sp="qkv" in split,
-                         corr=mc(b, "qkv", x, rstat))
+                    fold(x, b["wg_qkv"], qkv, b["cx_qkv" if raw else "c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, sp="qkv" in split,
+                         corr=mc(b, "qkv", x, rstat), corr_raw=raw)
                     if "out" in mcorr and self.fused_omeans:                           # the attention kernel emits its output's per-frame means
                         mO = ws["mX"][:F_]
                         hip.vit_attention_means(qkv, o, mO, F_, N, D, self.H)
@@ -437,16 +456,20 @@ class HipViT:
                         mO = None
                         hip.vit_attention(qkv, o, F_, N, D, self.H)
                     resid(o, b, "out", x, xlo, part, M, corr=mc(b, "out", o, means=mO))   # x += out_proj(attn); stats of the new x
+                    if raw:
+                        hip.mean_update_gemm(mO, b["wb_out"], b["b_out"], xbar)           # ... and its per-frame mean follows
                 if not fuse:
                     hip.ln_stats_finalize(part, rstat, M, S, D)
                 # c_fc also emits the per-frame token means of the hidden it writes: c_proj's correction needs no pass of its own over u
                 um = ws["mU"][:F_ * 4 * D].view(F_, 4 * D) if ("pr" in mcorr and self.fused_umeans) else None
-                fold(x, b["wg_fc"], u, b["c_fc"], b["d_fc"], part, rstat, act=hip.ACT_QUICKGELU, from_part=fuse, sp="fc" in split,
-                     corr=mc(b, "fc", x, rstat), umeans=um)
+                fold(x, b["wg_fc"], u, b["cx_fc" if raw else "c_fc"], b["d_fc"], part, rstat, act=hip.ACT_QUICKGELU, from_part=fuse, sp="fc" in split,
+                     corr=mc(b, "fc", x, rstat), umeans=um, corr_raw=raw)
                 if self.head_blocked:
                     hip.gemm_residual_stats(u, b["w_pr"], x, b["b_pr"], part, M=M)
                 else:
                     resid(u, b, "pr", x, xlo, part, M, corr=mc(b, "pr", u, means=um))  # x += c_proj(gelu(c_fc))
+                    if raw:
+                        hip.mean_update_gemm(um, b["wb_pr"], b["b_pr"], xbar)
                 if fuse:
                     in_part = True
                 else:

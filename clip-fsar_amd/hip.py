@@ -216,6 +216,12 @@ def gemm(A, W, out, bias=None, residual=None, act=ACT_NONE, M=None, N=None, K=No
 _gemm_unwrapped = gemm
 
 
+def mean_update_gemm(meanA, w, bias, xbar):
+    """xbar [frames, N] bf16 += meanA [frames, K] bf16 @ w [N, K]^T bf16 + bias: the per-frame mean of the residual stream follows the stream's
+    update x += A W^T + b (linear in the frame's token mean).  Unwrapped like corr_gemm."""
+    _gemm_unwrapped(meanA, w, xbar, bias=bias, residual=xbar)
+
+
 def corr_gemm(meanA, w_lo, out):
     """out [frames, N] fp32 = meanA [frames, K] bf16 @ w_lo [N, K]^T bf16: the per-frame low-word correction's small GEMM (cfsar_gemm).  A name
     of its own so that bench.py's per-launch timer, which wraps `gemm`, does not count it among the path's algorithmic GEMM launches."""
@@ -266,9 +272,10 @@ def gemm_residual_stats(A, W, x, bias, stats_partial=None, M=None):
 
 
 def gemm_lnfold_hp(x, Wg, out, cvec, dvec, rowstats=None, partial=None, slots=0, rowstats_ws=None, act=ACT_NONE, M=None, eps=1e-5,
-                   wsplit=False, corr=None, corr_tokens=0, colmean_out=None, colsum_ws=None):
+                   wsplit=False, corr=None, corr_tokens=0, colmean_out=None, colsum_ws=None, corr_raw=False):
     """fp16 numerics mode's LN-folded GEMM (cfsar_gemm_lnfold_hp): split weights Wg [N, 2K] = [hi | lo] (wsplit) and / or the per-frame
-    low-word correction corr [frames, N] fp32; colmean_out [frames, N] bf16 (+ colsum_ws): per-frame token means of the output."""
+    low-word correction corr [frames, N] fp32 (corr_raw: in raw-stream units, i.e. xbar W_lo^T with cvec = the EXACT column sums of W gamma; passed
+    as a negative corr_tokens); colmean_out [frames, N] bf16 (+ colsum_ws): per-frame token means of the output."""
     M = x.shape[0] if M is None else M
     K = x.shape[1]
     if Wg.shape[1] != (2 * K if wsplit else K) or out.dtype != torch.float16:
@@ -280,7 +287,7 @@ def gemm_lnfold_hp(x, Wg, out, cvec, dvec, rowstats=None, partial=None, slots=0,
                                       _opt(rowstats, torch.float32, "rowstats"), _opt(partial, torch.float32, "partial"), slots, eps,
                                       _opt(rowstats_ws, torch.float32, "rowstats_ws"), M, Wg.shape[0], K, x.shape[1], Wg.shape[1],
                                       out.shape[-1], act, _code(out.dtype), int(bool(wsplit)), _opt(corr, torch.float32, "corr"),
-                                      int(corr_tokens), _opt(colmean_out, torch.bfloat16, "colmean_out"),
+                                      -int(corr_tokens) if corr_raw else int(corr_tokens), _opt(colmean_out, torch.bfloat16, "colmean_out"),
                                       _opt(colsum_ws, torch.int32, "colsum_ws"), _stream()), "cfsar_gemm_lnfold_hp")
 
 

@@ -270,7 +270,10 @@ int cfsar_gemm_residual_stats_heads(const void* A, const void* W, void* x, const
  *
  * cfsar_gemm_lnfold_hp: cfsar_gemm_lnfold with fp16 output; wsplit = 1: Wg [N, ldw >= 2 K] split, cvec = sum_k (hi + lo).  Statistics
  * either finalized (rowstats [M, 4], partial = NULL) or the producer's partials (partial [M, slots, 2], rowstats = NULL, rowstats_ws
- * [M, 4] as in cfsar_gemm_lnfold_partials).  corr [ceil(M / corr_tokens), N] fp32 or NULL.  colmean_out (act = QUICKGELU only; NULL = off):
+ * [M, 4] as in cfsar_gemm_lnfold_partials).  corr [ceil(M / |corr_tokens|), N] fp32 or NULL; corr_tokens < 0 selects the RAW-STREAM form of the
+ * correction: corr = (token mean of the frame's raw x rows) x W_lo^T, added before the division by the row's std, with cvec = the exact column
+ * sums of W gamma (the row mean's share of the low word) -- the caller then needs no pass over x: the stream's per-frame mean follows its
+ * updates x += A W^T + b linearly (engine.py: mean_update_gemm).  colmean_out (act = QUICKGELU only; NULL = off):
  * receives the per-frame token means of the OUTPUT, [ceil(M / corr_tokens), N] bf16 -- the c_fc GEMM hands the next GEMM (c_proj) the
  * means its own correction needs without another pass over the hidden; colsum_ws: workspace of (M / 96 + 2) x 2 x N int32 (the sums are taken in fixed point: an episode's
  * result does not depend on the batch it is served in).

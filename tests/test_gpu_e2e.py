@@ -391,3 +391,17 @@ def test_fp16_mode_b16_equals_b1():
         l1, c1 = run_engine(m, a, sd, tt, te, [eps[i]], "fp16")
         assert maxdiff(l16[i], l1[0]) <= 4e-6, (i, maxdiff(l16[i], l1[0]))
         assert maxdiff(c16[i], c1[0]) <= 4e-6, i
+
+def test_fp16_raw_stream_correction_switch(monkeypatch):
+    """The fp16 mode's LN-folded GEMMs take their per-frame correction in the raw-stream form by default (no pass over x: the stream's per-frame
+    mean follows its updates through two [frames, K] x [K, D] GEMMs per block); CFSAR_FP16_RAWMEANS=0 restores the normalised-mean form with its
+    two frame_col_means passes per block.  Both inside the north-star tolerance on the cfg2 golden; 64 fresh episodes per configuration give the
+    same rms for both (profiles/r04_parity_table.md)."""
+    g = load_golden("cfg2_B16_5w1s_T8")
+    m = g["meta"]
+    a, sd, tt, te, ep = case_inputs(m)
+    l_raw, _ = run_engine(m, a, sd, tt, te, [ep], "fp16")
+    monkeypatch.setenv("CFSAR_FP16_RAWMEANS", "0")
+    l_norm, _ = run_engine(m, a, sd, tt, te, [ep], "fp16")
+    assert maxdiff(l_raw[0], g["logits"]) < NORTH_STAR_TOLERANCE and maxdiff(l_norm[0], g["logits"]) < NORTH_STAR_TOLERANCE
+    assert not torch.equal(l_raw, l_norm)                       # the switch is live

@@ -1094,8 +1094,10 @@ def test_gemm_residual_wide_per_frame_correction(hip, frames, tokens, N, K, two_
 
 @pytest.mark.parametrize("frames,tokens,N,K,act", [(6, 197, 2304, 768, "none"), (40, 197, 3072, 768, "gelu"), (3, 257, 3072, 1024, "gelu"),
                                                    (80, 197, 2304, 768, "none"), (1, 197, 768, 768, "none")])
-def test_gemm_lnfold_hp_per_frame_correction(hip, frames, tokens, N, K, act):
-    """out = act(LayerNorm(x) Wg^T + d + corr[frame]): the correction enters in normalised units, BEFORE the activation."""
+@pytest.mark.parametrize("raw", [False, True])
+def test_gemm_lnfold_hp_per_frame_correction(hip, frames, tokens, N, K, act, raw):
+    """out = act(LayerNorm(x) Wg^T + d + corr[frame]): the correction enters in normalised units, BEFORE the activation.  raw (corr_tokens < 0 at
+    the C ABI): corr is in raw-stream units and shares the row's 1 / std with the GEMM: out = act(LayerNorm(x) Wg^T + d + corr[frame] / std_row)."""
     g = torch.Generator().manual_seed(61)
     M = frames * tokens
     x = (torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 2.0) + torch.randn(M, 1, generator=g)).to(torch.float16).cuda()
@@ -1107,11 +1109,11 @@ def test_gemm_lnfold_hp_per_frame_correction(hip, frames, tokens, N, K, act):
     hip.row_stats(x, rstat, M, K)
     a = hip.ACT_QUICKGELU if act == "gelu" else hip.ACT_NONE
     out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
-    hip.gemm_lnfold_hp(x, Wg, out, c, d, rowstats=rstat, act=a, corr=corr, corr_tokens=tokens)
+    hip.gemm_lnfold_hp(x, Wg, out, c, d, rowstats=rstat, act=a, corr=corr, corr_tokens=tokens, corr_raw=raw)
     xd = x.double()
     mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
     pre = ((xd - mean) / torch.sqrt(var + 1e-5)) @ Wg.double().t() + d.double()
-    ref = pre + corr.double().repeat_interleave(tokens, 0)
+    ref = pre + corr.double().repeat_interleave(tokens, 0) / (torch.sqrt(var + 1e-5) if raw else 1.0)
     ref0 = pre
     if act == "gelu":
         ref, ref0 = ref * torch.sigmoid(1.702 * ref), ref0 * torch.sigmoid(1.702 * ref0)
@@ -1120,7 +1122,7 @@ def test_gemm_lnfold_hp_per_frame_correction(hip, frames, tokens, N, K, act):
     e0 = float((out.double() - ref0).abs().max())
     # tolerance: fp16 output rounding + the fp16 factors of the correction (std x corr: 2^-11 each of a 1e-2-size term)
     assert e < 6e-4 * scale + 1e-4, (e, scale)
-    assert e0 > 5 * e, (e0, e)            # the uncorrected reference is clearly farther away: the correction is really applied
+    assert e0 > (3 if raw else 5) * e, (e0, e)            # the uncorrected reference is clearly farther away: the correction is really applied
 
 
 @pytest.mark.parametrize("frames,tokens,N,K", [(6, 197, 3072, 768), (80, 197, 3072, 768), (3, 257, 4096, 1024), (1, 197, 768, 768), (33, 130, 512, 256)])
