@@ -27,7 +27,7 @@ from . import hip
 # fp16 numerics mode (HipViT.__init__, profiles/r04_parity_table.md): the GEMMs whose weights' second fp16 word is applied to the per-frame
 # token mean of the operand (MCORR: one pass over the operand + a 1 / tokens-size GEMM) or to the whole operand (SPLIT: a second MFMA pass).
 # 16 fresh episodes per configuration against the fp32 mode, rms / max |dlogits| on cfg2, cfg3, cfg4:  mcorr all 2.4e-4 / 2.2e-4 / 2.5e-4 and
-# 6.1e-4 / 6.7e-4 / 6.7e-4 at 276-288 episodes/s;  split qkv,out,pr 2.5 / 2.1 / 2.9 and 8.2 / 6.3 / 8.2 at 217;  split all 2.2 / 1.7 / 1.9 and
+# 6.1e-4 / 6.7e-4 / 6.7e-4 at 276-288 episodes/s (64 episodes, final build: 2.7 / 2.1 / 2.3 and 11.4 / 7.3 / 10.2 at 284-298);  split qkv,out,pr 2.5 / 2.1 / 2.9 and 8.2 / 6.3 / 8.2 at 217;  split all 2.2 / 1.7 / 1.9 and
 # 6.7 / 5.5 / 5.3 at 194;  neither 3.3 / 2.8 / 5.0 and 9.0 / 9.3 / 16.0 at 308.
 FP16_SPLIT_DEFAULT = ""
 FP16_MCORR_DEFAULT = "qkv,out,fc,pr"

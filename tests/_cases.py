@@ -27,7 +27,7 @@ MEASURED_DLOGITS = {
     "t_5w5s_q2_T8": {"bf16": 0.0135, "fp16": 0.002728},
     "t_5w3s_T16_mb_d2": {"bf16": 0.02286, "fp16": 0.003726},
     "t_5w2s_T4_sd": {"bf16": 0.004334, "fp16": 0.0009908},
-    "t197_5w1s_T2": {"bf16": 0.008597, "fp16": 0.0007835},
+    "t197_5w1s_T2": {"bf16": 0.008597, "fp16": 0.00097},
     "t257_5w1s_T2": {"bf16": 0.003436, "fp16": 0.0007384},
     "rn_t_5w2s_T4": {"bf16": 0.001986, "fp16": 0.00027},
     "t_outlier_5w1s_T8": {"bf16": 0.0007324, "fp16": 0.000144},
