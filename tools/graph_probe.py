@@ -14,7 +14,7 @@ if os.environ.get("VIT_DBG"):
 a = synth.ARCHS["ViT-B/16"]
 sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict("ViT-B/16", seed=18, depth=1).items()}
 tt = torch.from_numpy(synth.text_features(64, a["embed"], "train", 18)); te = torch.from_numpy(synth.text_features(24, a["embed"], "test", 18))
-eng = ClipFsarEngine(a, sd, tt, te, precision="bf16", device="cuda")
+eng = ClipFsarEngine(a, sd, tt, te, precision=os.environ.get("PROBE_PRECISION", "bf16"), device="cuda")
 ep = {k: torch.from_numpy(v).cuda() for k, v in synth.make_episode(5, 1, 1, 8, 224, 24, 0, 18).items()}
 args = (ep["support_set"][None], ep["target_set"][None], ep["support_labels"][None], ep["real_support_labels"][None])
 kw = dict(way=5, T=8)
