@@ -85,5 +85,8 @@ struct VitGemmCall {          // host-side request
 
 // 0 = launched, > 0 = error (cfsar_last_error), -2 = outside this kernel's contract (caller falls back)
 int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s);
-// operand path the policy gives a launch with this K (0 register-staged, 1 LDS-DMA, 2 LDS-DMA issued one barrier earlier)
+// operand path the policy gives a launch with this K (0 register-staged, 1 LDS-DMA, 2 LDS-DMA issued one barrier earlier, 4 = the
+// two-workgroups-per-CU kernel of gemm_vit4.hip)
 int cfsar_vit_policy_opath(int K);
+// gemm_vit4.hip: the launch `a` (as cfsar_gemm_vit_try filled it) on 192 x 128 tiles, two 4-wave workgroups per CU; -2 = not covered
+int cfsar_gemm_vit4_launch(const VitGemmArgs& a, int mode, bool f16io, int store, hipStream_t s);
