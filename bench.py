@@ -104,6 +104,9 @@ class GemmTimer:
         ms = sum(s.elapsed_time(e) for s, e in self.events)
         return ms, self.flops, self.launches
 
+    def reset(self):
+        self.events, self.flops, self.launches = [], 0.0, 0
+
 
 def csrc_fingerprint():
     """sha256 (16 hex digits) over the GEMM sources: a PMC profile is only quoted for the kernels it was taken on."""
@@ -198,10 +201,13 @@ def cpu_baseline(sample_episodes: int = 5):
                       "median %.2f s/episode (min %.2f, max %.2f)" % (sample_episodes, best_t, ncpu, med, min(times), max(times))}
 
 
-def golden_parity(logits0, precision):
-    """Rank 0's first pooled episode (seed 18, episode id 0) is the `cfg2_B16_5w1s_T8` golden case generated from the
+GOLDEN_FILE = {"cfg2": "head_cfg2_B16_5w1s_T8.npz", "cfg3": "head_cfg3_B16_5w5s_T8_mb.npz", "cfg4": "head_cfg4_L14_5w1s_T16.npz"}
+
+
+def golden_parity(logits0, precision, config="cfg2"):
+    """Rank 0's first pooled episode (seed 18, episode id 0) is the configuration's golden case generated from the
     reference itself (oracle/make_golden.py): compare the logits this run produced, in the configuration it timed."""
-    path = os.path.join(ROOT, "tests", "golden", "head_cfg2_B16_5w1s_T8.npz")
+    path = os.path.join(ROOT, "tests", "golden", GOLDEN_FILE[config])
     try:
         import numpy as np
         z = np.load(path)
@@ -214,12 +220,78 @@ def golden_parity(logits0, precision):
     d = float((got - ref).abs().max())
     from clip_fsar_amd import LOGITS_TOLERANCE, NORTH_STAR_TOLERANCE
     tol = LOGITS_TOLERANCE[precision]
-    return {"checked": True, "against": "tests/golden/head_cfg2_B16_5w1s_T8.npz (reference fp32 logits)",
+    return {"checked": True, "against": "tests/golden/%s (reference fp32 logits)" % GOLDEN_FILE[config],
             "max_abs_dlogits": round(d, 6), "argmax_equal": bool(torch.equal(got.argmax(1), ref.argmax(1))),
             "north_star_tolerance": NORTH_STAR_TOLERANCE, "meets_north_star": bool(d < NORTH_STAR_TOLERANCE),
             "tolerance": tol, "within_tolerance": bool(d < tol),
             "tolerance_note": "this mode's own regression bound on the full-size configurations (2 x the measured deviation, "
                               "profiles/r04_parity_table.md); the north-star bound is 1e-3"}
+
+
+def executed_gflop_per_frame(arch, gflop, pruned):
+    """the last ViT block is computed for the class-token rows only (engine.py: prune_last; few_shot.py:683 reads nothing else of it):
+    (N - 1) (20 D^2 + 4 N D) FLOPs per frame fewer than the reference path's figure"""
+    if not (pruned and arch.startswith("ViT")):
+        return gflop
+    a_ = synth.ARCHS[arch]
+    n_, d_ = (a_["res"] // a_["patch"]) ** 2 + 1, a_["width"]
+    return gflop - (n_ - 1) * (20.0 * d_ * d_ + 4.0 * n_ * d_) / 1e9
+
+
+def timed_leg(cfgname, precision, B, steps, dev, timer, weights=None, batches=None, distinct=2):
+    """A short extra measurement inside the default run: `steps` timed steps of B episodes of configuration
+    `cfgname` in `precision` after two warm-up steps, with the GEMM launches' HIP events (-> roofline) and the configuration's golden
+    parity (its first episode is the golden case).  `batches`: resident steps to reuse (the headline's); else `distinct` episodes are
+    generated and tiled to B per step.  Returns the leg's object."""
+    from clip_fsar_amd import hip
+    from clip_fsar_amd.engine import ClipFsarEngine
+    c = CONFIGS[cfgname]
+    a = synth.ARCHS[c["arch"]]
+    fpe = (WAY * c["shot"] + WAY * QPC) * c["T"]
+    if weights is None:
+        weights = ({k: torch.from_numpy(v) for k, v in synth.head_state_dict(c["arch"], SEED).items()},
+                   synth.text_features(N_TRAIN, a["embed"], "train", SEED), synth.text_features(N_TEST, a["embed"], "test", SEED))
+    sd, tt, te = weights
+    eng = ClipFsarEngine(a, sd, tt, te, precision=precision, device=dev, max_frames=max(1280, B * fpe))
+    keys = (("sup", "support_set"), ("tgt", "target_set"), ("sl", "support_labels"), ("rl", "real_support_labels"))
+    if batches is None:
+        eps = [synth.make_episode(WAY, c["shot"], QPC, c["T"], a["res"], N_TEST, i, SEED) for i in range(distinct)]
+        dev_eps = [{k: torch.from_numpy(e[src]).to(dev) for k, src in keys} for e in eps]
+        batches = [{k: torch.stack([dev_eps[i % distinct][k] for i in range(B)]) for k, _ in keys}]
+        del dev_eps
+    lg0 = None
+    for i in range(2 + steps):
+        if i == 2:
+            torch.cuda.synchronize()
+            if timer is not None:
+                timer.reset()
+                timer.enabled = True
+            t1 = time.perf_counter()
+        b = batches[i % len(batches)]
+        lg, _ = eng.forward(b["sup"], b["tgt"], b["sl"], b["rl"], way=WAY, T=c["T"], merge_before=c["merge_before"])
+        if i == 0:
+            lg0 = lg
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    eps_per_s = steps * B / dt
+    gexec = executed_gflop_per_frame(c["arch"], c["gflop"], getattr(getattr(eng, "vit", None), "prune_last", False))
+    e2e = eps_per_s * gexec * fpe / 1e3
+    leg = {"config": cfgname, "precision": precision, "value": round(eps_per_s, 3), "unit": "episodes/s", "steps": steps,
+           "episodes_per_step": B, "ms_per_step": round(dt / steps * 1e3, 4), "frames_per_episode": fpe,
+           "tflop_per_episode_executed": round(gexec * fpe / 1e3, 4)}
+    if timer is not None:
+        timer.enabled = False
+        if timer.launches:
+            ms, flops, n = timer.result()
+            ach = flops / (ms * 1e-3) / 1e12
+            leg["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "frac_end_to_end": round(e2e / PEAK_BF16_TFLOPS, 4),
+                               "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "traffic": None,
+                               "frac_scope": "dominant kernel only: the 16-bit MFMA GEMM launches of this leg (HIP events)"}
+    leg["parity"] = golden_parity(lg0[0], precision, cfgname) if cfgname in GOLDEN_FILE else {"checked": False, "reason": "config has no in-bench golden"}
+    del eng
+    torch.cuda.empty_cache()
+    return leg
 
 
 def parse_args(argv=None):
@@ -239,6 +311,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-fp16-leg", action="store_true", help="skip the extra fp16-mode measurement of the default (bf16) run")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the short cfg3 / cfg4 legs (bf16 and fp16) of the default run")
     ap.add_argument("--dev-gemm-variant", default=None,
                     help="developer A/B only (needs CFSAR_DEV_LIB=1): 'variant[:dbg]' forced on every 16-bit GEMM, e.g. 13 = p12")
     ap.add_argument("--rendezvous-timeout", type=int, default=300,
@@ -298,6 +371,41 @@ def _checkin(tag, rank, world, timeout_s):
             missing.append(r)
     if missing:
         raise SystemExit("bench.py rank %d: rank(s) %s did not reach '%s' within %d s" % (rank, missing, tag, timeout_s))
+
+
+class _CollectiveWatchdog:
+    """The timed region ends in the path's one collective.  A rank that died or hangs inside its steps would leave the others waiting in it
+    (RCCL: until the process-group watchdog tears the job down, naming nobody).  Every rank posts `<tag>/<rank>` in the rendezvous store (a
+    non-blocking set) right before it enters the collective; if the collective has not returned after `timeout_s` seconds this timer thread
+    reads which ranks never posted, names them on stderr and ends the process with a non-zero code."""
+
+    def __init__(self, tag, rank, world, timeout_s):
+        import threading
+        self.tag, self.rank, self.world, self.timeout_s = tag, rank, world, timeout_s
+        self.store = dist.distributed_c10d._get_default_store()
+        self.store.set("%s/%d" % (tag, rank), "1")
+        self.timer = threading.Timer(timeout_s, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def missing(self):
+        out = []
+        for r in range(self.world):
+            try:
+                if not self.store.check(["%s/%d" % (self.tag, r)]):
+                    out.append(r)
+            except Exception:
+                return "unknown (the rendezvous store on rank 0 is unreachable: rank 0 is gone)"
+        return out
+
+    def _fire(self):
+        sys.stderr.write("bench.py rank %d: the timed collective did not complete within %d s -- rank(s) %s never reached it\n" % (
+            self.rank, self.timeout_s, self.missing()))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def cancel(self):
+        self.timer.cancel()
 
 
 def run(args):
@@ -402,16 +510,27 @@ def run(args):
             timer.enabled = (not args.no_kernel_events) and i % event_every == 0
         step(i, acc)
     gathered = acc[:args.steps * B]
+    if dry and os.environ.get("CFSAR_BENCH_TEST_HANG_RANK") == str(rank):      # dry runs only (tests/test_bench_contract.py): a rank that
+        time.sleep(3600)                                                        # never leaves its timed steps
     if use_dist:                                                     # the path's single collective
-        allacc = torch.empty(world * args.steps * B, device=dev)
-        dist.all_gather_into_tensor(allacc, gathered.contiguous())
-        gathered = allacc
-        sync()
-        dist.barrier()
+        wd = _CollectiveWatchdog("timed", rank, world, args.rendezvous_timeout)
+        try:
+            allacc = torch.empty(world * args.steps * B, device=dev)
+            dist.all_gather_into_tensor(allacc, gathered.contiguous())
+            gathered = allacc
+            sync()
+            dist.barrier()
+        except Exception as exc:                                     # gloo reports a dead peer at once: say WHICH rank is missing
+            raise SystemExit("bench.py rank %d: the timed collective failed (%s) -- rank(s) %s never reached it" % (rank, exc, wd.missing()))
+        finally:
+            wd.cancel()
     sync()
     elapsed = time.perf_counter() - t0
+    main_gemm = None
     if timer is not None:
         timer.enabled = False
+        if timer.launches:
+            main_gemm = timer.result()              # read NOW: the extra legs below reuse (and reset) the timer
     rank_elapsed = [elapsed]
     collective = None
     if use_dist:
@@ -453,28 +572,27 @@ def run(args):
                                "(utils/prefetch.py, the product harness's path)"}
 
     fp16_mode = None
+    config_legs = None
     if (not dry and rank == 0 and world == 1 and args.precision == "bf16" and not args.no_fp16_leg
             and B * frames_per_ep > 160):              # (small steps: a handful of them does not time anything)
-        # The 16-bit mode that meets the north-star tolerance (precision "fp16": IEEE-half operands everywhere, same kernels), timed
+        # The 16-bit mode that meets the north-star tolerance on the goldens (precision "fp16": IEEE-half operands everywhere, same kernels), timed
         # in the same process on the same resident steps: `value` stays BASELINE's bf16 configuration, this object says what the
-        # 1e-3-conforming mode costs.  `python bench.py --precision fp16` makes it the headline instead.
-        eng16 = ClipFsarEngine(a, sd, tt, te, precision="fp16", device=dev, max_frames=max(1280, B * frames_per_ep))
-        n16 = max(4, min(args.steps, 10))
-        lg16 = None
-        for i in range(2 + n16):
-            if i == 2:
-                sync()
-                t1 = time.perf_counter()
-            b = batches[i % len(batches)]
-            lg, _ = eng16.forward(b["sup"], b["tgt"], b["sl"], b["rl"], way=WAY, T=T, merge_before=MERGE_BEFORE)
-            if i == 0:
-                lg16 = lg
-        sync()
-        dt16 = time.perf_counter() - t1
-        fp16_mode = {"precision": "fp16", "value": round(n16 * B / dt16, 3), "unit": "episodes/s", "steps": n16,
-                     "ms_per_step": round(dt16 / n16 * 1e3, 4),
-                     "parity": golden_parity(lg16[0], "fp16") if args.config == "cfg2" else {"checked": False, "reason": "config has no in-bench golden"}}
-        del eng16
+        # conforming mode costs and where its GEMMs sit on the roofline.  `python bench.py --precision fp16` makes it the headline instead.
+        fp16_mode = timed_leg(args.config, "fp16", B, max(4, min(args.steps, 10)), dev, timer, weights=(sd, tt, te), batches=batches)
+    if (not dry and rank == 0 and world == 1 and args.precision == "bf16" and args.config == "cfg2" and not args.no_config_legs
+            and B * frames_per_ep > 160):
+        # BASELINE configs[2..3] in front of the driver: 3 timed steps of 8 episodes each, bf16 and fp16, with golden parity
+        config_legs = {}
+        for cname in ("cfg3", "cfg4"):
+            cc = CONFIGS[cname]
+            w = (sd, tt, te) if cc["arch"] == ARCH else None
+            if w is None:
+                aa = synth.ARCHS[cc["arch"]]
+                w = ({k: torch.from_numpy(v) for k, v in synth.head_state_dict(cc["arch"], SEED).items()},
+                     synth.text_features(N_TRAIN, aa["embed"], "train", SEED), synth.text_features(N_TEST, aa["embed"], "test", SEED))
+            for prec in ("bf16", "fp16"):
+                config_legs["%s_%s" % (cname, prec)] = timed_leg(cname, prec, 8, 3, dev, timer, weights=w)
+            del w
 
     if rank == 0:
         episodes = world * args.steps * B
@@ -483,13 +601,8 @@ def run(args):
         # executed work: the last ViT block is computed for the class-token rows only (engine.py: prune_last; few_shot.py:683 reads
         # nothing else of it; q, attention, out_proj and the MLP of the other N - 1 rows) -- (N - 1) (20 D^2 + 4 N D) FLOPs per frame fewer; every
         # end-to-end fraction below is priced on THIS figure
-        gflop_exec = GFLOP_PER_FRAME
-        pruned = False
-        if not dry and ARCH.startswith("ViT") and getattr(eng.vit, "prune_last", False):
-            a_ = synth.ARCHS[ARCH]
-            n_, d_ = (a_["res"] // a_["patch"]) ** 2 + 1, a_["width"]
-            gflop_exec = GFLOP_PER_FRAME - (n_ - 1) * (20.0 * d_ * d_ + 4.0 * n_ * d_) / 1e9
-            pruned = True
+        pruned = bool(not dry and ARCH.startswith("ViT") and getattr(eng.vit, "prune_last", False))
+        gflop_exec = executed_gflop_per_frame(ARCH, GFLOP_PER_FRAME, pruned)
         tflop_exec = gflop_exec * frames_per_ep / 1e3
         out = {
             "metric": "episodes/sec (5-way %d-shot, %d frames, %s)" % (SHOT, T, ARCH), "value": round(eps_per_s, 3),
@@ -522,8 +635,8 @@ def run(args):
         else:
             e2e_tflops = eps_per_s / world * tflop_exec                      # executed FLOPs, not the reference path's
             out["end_to_end_vit_tflops_per_gpu"] = round(e2e_tflops, 2)
-            if timer is not None and timer.launches:
-                ms, flops, n = timer.result()
+            if main_gemm is not None:
+                ms, flops, n = main_gemm
                 achieved = flops / (ms * 1e-3) / 1e12
                 traffic, traffic_src = measured_traffic(B) if (args.config == "cfg2" and args.precision == "bf16") else (None, None)
                 out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
@@ -543,6 +656,8 @@ def run(args):
             if fp16_mode is not None:
                 fp16_mode["relative_to_value"] = round(fp16_mode["value"] / eps_per_s, 4)
                 out["fp16_mode"] = fp16_mode
+            if config_legs is not None:
+                out["configs"] = config_legs
             if host_inputs is not None:
                 host_inputs["resident_episodes_per_s"] = round(eps_per_s / world, 3)
                 out["inputs_host"] = host_inputs

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libclipfsar_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_vit.hip", "gemm_vit4.hip", "rowops.hip", "attention.hip", "tail.hip", "conv.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_vit.hip", "gemm_vit4.hip", "gemm_vit1w.hip", "rowops.hip", "attention.hip", "tail.hip", "conv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # Developer build (`python clip-fsar_amd/build.py --dev`): the same sources with -DCFSAR_DEV -- ablation switches and the
 # cfsar_debug_* hooks of include/clipfsar_hip_dev.h -- as a SEPARATE library, libclipfsar_hip_dev.so, which clip_fsar_amd.hip

@@ -1603,7 +1603,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     // CU): the persistent kernel of gemm_vit.hip whose operand pipeline runs through the epilogues.  Dev builds: variant
     // 20 + 4 * opath + store forces it on any shape; dbg bit 256 = column-fastest tile walk, bits 9-11 = band group (see below).
     if (in_dtype == CFSAR_BF16 && row_group == 0 && res_mod == 0 && row_off == 0 &&
-        ((forced == 0 && kUseVitKernel && tiles4 >= 512) || (forced >= 20 && forced < 40))) {
+        ((forced == 0 && kUseVitKernel && tiles4 >= 512) || (forced >= 20 && forced < 44))) {
         VitGemmCall c;
         c.A = A; c.W = W; c.out = out; c.bias = bias; c.res = residual;
         c.rowstats = nullptr; c.cvec = nullptr; c.stats_out = nullptr;
@@ -1616,6 +1616,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
         c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = 0;
 #ifdef CFSAR_DEV
         if (forced >= 20 && forced < 31) { c.opath = (forced - 20) >> 2; c.store = (forced - 20) & 3; }
+        else if (forced >= 40) { c.opath = 5; c.store = forced - 40; }      // 40 / 42: one wave per SIMD, 128 x 128 wave tiles (gemm_vit1w.hip)
         else if (forced >= 36) { c.opath = 4; c.store = forced - 36; }      // 36 / 38: the two-workgroups-per-CU kernel (gemm_vit4.hip), plain / write-through stores
         else if (forced >= 31) { c.opath = 2; c.store = forced - 28; }      // 31..34: store-policy A/B on the early-DMA path
         c.dbg = g_dbg_override;

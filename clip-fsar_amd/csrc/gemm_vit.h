@@ -90,3 +90,5 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s);
 int cfsar_vit_policy_opath(int K);
 // gemm_vit4.hip: the launch `a` (as cfsar_gemm_vit_try filled it) on 192 x 128 tiles, two 4-wave workgroups per CU; -2 = not covered
 int cfsar_gemm_vit4_launch(const VitGemmArgs& a, int mode, bool f16io, int store, hipStream_t s);
+// gemm_vit1w.hip: the same launch with one wave per SIMD (4 waves, 128 x 128 wave tiles, 256 x 256 tiles); opath 5; -2 = not covered
+int cfsar_gemm_vit1w_launch(const VitGemmArgs& a, int mode, bool f16io, int store, hipStream_t s);

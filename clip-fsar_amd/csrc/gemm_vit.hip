@@ -752,6 +752,14 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
         }
         opath = c.K <= 1024 ? 2 : 0;
     }
+    if (opath == 5) {                               // the one-wave-per-SIMD form (gemm_vit1w.hip)
+        const int rc = cfsar_gemm_vit1w_launch(a, mode, f16io, c.store, s);
+        if (rc != -2) {
+            if (c.out_miw) *c.out_miw = 4;
+            return rc;
+        }
+        opath = c.K <= 1024 ? 2 : 0;
+    }
     switch (opath * 4 + c.store) {
         case 0: return launch_path<0, 0>(a, mode, f16io, s);
         case 2: return launch_path<0, 2>(a, mode, f16io, s);

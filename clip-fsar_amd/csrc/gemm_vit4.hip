@@ -298,6 +298,9 @@ __global__ __launch_bounds__(256, 2) void vit_gemm4_kernel(VitGemmArgs p) {
         if (has_next) origin(bn, m0n, n0n);
         static_for<NL>([&](auto J) { load_one(sb, 0, J, xfA, wfA); });
         CFSAR_TRACE4(0);
+#ifdef CFSAR_DEV
+        if (p.dbg & (1 << 19)) __builtin_amdgcn_s_setprio(1);          // A/B: the K loop outranks the partner workgroup's epilogue
+#endif
         int kt = 0;
         // nk >= 3 (launcher).  The second-to-last step ALWAYS prefetches K tile 0 of the "next" tile (after this workgroup's last tile that is the
         // current one again: the surplus loads re-read valid memory into the free stage and are waited for by the last step).
@@ -309,6 +312,9 @@ __global__ __launch_bounds__(256, 2) void vit_gemm4_kernel(VitGemmArgs p) {
         step((sb + kt) & 1, (sb + kt + 1) & 1, offX, offW, 0, F_{}, F_{}, F_{}, F_{}, T_{});      // last step: its stage becomes the slab
         tail_fold();
         CFSAR_TRACE4(1);
+#ifdef CFSAR_DEV
+        if (p.dbg & (1 << 19)) __builtin_amdgcn_s_setprio(0);
+#endif
         char* slab = smem + ((sb + kt) & 1) * STG + wave * 1024;
 #ifdef CFSAR_DEV
         if (p.dbg & 4) {                                                // ablation: no epilogue (keep the accumulators live)

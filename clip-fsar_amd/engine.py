@@ -40,9 +40,20 @@ def _round_up(x, m):
 class HipViT:
     """CLIP VisionTransformer.forward (reference few_shot.py:671-688) on the HIP kernels."""
 
-    def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda", stream_dtype=None, fp16_split=None, fp16_mcorr=None):
+    # developer options (tools/*.py; every default is the product setting and has a GPU test): ablations of the fp16 numerics mode and the
+    # statistics fusion.  They are constructor arguments -- the product path reads four environment variables only (CFSAR_LN_FOLD,
+    # CFSAR_FULL_LAST_BLOCK, CFSAR_FP16_SPLIT, CFSAR_FP16_MCORR).
+    OPTIONS = {"fp16_wide": True, "fp16_lo": True, "fp16_rawmeans": True, "fused_umeans": True, "fused_omeans": True, "fuse_stats": True}
+
+    def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda", stream_dtype=None, fp16_split=None, fp16_mcorr=None,
+                 options=None):
         if precision not in ("bf16", "fp16", "fp32"):
             raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
+        opt = dict(self.OPTIONS)
+        for k, v in (options or {}).items():
+            if k not in opt:
+                raise ValueError("HipViT: unknown option %r (known: %s)" % (k, ", ".join(sorted(opt))))
+            opt[k] = bool(v)
         self.arch = dict(arch)
         self.precision = precision
         self.dev = torch.device(device)
@@ -57,7 +68,7 @@ class HipViT:
         # stream's bytes, and on top of bf16 operands the fp16 rounding is not measurable (feature rms error 0.0064 with an
         # fp16 stream vs 0.0067 with an fp32 one, against 0.0092 for a bf16 stream; docs/history/design_r01-r03.md "Numerics modes").
         if stream_dtype is None:
-            stream_dtype = "fp16" if precision == "fp16" else os.environ.get("CFSAR_STREAM", "fp16" if precision == "bf16" else "fp32")
+            stream_dtype = "fp32" if precision == "fp32" else "fp16"
         if stream_dtype not in ("fp16", "fp32") or (precision == "fp32" and stream_dtype != "fp32") or (precision == "fp16" and stream_dtype != "fp16"):
             raise ValueError("stream_dtype must be 'fp32' (bf16 / fp32 precision) or 'fp16' (bf16 / fp16 precision)")
         self.xd = torch.float16 if stream_dtype == "fp16" else torch.float32
@@ -116,9 +127,9 @@ class HipViT:
         #             read x_hi and its statistics;
         #   split  -- which GEMMs carry their weights as fp16 hi + lo pairs [N, 2K] (the rounding of the WEIGHTS is the error that
         #             does not average out over tokens and frames): twice the MFMA work of each GEMM named.
-        # CFSAR_FP16_WIDE / CFSAR_FP16_LO / CFSAR_FP16_SPLIT override the defaults (ablation: tools/parity_report.py).
-        self.wide = precision == "fp16" and os.environ.get("CFSAR_FP16_WIDE", "1") != "0"
-        self.two_word = self.wide and os.environ.get("CFSAR_FP16_LO", "1") != "0"
+        # options fp16_wide / fp16_lo and CFSAR_FP16_SPLIT override the defaults (ablation: tools/fp16_variants.py).
+        self.wide = precision == "fp16" and opt["fp16_wide"]
+        self.two_word = self.wide and opt["fp16_lo"]
         sp = os.environ.get("CFSAR_FP16_SPLIT", FP16_SPLIT_DEFAULT if fp16_split is None else fp16_split) if precision == "fp16" else ""
         self.split = set(t for t in sp.split(",") if t)
         #   mcorr  -- which GEMMs get the PER-FRAME LOW-WORD CORRECTION instead: the second weight word multiplies only the per-frame
@@ -132,11 +143,17 @@ class HipViT:
         if not (self.split | self.mcorr) <= {"qkv", "out", "fc", "pr"}:
             raise ValueError("CFSAR_FP16_SPLIT / CFSAR_FP16_MCORR: names out of qkv,out,fc,pr expected, got %r / %r" % (sp, mc))
         self.mcorr -= self.split                                  # a split GEMM needs no correction
-        if self.mcorr and (self.ntok < 128 or not self.wide):
-            self.split |= self.mcorr                              # frames too short for the kernel's two-frames-per-tile form
+        if self.mcorr and self.ntok < 128:
+            self.split |= self.mcorr                              # frames too short for the kernel's two-frames-per-tile form: the exact form
             self.mcorr = set()
-        if self.split and not self.wide and (self.split & {"out", "pr"}):
-            raise ValueError("split out_proj / c_proj weights need the wide residual GEMM (CFSAR_FP16_WIDE=1)")
+        if not self.wide and precision == "fp16" and (self.mcorr or self.split & {"out", "pr"}):
+            # option fp16_wide = False is round 3's packed-fp16 residual add, kept as an ablation of the ONE-word mode: it has neither the
+            # correction's k slot nor split residual weights (say so instead of silently promoting the correction to the split)
+            import warnings
+            warnings.warn("HipViT: option fp16_wide=False drops the per-frame correction / split residual weights (%s / %s)" % (
+                ",".join(sorted(self.mcorr)) or "-", ",".join(sorted(self.split & {"out", "pr"})) or "-"))
+            self.mcorr = set()
+            self.split -= {"out", "pr"}
 
         def hilo(W32):
             """fp32 [N, K] -> fp16 [N, 2K] = [hi | lo]"""
@@ -195,27 +212,19 @@ class HipViT:
             if self.fold:
                 for blk in self.blocks:          # the unfolded 16-bit copies would only serve the fallback above: free ~1/3 of the tower's weights
                     blk["w_qkv"] = blk["w_fc"] = None
-        # head-blocked qkv / attention-output layout (bf16 folded path, >= 128 tokens per frame, 64-wide heads): OFF by default.
-        # Measured at 16 episodes per step, same box, alternating runs: the attention kernel gains 3-14 us per layer from the 75 KB
-        # contiguous (frame, head) blocks (9 % in isolation), the QKV GEMM's scattered 128-byte line stores lose 15-18 us, out_proj
-        # 3 us: GPU busy time 311.4 vs 308.7 ms per 6 steps.  Kept (bit-identical results, tests/test_gpu_kernels.py) for a future
-        # attention kernel that can use whole contiguous items.
-        self.head_blocked = (self.fold and self.ntok >= 128 and D == 64 * self.H and os.environ.get("CFSAR_HEAD_BLOCKED", "0") == "1")
-        if self.head_blocked and precision == "fp16":
-            raise ValueError("CFSAR_HEAD_BLOCKED=1 exists for the bf16 mode only (the head-blocked GEMM instances write bf16)")
         # Last block, class token only.  VisionTransformer.forward reads x[:, 0] after the last block and nothing else of it
         # (few_shot.py:683), so in THAT block the attention output, out_proj and the MLP are needed for row 0 of every frame alone
         # (K and V still come from all tokens): -6.3 % of the tower's FLOPs (ViT-B/16, 12 layers), same class-token arithmetic.
         # CFSAR_FULL_LAST_BLOCK=1 computes the whole block like the reference's PyTorch code does (taps always do).
         self.prune_last = os.environ.get("CFSAR_FULL_LAST_BLOCK", "0") != "1"
         # LN statistics finalized inside the consuming GEMM (ViT-B / ViT-L widths; CFSAR_FUSE_STATS=0: the separate finalize launches)
-        self.fuse_stats = bool(self.fold) and hip.lnfold_partials_ok(self.D, self.D // 64) and os.environ.get("CFSAR_FUSE_STATS", "1") != "0"
-        self.fused_umeans = os.environ.get("CFSAR_FUSED_UMEANS", "1") != "0"      # c_fc emits the hidden's per-frame means (A/B switch)
-        self.fused_omeans = os.environ.get("CFSAR_FUSED_OMEANS", "1") != "0"      # the attention kernel emits its output's per-frame means
+        self.fuse_stats = bool(self.fold) and hip.lnfold_partials_ok(self.D, self.D // 64) and opt["fuse_stats"]
+        self.fused_umeans = opt["fused_umeans"]      # c_fc emits the hidden's per-frame means (A/B switch)
+        self.fused_omeans = opt["fused_omeans"]      # the attention kernel emits its output's per-frame means
         # The LN-folded GEMMs' correction in its RAW-STREAM form: corr = xbar W_lo^T with xbar the per-frame token mean of the raw stream (the row
         # mean's share rides in cvec = the exact column sums of W gamma).  xbar needs no pass over x: the stream's update x += A W^T + b is linear
         # in the frame's token mean, so xbar += mean_t(A) W^T + b from the operand means the residual GEMMs' own corrections already have.
-        self.rawmeans = (os.environ.get("CFSAR_FP16_RAWMEANS", "1") != "0" and self.fused_umeans and self.fused_omeans
+        self.rawmeans = (opt["fp16_rawmeans"] and self.fused_umeans and self.fused_omeans
                          and all(k in self.mcorr for k in ("qkv", "out", "fc", "pr")))
         if self.rawmeans:
             for i, blk in enumerate(self.blocks):
@@ -224,10 +233,6 @@ class HipViT:
                 blk["wb_pr"] = g(bb + "mlp.c_proj.weight").to(torch.bfloat16).contiguous()
         if self.mcorr & {"qkv", "fc"}:
             self.fuse_stats = False          # the token means of LayerNorm(x) need the finalized statistics in front of the GEMM
-        # band-chunked layer schedule (developer switch; measured in profiles/r04_chunked_schedule.md): CFSAR_CHUNK_FRAMES=k,
-        # CFSAR_CHUNK_MODE = block | pairs | mlp
-        self.chunk_frames = int(os.environ.get("CFSAR_CHUNK_FRAMES", "0"))
-        self.chunk_mode = os.environ.get("CFSAR_CHUNK_MODE", "block")
         self._slots = {}
         self.max_frames_32bit = (2 ** 32 - 1) // (self.ntok * 4 * self.D * 2) - 1
 
@@ -316,7 +321,7 @@ class HipViT:
             if xlo is not None:
                 xlo[:M].zero_()                                                       # memset: the stream enters the blocks as ln_pre's fp16 output
             hip.row_stats(x, rstat, M, D)                                             # statistics of ln_pre's output
-            prune = self.prune_last and taps is None and not self.head_blocked
+            prune = self.prune_last and taps is None
             # ViT-B / ViT-L widths: the LN-folded GEMMs finalize the producer's partial statistics themselves (cfsar_gemm_lnfold_partials):
             # no kernel between out_proj and c_fc, c_proj and the next block's QKV (46 launches per tower call; 8 % of a one-episode step)
             fuse = self.fuse_stats
@@ -347,17 +352,14 @@ class HipViT:
                 hip.corr_gemm(mA, wlo, cr)
                 return cr
 
-            def fold(xx, wg, out, c, d, pt, rs, act=hip.ACT_NONE, rows=M, from_part=False, heads=False, sp=False, corr=None, umeans=None,
-                     corr_raw=False):
+            def fold(xx, wg, out, c, d, pt, rs, act=hip.ACT_NONE, rows=M, from_part=False, sp=False, corr=None, umeans=None, corr_raw=False):
                 if sp or corr is not None or umeans is not None:                      # fp16 numerics mode: split weights [N, 2K] / correction
                     hip.gemm_lnfold_hp(xx, wg, out, c, d, rowstats=None if from_part else rs, partial=pt if from_part else None,
                                        slots=S if from_part else 0, rowstats_ws=rs, act=act, M=rows, wsplit=sp, corr=corr,
                                        corr_tokens=N if (corr is not None or umeans is not None) else 0, colmean_out=umeans,
                                        colsum_ws=ws["colsum"] if umeans is not None else None, corr_raw=corr_raw and corr is not None)
                 elif from_part:
-                    hip.gemm_lnfold_partials(xx, wg, out, c, d, pt, S, rs, act=act, M=rows, tokens=N if heads else 0, heads=self.H if heads else 0)
-                elif heads:
-                    hip.gemm_lnfold_heads(xx, wg, out, c, d, rs, N, self.H, M=rows)
+                    hip.gemm_lnfold_partials(xx, wg, out, c, d, pt, S, rs, act=act, M=rows)
                 else:
                     hip.gemm_lnfold(xx, wg, out, c, d, rs, act=act, M=rows)
 
@@ -403,73 +405,26 @@ class HipViT:
                     resid(uc, b, "pr", xc, xlc, None, F_, cls=True)
                     xc_final = xc
                     break
-                if self.head_blocked:
-                    # qkv and the attention output in head-blocked layout: 75 KB contiguous per (frame, head) for the attention
-                    # kernel (called as frames x heads one-head problems), K tile kt of out_proj = head kt
-                    fold(x, b["wg_qkv"], qkv, b["c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, heads=True)
-                    hip.vit_attention(qkv, o, F_ * self.H, N, 64, 1)
-                    hip.gemm_residual_stats_heads(o, b["w_out"], x, b["b_out"], N, part, M=M)
-                elif self.chunk_frames and fuse and F_ > self.chunk_frames and not self.wide:
-                    # band-chunked schedule (developer switch, measured SLOWER at every chunk size:
-                    # profiles/r04_chunked_schedule.md): the block runs chunk by chunk of frames, the chunk's qkv / o / u live in ONE
-                    # reused buffer prefix so that they are consumed while cache-resident
-                    cf, mode = self.chunk_frames, self.chunk_mode
-
-                    def attn_part(f0, f1):
-                        r0, r1, nr = f0 * N, f1 * N, (f1 - f0) * N
-                        xs, ps, rs = x[r0:r1], part[r0:r1], rstat[r0:r1]
-                        fold(xs, b["wg_qkv"], qkv[:nr], b["c_qkv"], b["d_qkv"], ps, rs, rows=nr, from_part=in_part)
-                        hip.vit_attention(qkv[:nr], o[:nr], f1 - f0, N, D, self.H)
-                        hip.gemm_residual_stats(o[:nr], b["w_out"], xs, b["b_out"], ps, M=nr)
-
-                    def mlp_part(f0, f1):
-                        r0, r1, nr = f0 * N, f1 * N, (f1 - f0) * N
-                        xs, ps, rs = x[r0:r1], part[r0:r1], rstat[r0:r1]
-                        fold(xs, b["wg_fc"], u[:nr], b["c_fc"], b["d_fc"], ps, rs, act=hip.ACT_QUICKGELU, rows=nr, from_part=True)
-                        hip.gemm_residual_stats(u[:nr], b["w_pr"], xs, b["b_pr"], ps, M=nr)
-
-                    chunks = [(f0, min(F_, f0 + cf)) for f0 in range(0, F_, cf)]
-                    if mode == "block":              # the whole block per chunk
-                        for f0, f1 in chunks:
-                            attn_part(f0, f1)
-                            mlp_part(f0, f1)
-                    elif mode == "pairs":            # QKV -> attention -> out_proj per chunk, then c_fc -> c_proj per chunk
-                        for f0, f1 in chunks:
-                            attn_part(f0, f1)
-                        for f0, f1 in chunks:
-                            mlp_part(f0, f1)
-                    else:                            # "mlp": only c_fc -> c_proj per chunk
-                        attn_part(0, F_)
-                        for f0, f1 in chunks:
-                            mlp_part(f0, f1)
-                    in_part = True
-                    if taps is not None:
-                        taps["block%d" % i] = x[:M].clone()
-                    continue
+                fold(x, b["wg_qkv"], qkv, b["cx_qkv" if raw else "c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, sp="qkv" in split,
+                     corr=mc(b, "qkv", x, rstat), corr_raw=raw)
+                if "out" in mcorr and self.fused_omeans:                           # the attention kernel emits its output's per-frame means
+                    mO = ws["mX"][:F_]
+                    hip.vit_attention_means(qkv, o, mO, F_, N, D, self.H)
                 else:
-                    fold(x, b["wg_qkv"], qkv, b["cx_qkv" if raw else "c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, sp="qkv" in split,
-                         corr=mc(b, "qkv", x, rstat), corr_raw=raw)
-                    if "out" in mcorr and self.fused_omeans:                           # the attention kernel emits its output's per-frame means
-                        mO = ws["mX"][:F_]
-                        hip.vit_attention_means(qkv, o, mO, F_, N, D, self.H)
-                    else:
-                        mO = None
-                        hip.vit_attention(qkv, o, F_, N, D, self.H)
-                    resid(o, b, "out", x, xlo, part, M, corr=mc(b, "out", o, means=mO))   # x += out_proj(attn); stats of the new x
-                    if raw:
-                        hip.mean_update_gemm(mO, b["wb_out"], b["b_out"], xbar)           # ... and its per-frame mean follows
+                    mO = None
+                    hip.vit_attention(qkv, o, F_, N, D, self.H)
+                resid(o, b, "out", x, xlo, part, M, corr=mc(b, "out", o, means=mO))   # x += out_proj(attn); stats of the new x
+                if raw:
+                    hip.mean_update_gemm(mO, b["wb_out"], b["b_out"], xbar)           # ... and its per-frame mean follows
                 if not fuse:
                     hip.ln_stats_finalize(part, rstat, M, S, D)
                 # c_fc also emits the per-frame token means of the hidden it writes: c_proj's correction needs no pass of its own over u
                 um = ws["mU"][:F_ * 4 * D].view(F_, 4 * D) if ("pr" in mcorr and self.fused_umeans) else None
                 fold(x, b["wg_fc"], u, b["cx_fc" if raw else "c_fc"], b["d_fc"], part, rstat, act=hip.ACT_QUICKGELU, from_part=fuse, sp="fc" in split,
                      corr=mc(b, "fc", x, rstat), umeans=um, corr_raw=raw)
-                if self.head_blocked:
-                    hip.gemm_residual_stats(u, b["w_pr"], x, b["b_pr"], part, M=M)
-                else:
-                    resid(u, b, "pr", x, xlo, part, M, corr=mc(b, "pr", u, means=um))  # x += c_proj(gelu(c_fc))
-                    if raw:
-                        hip.mean_update_gemm(um, b["wb_pr"], b["b_pr"], xbar)
+                resid(u, b, "pr", x, xlo, part, M, corr=mc(b, "pr", u, means=um))      # x += c_proj(gelu(c_fc))
+                if raw:
+                    hip.mean_update_gemm(um, b["wb_pr"], b["b_pr"], xbar)
                 if fuse:
                     in_part = True
                 else:
@@ -768,14 +723,14 @@ class ClipFsarEngine:
     """Full episodic forward A0 -> A15 for a batch of B episodes with identical (way, shot, query, T)."""
 
     def __init__(self, arch: dict, head_sd: dict, text_train, text_test, depth: int = 1, precision: str = "bf16",
-                 device="cuda", max_frames: int = 1280, fp16_split=None, fp16_mcorr=None):
+                 device="cuda", max_frames: int = 1280, fp16_split=None, fp16_mcorr=None, vit_options=None):
         self.dev = torch.device(device)
         self.arch = dict(arch)
         if arch.get("kind") == "rn":
             self.vit = HipResNet(arch, head_sd, prefix="backbone.", precision=precision, device=device)
         else:
             self.vit = HipViT(arch, head_sd, prefix="backbone.", precision=precision, device=device, fp16_split=fp16_split,
-                              fp16_mcorr=fp16_mcorr)
+                              fp16_mcorr=fp16_mcorr, options=vit_options)
         self.temporal = HipTemporalHead(head_sd, arch["embed"], depth=depth, device=device)
         f32 = lambda t: (t if isinstance(t, torch.Tensor) else torch.from_numpy(t)).detach().to(
             device=self.dev, dtype=torch.float32).contiguous()
@@ -785,15 +740,6 @@ class ClipFsarEngine:
         # hidden [F * tokens, 4 D] in 2 bytes (ViT-B/16: 3 548 frames fit; the engine keeps one frame of margin: 3 547); larger episode batches run the tower in chunks
         limit = getattr(self.vit, "max_frames_32bit", None)
         self.max_frames = min(max_frames, limit) if limit else max_frames
-        # Two episodes per call (81-160 frames): the support and the query frames go through the tower as two concurrent forwards on
-        # two HIP streams -- with two independent kernel chains the tail of one chain's kernel is filled by the other chain's next
-        # kernel (311 vs 304 episodes/s).  One episode (80 frames) runs as ONE chain since the ViT GEMM has its 192-row tile form
-        # (csrc/gemm_vit.hip, MIW = 3: 2.9 rounds of 192-row tiles instead of 2.2 rounds of 256-row ones that cost 3): 272 vs 269.
-        # Opt-in since round 4 (CFSAR_DUAL_STREAM=1): the mirrored harness batches 16 episodes per call by default, and a second kernel on the chip
-        # was the condition under which round 2's stale-lanes fault was most frequent (profiles/r04_fault_audit.md).
-        self.dual_frames = 160 if os.environ.get("CFSAR_DUAL_STREAM", "0") == "1" else 0
-        self.dual_min_frames = int(os.environ.get("CFSAR_DUAL_MIN_FRAMES", "81"))
-        self._side = None
 
     def forward(self, support_set, target_set, support_labels, real_support_labels, way, T, merge_before=False,
                 single_direct=False, taps=None, mode="otam", text_coff=0.9):
@@ -809,21 +755,7 @@ class ClipFsarEngine:
         feats = torch.empty(B, S + Q, T, E, device=self.dev, dtype=torch.float32)
         chunk = max(1, self.max_frames // per_ep)
         feats2d = feats.reshape(B * per_ep, E)
-        dual = (taps is None and self.dual_min_frames <= B * per_ep <= self.dual_frames and B <= chunk and self.dev.type == "cuda" and
-                not isinstance(self.vit, HipResNet))
-        if dual:
-            if self._side is None:
-                self._side = (torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev))
-            cur = torch.cuda.current_stream(self.dev)
-            sets = (support_set.reshape(-1, *support_set.shape[2:]), target_set.reshape(-1, *target_set.shape[2:]))
-            maps = ((S * T, Q * T, 0), (Q * T, S * T, S * T))
-            for slot, (st, fr, rm) in enumerate(zip(self._side, sets, maps)):
-                st.wait_stream(cur)                                          # the frames were produced on the caller's stream
-                with torch.cuda.stream(st):
-                    self.vit.forward([fr], feats2d, row_maps=[rm], slot=1 + slot)
-            for st in self._side:
-                cur.wait_stream(st)                                          # the head below reads feats on the caller's stream
-        for b0 in range(0, B if not dual else 0, chunk):
+        for b0 in range(0, B, chunk):
             b1 = min(B, b0 + chunk)
             sup = support_set[b0:b1].reshape(-1, *support_set.shape[2:])
             tgt = target_set[b0:b1].reshape(-1, *target_set.shape[2:])

@@ -54,6 +54,43 @@ HEAD_CASES = {
 }
 N_TRAIN, N_TEST, SEED = 64, 24, 18
 
+# Round 5: MANY episodes per full-size configuration, at the generator's standard contrast (logits spread ~1) and at
+# HIGH contrast (lowfreq = 2.0: a coarse per-class pattern, logits spread 3-4 as trained CLIP features give) -- the 16-bit modes' deviation
+# is judged as a statistic over >= 64 reference logit rows per configuration, not on one episode.  Only logits / class_logits are kept.
+MULTI_CASES = {
+    "mc_cfg2_B16_5w1s_T8": dict(arch="ViT-B/16", way=5, shot=1, q=1, T=8, episodes=13),
+    "hc_cfg2_B16_5w1s_T8": dict(arch="ViT-B/16", way=5, shot=1, q=1, T=8, episodes=13, lowfreq=2.0),
+    "hc_cfg3_B16_5w5s_T8_mb": dict(arch="ViT-B/16", way=5, shot=5, q=1, T=8, merge_before=True, episodes=13, lowfreq=2.0),
+    "hc_cfg4_L14_5w1s_T16": dict(arch="ViT-L/14", way=5, shot=1, q=1, T=16, episodes=13, lowfreq=2.0),
+    "mc_cfg4_L14_5w1s_T16": dict(arch="ViT-L/14", way=5, shot=1, q=1, T=16, episodes=13),
+}
+
+
+def run_multi_case(name, p):
+    arch = p["arch"]
+    a = synth.ARCHS[arch]
+    sd = synth.head_state_dict(arch, seed=SEED)
+    tt = synth.text_features(N_TRAIN, a["embed"], "train", SEED)
+    te = synth.text_features(N_TEST, a["embed"], "test", SEED)
+    cfg = rh.make_cfg(arch, way=p["way"], shot=p["shot"], frames=p["T"], n_train=N_TRAIN, n_test=N_TEST,
+                      merge_before=p.get("merge_before", False))
+    head = rh.build_reference_head(cfg, a, sd, tt, te)
+    logits, class_logits = [], []
+    t0 = time.time()
+    for e in range(p["episodes"]):
+        ep = synth.make_episode(way=p["way"], shot=p["shot"], query_per_class=p["q"], frames=p["T"], res=a["res"],
+                                n_test_classes=N_TEST, episode=e, seed=SEED, lowfreq=p.get("lowfreq", 0.0))
+        with torch.no_grad():
+            out = head(rh.episode_to_torch(ep))
+        logits.append(out["logits"].numpy())
+        class_logits.append(out["class_logits"].numpy())
+        print("  %s episode %d: spread %.3f (%.0f s)" % (name, e, float(out["logits"].max() - out["logits"].min()), time.time() - t0), flush=True)
+    meta = dict(p)
+    meta.update(n_train=N_TRAIN, n_test=N_TEST, seed=SEED, ref_seconds=round(time.time() - t0, 1), torch=torch.__version__)
+    lg = np.stack(logits)
+    np.savez_compressed(os.path.join(GOLD, "multi_%s.npz" % name), meta=json.dumps(meta), logits=lg, class_logits=np.stack(class_logits))
+    print("%-26s %d episodes, mean spread %.3f" % (name, len(logits), float(np.mean(lg.max((1, 2)) - lg.min((1, 2))))), flush=True)
+
 
 def run_head_case(name, p):
     arch = p["arch"]
@@ -279,9 +316,16 @@ def main():
     ap.add_argument("--only", nargs="*", default=None)
     ap.add_argument("--skip-large", action="store_true")
     ap.add_argument("--text-only", action="store_true")
+    ap.add_argument("--multi", nargs="*", default=None, help="only the multi-episode cases (all of them, or the ones named)")
+    ap.add_argument("--threads", type=int, default=0)
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(args.threads or os.cpu_count() or 1)
+    if args.multi is not None:
+        for name, p in MULTI_CASES.items():
+            if not args.multi or name in args.multi:
+                run_multi_case(name, p)
+        return
     if args.keys_only:
         run_state_dict_keys()
         return

@@ -67,10 +67,21 @@ def case_inputs(meta, episode=None):
     return a, sd, tt, te, ep
 
 
-def run_engine(meta, a, sd, tt, te, eps, precision, taps=None):
+_DEV_ENV = {"CFSAR_FP16_WIDE": "fp16_wide", "CFSAR_FP16_LO": "fp16_lo", "CFSAR_FP16_RAWMEANS": "fp16_rawmeans",
+            "CFSAR_FUSED_UMEANS": "fused_umeans", "CFSAR_FUSED_OMEANS": "fused_omeans", "CFSAR_FUSE_STATS": "fuse_stats"}
+
+
+def vit_options_from_env():
+    """HipViT's developer options from the environment names the tools and ablation tests set (value "0" = off).  Test / tool
+    infrastructure: the engine itself takes them as the `vit_options` constructor argument and reads none of these variables."""
+    return {opt: os.environ[env] != "0" for env, opt in _DEV_ENV.items() if env in os.environ}
+
+
+def run_engine(meta, a, sd, tt, te, eps, precision, taps=None, vit_options=None):
     """eps: list of episode dicts (cpu) -> (logits [B,Q,way], class_logits) on cpu."""
     from clip_fsar_amd.engine import ClipFsarEngine
-    eng = ClipFsarEngine(a, sd, tt, te, depth=meta.get("depth", 1), precision=precision, device="cuda")
+    eng = ClipFsarEngine(a, sd, tt, te, depth=meta.get("depth", 1), precision=precision, device="cuda",
+                         vit_options=vit_options_from_env() if vit_options is None else vit_options)
     dev = torch.device("cuda")
     sup = torch.stack([e["support_set"] for e in eps]).to(dev)
     tgt = torch.stack([e["target_set"] for e in eps]).to(dev)
@@ -87,3 +98,39 @@ def maxdiff(a, b):
     a = torch.as_tensor(a).float()
     b = torch.as_tensor(b).float()
     return float((a - b).abs().max())
+
+
+# ---- multi-episode reference goldens (round 5; oracle/make_golden.py --multi): name -> file tests/golden/multi_<name>.npz
+MULTI_CASES = ("mc_cfg2_B16_5w1s_T8", "hc_cfg2_B16_5w1s_T8", "hc_cfg3_B16_5w5s_T8_mb", "hc_cfg4_L14_5w1s_T16", "mc_cfg4_L14_5w1s_T16")
+
+
+def load_multi(name):
+    z = np.load(os.path.join(GOLD, "multi_%s.npz" % name))
+    return {"meta": json.loads(str(z["meta"])), "logits": z["logits"], "class_logits": z["class_logits"]}
+
+
+def multi_case_stats(name, precision, chunk=None):
+    """Run every episode of a multi-episode golden through the engine in `precision`; deviation statistics of the logits against the
+    REFERENCE's (the generating script imported /root/reference)."""
+    g = load_multi(name)
+    m = g["meta"]
+    a = synth.ARCHS[m["arch"]]
+    sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(m["arch"], seed=m["seed"]).items()}
+    tt = torch.from_numpy(synth.text_features(m["n_train"], a["embed"], "train", m["seed"]))
+    te = torch.from_numpy(synth.text_features(m["n_test"], a["embed"], "test", m["seed"]))
+    E = m["episodes"]
+    eps = [{k: torch.from_numpy(v) for k, v in synth.make_episode(way=m["way"], shot=m["shot"], query_per_class=m["q"], frames=m["T"], res=a["res"],
+                                                                  n_test_classes=m["n_test"], episode=e, seed=m["seed"],
+                                                                  lowfreq=m.get("lowfreq", 0.0)).items()} for e in range(E)]
+    chunk = chunk or (4 if m["arch"] == "ViT-L/14" else 8)
+    lg = torch.cat([run_engine(m, a, sd, tt, te, eps[i:i + chunk], precision)[0] for i in range(0, E, chunk)])
+    ref = torch.from_numpy(g["logits"])
+    d = (lg - ref).abs()
+    per_ep = d.reshape(E, -1).max(1).values
+    spread = (ref.reshape(E, -1).max(1).values - ref.reshape(E, -1).min(1).values)
+    flat = d.flatten().sort().values
+    return {"episodes": E, "rows": int(ref.shape[0] * ref.shape[1]), "mean_spread": float(spread.mean()),
+            "rms": float(d.pow(2).mean().sqrt()), "p99": float(flat[min(len(flat) - 1, int(0.99 * len(flat)))]), "max": float(d.max()),
+            "worst_episode_max": float(per_ep.max()), "episodes_over_1e-3": int((per_ep > 1e-3).sum()),
+            "max_rel_spread": float((per_ep / spread).max()), "rms_rel_spread": float((d.reshape(E, -1).pow(2).mean(1).sqrt() / spread).mean()),
+            "argmax_equal": int((lg.argmax(-1) == ref.argmax(-1)).sum())}

@@ -11,6 +11,7 @@ cfg2 golden in the configuration that was timed, and the RCCL (backend "nccl") a
 import json
 import os
 import subprocess
+import time
 import sys
 
 import pytest
@@ -70,6 +71,25 @@ def test_missing_rank_is_named_not_hung():
     assert "rendezvous" in p.stderr or "did not reach" in p.stderr, p.stderr[-2000:]
 
 
+def test_rank_hung_inside_the_timed_region_is_named_not_hung():
+    """A rank that never leaves its timed steps (a hung GPU) must not leave the others waiting in the collective: after the rendezvous
+    timeout every live rank names the missing one and the job ends non-zero (self-spawn and torch.distributed.run)."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env["CFSAR_BENCH_TEST_HANG_RANK"] = "2"
+    port = 29300 + (os.getpid() % 250)
+    for cmd in ([sys.executable, BENCH, "--gpus", "4"],
+                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                 "--master-port", str(port), BENCH, "--gpus", "4"]):
+        t0 = time.time()
+        p = subprocess.run(cmd + ["--steps", "2", "--warmup", "1", "--episodes-per-step", "1", "--dry-run", "--rendezvous-timeout", "6"],
+                           cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+        assert p.returncode != 0
+        assert "rank(s) [2] never reached it" in p.stderr, p.stderr[-2000:]
+        assert time.time() - t0 < 120
+
+
 def test_torchrun_dry_run_gloo():
     port = 29600 + (os.getpid() % 300)
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -92,7 +112,7 @@ needs_gpu = pytest.mark.skipif(not torch.cuda.is_available(), reason="no GPU")
 def test_bench_line_bf16_parity_roofline_rccl_ws1():
     """The timed configuration (bf16, batched episodes, persistent GEMM kernels) is the one whose logits are compared with
     the reference golden; the RCCL all-gather path runs (world size 1)."""
-    out = _run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--episodes-per-step", "16", "--no-cpu-baseline"],
+    out = _run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--episodes-per-step", "16", "--no-cpu-baseline", "--no-config-legs"],
                env_extra={"CFSAR_BENCH_FORCE_DIST": "1"})
     assert out["n_gpus"] == 1 and out["unit"] == "episodes/s" and out["value"] > 0
     par = out["parity"]

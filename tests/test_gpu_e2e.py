@@ -353,30 +353,6 @@ def test_forward_is_bit_stable_run_to_run(episodes):
             assert torch.equal(lo, ref[0]) and torch.equal(cl, ref[1]), (it, float((lo - ref[0]).abs().max()))
 
 
-def test_two_stream_small_batch_path_is_opt_in_and_bit_identical(monkeypatch):
-    """CFSAR_DUAL_STREAM=1 runs the support and the query frames of a two-episode call as two concurrent tower forwards (+2 %): opt-in since round 4,
-    and its logits are the bits of the default one-chain path (the towers' results do not depend on what shares the chip)."""
-    from clip_fsar_amd.engine import ClipFsarEngine
-    g = load_golden("cfg2_B16_5w1s_T8")
-    m = g["meta"]
-    a, sd, tt, te, ep0 = case_inputs(m)
-    eps = [ep0, case_inputs(m, episode=m["episode"] + 1)[4]]
-    st = lambda k: torch.stack([e[k] for e in eps]).cuda()
-    args = (st("support_set"), st("target_set"), st("support_labels"), st("real_support_labels"))
-    outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("CFSAR_DUAL_STREAM", flag)
-        eng = ClipFsarEngine(a, sd, tt, te, precision="bf16", device="cuda")
-        assert (eng.dual_frames > 0) == (flag == "1")
-        lo, cl = eng.forward(*args, way=m["way"], T=m["T"])
-        torch.cuda.synchronize()
-        outs.append((lo.clone(), cl.clone()))
-    monkeypatch.delenv("CFSAR_DUAL_STREAM")
-    assert ClipFsarEngine(a, sd, tt, te, precision="bf16", device="cuda").dual_frames == 0
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert maxdiff(outs[0][0][0].cpu(), g["logits"]) < LOGITS_TOLERANCE["bf16"]
-
-
 def test_fp16_mode_b16_equals_b1():
     """An episode's fp16-mode logits do not depend on the batch it is served in: the per-frame correction's k slot is chosen by the FRAME's
     parity (not by the tile a row falls into) and c_fc's per-frame means are summed per 32-row group (not per wave tile), so the 192- and
@@ -394,7 +370,7 @@ def test_fp16_mode_b16_equals_b1():
 
 def test_fp16_raw_stream_correction_switch(monkeypatch):
     """The fp16 mode's LN-folded GEMMs take their per-frame correction in the raw-stream form by default (no pass over x: the stream's per-frame
-    mean follows its updates through two [frames, K] x [K, D] GEMMs per block); CFSAR_FP16_RAWMEANS=0 restores the normalised-mean form with its
+    mean follows its updates through two [frames, K] x [K, D] GEMMs per block); the developer option fp16_rawmeans=False (tests/_cases.py maps CFSAR_FP16_RAWMEANS=0 to it) restores the normalised-mean form with its
     two frame_col_means passes per block.  Both inside the north-star tolerance on the cfg2 golden; 64 fresh episodes per configuration give the
     same rms for both (profiles/r04_parity_table.md)."""
     g = load_golden("cfg2_B16_5w1s_T8")

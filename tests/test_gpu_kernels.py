@@ -410,7 +410,7 @@ def test_gemm_policy_reaches_every_kernel(hip, M, N, K):
 
 
 @pytest.mark.skipif(os.environ.get("CFSAR_DEV_LIB", "0") != "1", reason="developer library only (CFSAR_DEV_LIB=1)")
-@pytest.mark.parametrize("variant", [1, 2, 10, 11, 12, 13, 20, 21, 22, 24, 25, 26, 28, 30, 36, 38])
+@pytest.mark.parametrize("variant", [1, 2, 10, 11, 12, 13, 20, 21, 22, 24, 25, 26, 28, 30, 36, 38, 40, 42])
 def test_gemm_forced_variants_dev(hip, variant):
     """Developer build: every kernel / operand path / store policy forced on ragged shapes (incl. shapes the policy would not
     give it), plus the alternative tile walks of the ViT kernel."""

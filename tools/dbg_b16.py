@@ -16,8 +16,7 @@ def run(eng, es, taps=None):
     lo, cl = eng.forward(sup, tgt, sl, rl, way=m["way"], T=m["T"], taps=taps)
     torch.cuda.synchronize()
     return lo.cpu(), cl.cpu()
-for mode in (os.environ.get("MODES", "dual,single,nofold").split(",")):
-    os.environ["CFSAR_DUAL_STREAM"] = "1" if mode == "dual" else "0"
+for mode in (os.environ.get("MODES", "single,nofold").split(",")):
     os.environ["CFSAR_LN_FOLD"] = "0" if mode == "nofold" else "1"
     eng = ClipFsarEngine(a, sd, tt, te, precision="bf16", device="cuda")
     ref = None

@@ -25,7 +25,7 @@ bias = torch.randn(n, device=dev)
 res_mode = shape in ("out", "proj")
 out = torch.empty(M, n, device=dev, dtype=torch.float16 if res_mode else torch.bfloat16)
 act = hip.ACT_QUICKGELU if shape == "fc" else hip.ACT_NONE
-GRID, MAXT = 256, 64
+GRID, MAXT = int(os.environ.get("TRACE_GRID", "256")), 64          # TRACE_GRID=512: the two-workgroups-per-CU kernel (variants 36 / 38)
 trace = torch.zeros(GRID * MAXT * 4, dtype=torch.int64, device=dev)
 
 
@@ -67,6 +67,9 @@ for unit in staggers:
         mid = (tr[0, t, 1] + tr[0, t, 2]) // 2
         inside = ((tr[:, :ntile, 1] <= mid) & (tr[:, :ntile, 2] >= mid)).any(1).sum()
         conc.append(int(inside))
+    st0 = tr[:, 0, 0].double() * 10.0                  # residency: first-tile start stamps of all workgroups (co-resident <=> all within a few us)
+    print("   first-tile starts: max - min %.2f us, workgroups starting > 5 us after the first: %d of %d" % (
+        float(st0.max() - st0.min()) / 1e3, int((st0 > st0.min() + 5000.0).sum()), GRID))
     if dbg & 32:                                       # half of the workgroups of each XCD skip their stores: compare the two populations
         odd = ((torch.arange(GRID) >> 3) & 1).bool()
         print("   K loop of storing workgroups %.2f us (p90 %.2f), of non-storing workgroups %.2f us (p90 %.2f); epilogue %.2f / %.2f us" % (
