@@ -113,7 +113,7 @@ def csrc_fingerprint():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "clip-fsar_amd", "csrc")
-    for n in ("common.h", "gemm.hip", "gemm_vit.h", "gemm_vit.hip"):
+    for n in ("common.h", "gemm.hip", "gemm_vit.h", "gemm_vit_epi.h", "gemm_vit.hip"):
         with open(os.path.join(d, n), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -224,8 +224,14 @@ def golden_parity(logits0, precision, config="cfg2"):
             "max_abs_dlogits": round(d, 6), "argmax_equal": bool(torch.equal(got.argmax(1), ref.argmax(1))),
             "north_star_tolerance": NORTH_STAR_TOLERANCE, "meets_north_star": bool(d < NORTH_STAR_TOLERANCE),
             "tolerance": tol, "within_tolerance": bool(d < tol),
-            "tolerance_note": "this mode's own regression bound on the full-size configurations (2 x the measured deviation, "
-                              "profiles/r04_parity_table.md); the north-star bound is 1e-3"}
+            "scope": "ONE golden episode (%d logits).  What the mode guarantees over many episodes: `contract`" % ref.numel(),
+            "contract": {"fp32": "hard bound: every logit of every episode within 1e-3 (measured <= 7.6e-6)",
+                         "fp16": "statistic, not a bound: rms <= 3.5e-4 and p99 <= 1e-3 of |dlogits| over 65 reference logit rows per configuration, standard "
+                                 "and high-contrast episodes (measured rms 2.6-3.0e-4, p99 6.0-7.0e-4); an episode's largest deviation exceeds 1e-3 in about one "
+                                 "episode of 13-60 (max seen 1.14e-3)",
+                         "bf16": "throughput mode, NOT inside 1e-3: rms 2.3-2.5e-3, max 9.4e-3 over 65 rows per configuration"}[precision],
+            "tolerance_note": "this mode's own regression bound on the full-size configurations (profiles/r05_parity_table.md, "
+                              "tests/test_gpu_e2e.py::test_modes_against_multi_episode_reference_goldens); the north-star bound is 1e-3"}
 
 
 def executed_gflop_per_frame(arch, gflop, pruned):
@@ -297,7 +303,7 @@ def timed_leg(cfgname, precision, B, steps, dev, timer, weights=None, batches=No
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--episodes-per-step", type=int, default=16)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])

@@ -13,7 +13,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libclipfsar_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_vit.hip", "gemm_vit4.hip", "gemm_vit1w.hip", "rowops.hip", "attention.hip", "tail.hip", "conv.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_vit.hip", "rowops.hip", "attention.hip", "tail.hip", "conv.hip"]
+# developer library only: the two alternative GEMM forms measured in round 5 (profiles/r05_gemm_forms.md); the product library does not carry them
+DEV_ONLY_SOURCES = ["gemm_vit4.hip", "gemm_vit1w.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # Developer build (`python clip-fsar_amd/build.py --dev`): the same sources with -DCFSAR_DEV -- ablation switches and the
 # cfsar_debug_* hooks of include/clipfsar_hip_dev.h -- as a SEPARATE library, libclipfsar_hip_dev.so, which clip_fsar_amd.hip
@@ -32,7 +34,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
 # the fence stays because it costs nothing.  Same-box A/B: no measurable cost (profiles/r03_gemm_anatomy.md); MI355X_MICROARCH.md lists packed fp32
 # beside MFMAs as an anti-lever anyway.  `-DCFSAR_PACKED_FP32` in CFSAR_BUILD_DEFS (developer builds) switches the instructions back on.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-SOURCE_FLAGS = {src: NO_PACKED_FP32 for src in SOURCES}
+SOURCE_FLAGS = {src: NO_PACKED_FP32 for src in SOURCES + DEV_ONLY_SOURCES}
 USAGE = os.path.join(HERE, "build", "resource_usage.json")
 
 
@@ -80,7 +82,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False, packed: 
     procs = []
     bdir = os.path.join(HERE, "build", variant or "packed") if (packed or variant) else (os.path.join(HERE, "build", "dev") if dev else os.path.join(HERE, "build"))
     os.makedirs(bdir, exist_ok=True)
-    for src in SOURCES:
+    for src in SOURCES + (DEV_ONLY_SOURCES if dev else []):
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         extra = (os.environ.get("CFSAR_BUILD_DEFS", "").split() if dev else []) + list(defs)      # developer A/B builds only
         if packed or "-DCFSAR_PACKED_FP32" in extra:                                # A/B: compile with the packed instructions

@@ -744,22 +744,18 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     if (mode == 0 && c.act == CFSAR_ACT_NONE && (c.dbg & 64)) mode = 3;
 #endif
     int opath = c.opath;
-    if (opath == 4) {                               // the two-workgroups-per-CU form (gemm_vit4.hip); calls it does not cover fall back to the 8-wave kernel
-        const int rc = cfsar_gemm_vit4_launch(a, mode, f16io, c.store, s);
+#ifdef CFSAR_DEV
+    // Developer library only: the two alternative forms measured in round 5 (profiles/r05_gemm_forms.md; both lose against this kernel).
+    // Calls they do not cover fall back to the 8-wave kernel.
+    if (opath == 4 || opath == 5) {                 // 4 = two 4-wave workgroups per CU (gemm_vit4.hip), 5 = one wave per SIMD (gemm_vit1w.hip)
+        const int rc = opath == 4 ? cfsar_gemm_vit4_launch(a, mode, f16io, c.store, s) : cfsar_gemm_vit1w_launch(a, mode, f16io, c.store, s);
         if (rc != -2) {
-            if (c.out_miw) *c.out_miw = 3;
+            if (c.out_miw) *c.out_miw = opath == 4 ? 3 : 4;
             return rc;
         }
         opath = c.K <= 1024 ? 2 : 0;
     }
-    if (opath == 5) {                               // the one-wave-per-SIMD form (gemm_vit1w.hip)
-        const int rc = cfsar_gemm_vit1w_launch(a, mode, f16io, c.store, s);
-        if (rc != -2) {
-            if (c.out_miw) *c.out_miw = 4;
-            return rc;
-        }
-        opath = c.K <= 1024 ? 2 : 0;
-    }
+#endif
     switch (opath * 4 + c.store) {
         case 0: return launch_path<0, 0>(a, mode, f16io, s);
         case 2: return launch_path<0, 2>(a, mode, f16io, s);
@@ -785,11 +781,16 @@ int g_force_opath = -1, g_force_store = -1, g_force_dbg = 0;
 #endif
 // Operand path by K (same-box A/B at 16 episodes, profiles/r03_gemm_anatomy.md): short K -- QKV, out_proj, c_fc -- takes the LDS-DMA
 // path with the pieces issued right behind the previous step's barrier (2); the long-K c_proj the register-staged path (0).
-int vit_policy_opath(int K) {
+// kind: 0 = LN-folded launch, 1 = residual launch (dev builds: dbg bit 21 / 22 of cfsar_debug_set_vit_dbg keep the product policy for the LN-folded /
+// the residual launches, so a forced form can be A/B'd on one kind of launch alone)
+int vit_policy_opath(int K, int kind = -1) {
 #ifdef CFSAR_DEV
-    if (g_force_opath >= 10) { if (K <= 1024) return g_force_opath - 10; }     // 10 + path: short-K launches only
+    const bool keep = (kind == 0 && (g_force_dbg & (1 << 21))) || (kind == 1 && (g_force_dbg & (1 << 22)));
+    if (keep) { }
+    else if (g_force_opath >= 10) { if (K <= 1024) return g_force_opath - 10; }     // 10 + path: short-K launches only
     else if (g_force_opath >= 0) return g_force_opath;
 #endif
+    (void)kind;
     return K <= 1024 ? 2 : 0;
 }
 int vit_policy_store(int dflt) {
@@ -849,7 +850,7 @@ static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const floa
     c.part = partial; c.part_slots = slots; c.part_eps = eps;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = 0;
     c.out_dtype = out_dtype; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F32; c.act = act; c.relu = 0;
-    c.opath = vit_policy_opath(K); c.store = vit_policy_store(2); c.group = 8; c.colfast = 0; c.dbg = 0;
+    c.opath = vit_policy_opath(K, 0); c.store = vit_policy_store(2); c.group = 8; c.colfast = 0; c.dbg = 0;
     c.hb_tokens = hb_tokens; c.hb_heads = hb_heads; c.ha_tokens = 0;
 #ifdef CFSAR_DEV
     c.dbg = g_force_dbg;
@@ -897,7 +898,7 @@ static int lnfold_partials_impl(const void* x, const void* Wg, void* out, const 
     // The 192-row instances (small M: one or two episodes per call) finalize the statistics themselves; at batch scale the 256-row
     // instances have no registers to spare for it and the finalize launch is 0.4 % of the step: two launches from here.
     const int Kt = wsplit ? 2 * K : K;
-    const bool fused = vit_policy_opath(Kt) == 2 && (slots == 12 || slots == 16) && K >= 512 &&
+    const bool fused = vit_policy_opath(Kt, 0) == 2 && (slots == 12 || slots == 16) && K >= 512 &&
                        vit_pick_miw(M, (N + TN - 1) / TN, 2, 2, vit_policy_store(2), Kt, dbg) == 3;
     if (!fused) {
         if (int rc = cfsar_ln_stats_finalize(partial, rowstats_ws, M, slots, K, eps, stream)) return rc;
@@ -953,7 +954,7 @@ static int gemm_residual_stats_impl(const void* A, const void* W, void* x, const
     c.part = nullptr; c.part_slots = 0; c.part_eps = 0.f;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldx; c.ldr = ldx;
     c.out_dtype = CFSAR_F16; c.in_dtype = in_dtype; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
-    c.opath = vit_policy_opath(K); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;
+    c.opath = vit_policy_opath(K, 1); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;
     c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = ha_tokens;
 #ifdef CFSAR_DEV
     c.dbg = g_force_dbg & ((1 << 17) | (1 << 18));       // tile-height overrides only
@@ -982,7 +983,7 @@ extern "C" int cfsar_gemm_residual_wide(const void* A, const void* W, void* x_hi
     c.part = nullptr; c.part_slots = 0; c.part_eps = 0.f;
     c.M = M; c.N = N; c.K = Kt; c.lda = lda; c.ldw = ldw; c.ldo = ldx; c.ldr = ldx;
     c.out_dtype = CFSAR_F16; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
-    c.opath = vit_policy_opath(Kt); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;
+    c.opath = vit_policy_opath(Kt, 1); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;
     c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = 0;
     c.ka = K; c.wide = 1; c.res_lo = x_lo; c.corr = corr; c.corr_tokens = corr_tokens;
 #ifdef CFSAR_DEV

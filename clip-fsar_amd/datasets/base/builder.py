@@ -47,6 +47,7 @@ def build_dataset(name, cfg, split):
     return cls(cfg, split)
 
 
+_LOGGED_K = set()
 AUTO_EPISODES_PER_STEP_MAX = 16      # the tower's GEMMs run at their batch-scale rate from ~1 000 frames per launch
 
 
@@ -54,8 +55,8 @@ def auto_episodes_per_step(cfg, n_local):
     """Episodes per model call when the config does not say (a reference-shaped config has no TEST.EPISODES_PER_STEP: the reference
     feeds ONE episode per iteration, runs/test_net_few_shot.py:57-64, which leaves 20 % of this tower's throughput on the table).
     The loader collates k episodes -- per-episode results do not depend on k (tests/test_gpu_e2e.py: batch invariance) -- with k
-    bounded by the rank's episode count, by 16, and by half of the free HBM over an upper estimate of one episode's footprint (two
-    upload buffers of fp32 frames + the tower's activation workspace)."""
+    bounded by the rank's episode count, by 16, and by a quarter of the device's TOTAL HBM over an upper estimate of one episode's footprint
+    (two upload buffers of fp32 frames + the tower's activation workspace): deterministic per device and config, logged once."""
     if not (torch.cuda.is_available() and int(getattr(cfg, "NUM_GPUS", 1) or 0) > 0):
         return 1
     arch = synth.ARCHS.get(cfg.VIDEO.HEAD.BACKBONE_NAME, None)
@@ -70,12 +71,21 @@ def auto_episodes_per_step(cfg, n_local):
         per_frame += ntok * arch["width"] * 28          # x (two words), qkv, o, u, patches, statistics: < 28 bytes per token-channel
     else:
         per_frame += 12 << 20                           # RN50: NHWC activations of the widest stage, generously
+    # from the device's TOTAL memory, not from what happens to be free at the call: the choice must be the same on every rank and in every
+    # run (the fp32 tail picks its GEMM kernel by row count: logits are bit-reproducible only at a fixed k)
     try:
-        free = torch.cuda.mem_get_info()[0]
+        total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
     except Exception:
         return 1
-    k = int(0.5 * free // max(1, per_frame * frames))
-    return max(1, min(AUTO_EPISODES_PER_STEP_MAX, k, max(1, int(n_local))))
+    k = int(0.25 * total // max(1, per_frame * frames))
+    k = max(1, min(AUTO_EPISODES_PER_STEP_MAX, k, max(1, int(n_local))))
+    key = (frames, res, k)
+    if key not in _LOGGED_K:
+        _LOGGED_K.add(key)
+        import logging
+        logging.getLogger(__name__).info("TEST.EPISODES_PER_STEP unset: %d episodes per model call (%d frames each, %.0f GB device memory)",
+                                         k, frames, total / 2 ** 30)
+    return k
 
 
 def build_loader(cfg, split):

@@ -97,6 +97,10 @@ def lib():
             if os.environ.get("CFSAR_DEV_VIT_PATHS"):          # "opath,store" (10 + opath: short-K launches only; -1 = policy): bench A/B
                 o, st = (int(v) for v in os.environ["CFSAR_DEV_VIT_PATHS"].split(","))
                 L.cfsar_debug_set_vit_paths(o, st)
+            if os.environ.get("CFSAR_DEV_VIT_DBG"):            # ablation bits of the ViT GEMM launches (bit 21 / 22: forced paths skip the LN-folded / the residual launches)
+                L.cfsar_debug_set_vit_dbg.argtypes = [ctypes.c_int]
+                L.cfsar_debug_set_vit_dbg.restype = None
+                L.cfsar_debug_set_vit_dbg(int(os.environ["CFSAR_DEV_VIT_DBG"], 0))
         _lib = L
     return _lib
 

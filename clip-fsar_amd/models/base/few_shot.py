@@ -175,13 +175,16 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
         if self._engine is None or self._engine_key != key:
             if self.precision == "bf16" and not getattr(self, "_warned_bf16", False):
                 import logging
-                from ... import LOGITS_TOLERANCE, NORTH_STAR_TOLERANCE
+                from ... import LOGITS_TOLERANCE, LOGITS_TOLERANCE_RN50, NORTH_STAR_TOLERANCE
+                rn = self.arch.get("kind") == "rn"
                 logging.getLogger(__name__).warning(
                     "CNN_OTAM_CLIPFSAR (HIP): VIDEO.HEAD.PRECISION = 'bf16' (throughput mode) -- logits deviate from the reference's "
-                    "fp32 path by 3e-3 ... 6e-3 on the BASELINE configurations and up to 2.3e-2 on tiny test architectures, no argmax "
-                    "flips (profiles/r04_parity_table.md; regression bound %g); PRECISION: 'fp16' (0.85 x the bf16 rate; goldens of cfg2 / cfg3 / cfg4 "
-                    "<= 5.8e-4, rms 2-3e-4 over fresh episodes, about one episode in 60 above the tolerance in its largest logit) and 'fp32' "
-                    "(0.1 x, every episode) are the modes built for the %g tolerance" % (LOGITS_TOLERANCE["bf16"], NORTH_STAR_TOLERANCE))
+                    "fp32 path by rms 2.5e-3 / up to 9.4e-3 on the BASELINE ViT configurations (standard and high-contrast episodes alike) "
+                    "and up to 2.3e-2 on tiny test architectures, no argmax flips (profiles/r05_parity_table.md; regression bound %g).  "
+                    "PRECISION 'fp16' (0.85 x the bf16 rate) is a STATISTICAL 1e-3 mode: rms <= 3.5e-4 and 99 %% of the logits within %g, "
+                    "an episode's largest deviation up to 1.1e-3 in about one episode of 13-60 (RN50: rms 8e-4, max 2.5e-3); PRECISION 'fp32' "
+                    "(0.1 x) holds every logit of every episode within %g" % (
+                        (LOGITS_TOLERANCE_RN50 if rn else LOGITS_TOLERANCE)["bf16"], NORTH_STAR_TOLERANCE, NORTH_STAR_TOLERANCE))
                 self._warned_bf16 = True
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             self._engine = ClipFsarEngine(self.arch, sd, self.text_features_train, self.text_features_test,

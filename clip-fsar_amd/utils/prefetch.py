@@ -42,6 +42,14 @@ class DevicePrefetcher:
                 extra = e if e is not None else extra
         host = hosts[0]
         keys = [k for k, v in host.items() if isinstance(v, torch.Tensor)]
+        for j, h in enumerate(hosts[1:], 1):                        # collated items must agree (a mismatch would fail inside copy_ or drop keys silently)
+            hk = [k for k, v in h.items() if isinstance(v, torch.Tensor)]
+            if hk != keys:
+                raise ValueError("DevicePrefetcher: collated item %d has tensor keys %s, item 0 has %s" % (j, hk, keys))
+            for k in keys:
+                if h[k].shape[1:] != host[k].shape[1:] or h[k].dtype != host[k].dtype:
+                    raise ValueError("DevicePrefetcher: collated item %d disagrees on %r: %s %s vs %s %s" % (
+                        j, k, tuple(h[k].shape), h[k].dtype, tuple(host[k].shape), host[k].dtype))
         if keys and all(h[k].is_cuda for h in hosts for k in keys):      # already resident: hand it through / concatenate on the device
             out = dict(host)
             if len(hosts) > 1:
@@ -57,7 +65,14 @@ class DevicePrefetcher:
         buf = self._bufs[i]
         if buf is None or any(k not in buf or buf[k].shape[1:] != host[k].shape[1:] or buf[k].dtype != host[k].dtype or buf[k].shape[0] < rows[k]
                               for k in keys):
+            if buf is not None:
+                # the old (smaller) buffer may still be read by the step in flight and written by a pending copy: keep it alive until the
+                # compute work that used it has finished instead of returning it to the allocator with compute-stream ordering only
+                self._retired = [(b, e) for b, e in getattr(self, "_retired", []) if e is not None and not e.query()]
+                self._retired.append((buf, self._done[i]))
             buf = {k: torch.empty((rows[k],) + tuple(host[k].shape[1:]), dtype=host[k].dtype, device=self.device) for k in keys}
+            for t in buf.values():
+                t.record_stream(self.copy_stream)                    # allocated on the compute stream, written on the copy stream
             self._bufs[i] = buf
             # the caching allocator may hand out a block whose previous owner still has kernels queued on the compute stream: the copy
             # stream must not write it before they ran

@@ -146,3 +146,22 @@ def test_hot_kernels_use_no_scratch():
     for n, u in usage.items():
         if "gemm_kernel_p6" in n or "gemm_kernel_p10" in n or "gemm_kernel_p12" in n:
             assert u.get("scratch", 0) <= 256, (n, u)
+
+
+def test_dev_only_gemm_forms_compile():
+    """csrc/gemm_vit4.hip and csrc/gemm_vit1w.hip (round 5's alternative GEMM forms, profiles/r05_gemm_forms.md) are part of the developer
+    library only; they must keep compiling for gfx950 next to the shared epilogue header, and the product source list must not carry them."""
+    import importlib.util
+    import subprocess
+    import tempfile
+    spec = importlib.util.spec_from_file_location("_cfsar_build_t", os.path.join(ROOT, "clip-fsar_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert set(mod.DEV_ONLY_SOURCES) == {"gemm_vit4.hip", "gemm_vit1w.hip"} and not set(mod.DEV_ONLY_SOURCES) & set(mod.SOURCES)
+    with tempfile.TemporaryDirectory() as td:
+        procs = [subprocess.Popen([mod.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCFSAR_DEV"] + mod.NO_PACKED_FP32 +
+                                  ["-c", os.path.join(mod.CSRC, src), "-o", os.path.join(td, src + ".o")],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for src in mod.DEV_ONLY_SOURCES]
+        for src, p in zip(mod.DEV_ONLY_SOURCES, procs):
+            out, _ = p.communicate()
+            assert p.returncode == 0, (src, out[-2000:])

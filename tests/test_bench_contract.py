@@ -121,7 +121,10 @@ def test_bench_line_bf16_parity_roofline_rccl_ws1():
     assert par["north_star_tolerance"] == 1e-3 and par["meets_north_star"] == (par["max_abs_dlogits"] < 1e-3)
     f16 = out["fp16_mode"]                                  # the 1e-3-conforming 16-bit mode, timed in the same run
     # (round 4: two-word stream + per-frame low-word correction of the weights: ~0.78 x the bf16 rate, 8 x the fp32 mode's)
-    assert f16["parity"]["meets_north_star"] and f16["parity"]["argmax_equal"] and f16["value"] > 0.7 * out["value"], f16
+    # one golden episode: inside the mode's regression bound (its contract is the multi-episode statistic of tests/test_gpu_e2e.py); measured
+    # ratio to the bf16 rate 0.845 (README, head warning): guard at 0.9 x that
+    assert f16["parity"]["within_tolerance"] and f16["parity"]["argmax_equal"] and f16["value"] > 0.76 * out["value"], f16
+    assert 0 < f16["roofline"]["frac"] <= 1, f16
     assert out["collective"]["rccl_world_size"] == 1 and out["collective"]["backend"] == "nccl", out["collective"]
     assert out["per_rank_episodes_per_s"]["ranks"] == 1
     r = out["roofline"]
@@ -143,3 +146,18 @@ def test_bench_line_fp32_meets_north_star_tolerance():
 def test_bench_self_spawn_two_gpus_rccl():
     out = _run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--episodes-per-step", "4"])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["launcher"] == "bench.py self-spawn"
+
+
+@pytest.mark.gpu
+@needs_gpu
+def test_bench_line_carries_cfg3_cfg4_legs():
+    """BASELINE configs[2..3] in front of the driver: the default run's `configs` object holds short cfg3 / cfg4 legs in
+    bf16 and fp16, each with its rate, roofline fractions and golden parity."""
+    out = _run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fp16-leg"])
+    from clip_fsar_amd import LOGITS_TOLERANCE
+    legs = out["configs"]
+    assert sorted(legs) == ["cfg3_bf16", "cfg3_fp16", "cfg4_bf16", "cfg4_fp16"]
+    for name, leg in legs.items():
+        prec = name.split("_")[1]
+        assert leg["value"] > 0 and 0 < leg["roofline"]["frac_end_to_end"] <= leg["roofline"]["frac"] + 0.05, leg
+        assert leg["parity"]["checked"] and leg["parity"]["argmax_equal"] and leg["parity"]["max_abs_dlogits"] < LOGITS_TOLERANCE[prec], leg

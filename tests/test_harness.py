@@ -408,6 +408,30 @@ def test_per_class_tallies_survive_the_prefetchers_buffer_reuse():
 
 @gpu
 @needs_gpu
+def test_prefetcher_collate_rejects_mismatched_items_and_survives_a_growing_batch():
+    """collated items that disagree on their tensor keys, trailing shapes or dtypes raise a ValueError that names the item
+    (not an opaque copy_ failure, not silently dropped keys); a later, larger group re-allocates the device buffer without corrupting the
+    group still in flight."""
+    from clip_fsar_amd.utils.prefetch import DevicePrefetcher
+    dev = torch.device("cuda")
+    item = lambda n, extra=False, wide=False: dict({"x": torch.full((1, 6 if wide else 4), float(n)).pin_memory(), "y": torch.tensor([n])},
+                                                   **({"z": torch.zeros(1)} if extra else {}))
+    with pytest.raises(ValueError, match="item 1 has tensor keys"):
+        list(DevicePrefetcher([item(0), item(1, extra=True)], dev, collate=2))
+    with pytest.raises(ValueError, match="item 1 disagrees on 'x'"):
+        list(DevicePrefetcher([item(0), item(1, wide=True)], dev, collate=2))
+    # groups of 1 item, then 3 items per buffer slot: the second use of each slot needs a larger buffer
+    class _L:
+        def __init__(self, items): self.items = items
+        def __len__(self): return len(self.items)
+        def __iter__(self): return iter(self.items)
+    groups = [{"x": torch.full((n, 4), float(i)).pin_memory()} for i, n in enumerate([1, 1, 3, 3, 2])]
+    seen = [(int(b["x"].shape[0]), float(b["x"].mean())) for b in DevicePrefetcher(_L(groups), dev)]
+    assert seen == [(1, 0.0), (1, 1.0), (3, 2.0), (3, 3.0), (2, 4.0)], seen
+
+
+@gpu
+@needs_gpu
 def test_reference_shaped_cfg_reaches_the_batched_rate():
     """a reference-shaped config (no TEST.EPISODES_PER_STEP) over a loader that yields ONE episode per item -- what the
     reference's own harness feeds (runs/test_net_few_shot.py:57-64) -- must deliver the batched rate: test_epoch collates k items per

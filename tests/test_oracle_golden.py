@@ -102,3 +102,29 @@ def test_head_full_size(name):
     if not os.path.exists(os.path.join(GOLD, "head_%s.npz" % name)):
         pytest.skip("fixture not generated")
     _run_case(name, atol_feat=5e-4, atol_logit=2e-4)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name,episode", [("mc_cfg2_B16_5w1s_T8", 5), ("hc_cfg2_B16_5w1s_T8", 9)])
+def test_oracle_matches_the_multi_episode_reference_goldens(name, episode):
+    """The multi-episode goldens (oracle/make_golden.py --multi: 13 episodes per configuration run through the REFERENCE, standard and high
+    contrast) pin the oracle too: one episode of each cfg2 set, logits and class logits."""
+    path = os.path.join(GOLD, "multi_%s.npz" % name)
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    z = np.load(path)
+    m = json.loads(str(z["meta"]))
+    a = synth.ARCHS[m["arch"]]
+    sd = {k: _t(v) for k, v in synth.head_state_dict(m["arch"], seed=m["seed"]).items()}
+    tt = _t(synth.text_features(m["n_train"], a["embed"], "train", m["seed"]))
+    te = _t(synth.text_features(m["n_test"], a["embed"], "test", m["seed"]))
+    ep = {k: _t(v) for k, v in synth.make_episode(way=m["way"], shot=m["shot"], query_per_class=m["q"], frames=m["T"], res=a["res"],
+                                                  n_test_classes=m["n_test"], episode=episode, seed=m["seed"],
+                                                  lowfreq=m.get("lowfreq", 0.0)).items()}
+    with torch.no_grad():
+        out = orc.head_forward(ep, sd, tt, te, a, frames=m["T"], merge_before=m.get("merge_before", False))
+    assert torch.allclose(out["logits"], _t(z["logits"][episode]), atol=2e-4), float((out["logits"] - _t(z["logits"][episode])).abs().max())
+    assert torch.allclose(out["class_logits"], _t(z["class_logits"][episode]), atol=2e-4)
+    lg = z["logits"]
+    spread = float(np.mean(lg.max((1, 2)) - lg.min((1, 2))))
+    assert (spread > 2.5) == name.startswith("hc_"), spread          # the high-contrast set really is one

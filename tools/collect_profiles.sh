@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 EPS=${EPS:-16}
-CMD="python bench.py --steps 4 --warmup 2 --episodes-per-step $EPS --no-cpu-baseline --no-kernel-events --no-fp16-leg ${CMD_EXTRA:-}"
+CMD="python bench.py --steps 4 --warmup 2 --episodes-per-step $EPS --no-cpu-baseline --no-kernel-events --no-fp16-leg --no-config-legs ${CMD_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 python tools/trace_summary.py $OUT/trace/t_kernel_trace.csv 0 > $OUT/kernel_summary.txt
 cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
@@ -46,7 +46,7 @@ for k in f:
         tot += fb + wb; n += len(fv)
 import hashlib, socket
 h = hashlib.sha256()
-for nm in ("common.h", "gemm.hip", "gemm_vit.h", "gemm_vit.hip"):          # bench.py::csrc_fingerprint
+for nm in ("common.h", "gemm.hip", "gemm_vit.h", "gemm_vit_epi.h", "gemm_vit.hip"):          # bench.py::csrc_fingerprint
     h.update(open(os.path.join("clip-fsar_amd", "csrc", nm), "rb").read())
 traffic["_all_bf16_gemm"] = {"launches": n, "hbm_bytes_per_launch": tot / max(n, 1),
                              "csrc_sha16": h.hexdigest()[:16], "commit": os.environ.get("COMMIT", "unknown (no .git on the GPU box)"),
