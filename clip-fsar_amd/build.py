@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libclipfsar_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_vit.hip", "rowops.hip", "attention.hip", "tail.hip", "conv.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_vit.hip", "frame_gemm.hip", "rowops.hip", "attention.hip", "tail.hip", "conv.hip"]
 # developer library only: the two alternative GEMM forms measured in round 5 (profiles/r05_gemm_forms.md); the product library does not carry them
 DEV_ONLY_SOURCES = ["gemm_vit4.hip", "gemm_vit1w.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -781,8 +781,8 @@ int g_force_opath = -1, g_force_store = -1, g_force_dbg = 0;
 #endif
 // Operand path by K (same-box A/B at 16 episodes, profiles/r03_gemm_anatomy.md): short K -- QKV, out_proj, c_fc -- takes the LDS-DMA
 // path with the pieces issued right behind the previous step's barrier (2); the long-K c_proj the register-staged path (0).
-// kind: 0 = LN-folded launch, 1 = residual launch (dev builds: dbg bit 21 / 22 of cfsar_debug_set_vit_dbg keep the product policy for the LN-folded /
-// the residual launches, so a forced form can be A/B'd on one kind of launch alone)
+// kind: 0 = LN-folded launch, 1 = residual launch (developer builds: ablation bits 21 / 22 keep the product policy for the LN-folded / the residual
+// launches, so a forced form can be A/B'd on one kind of launch alone)
 int vit_policy_opath(int K, int kind = -1) {
 #ifdef CFSAR_DEV
     const bool keep = (kind == 0 && (g_force_dbg & (1 << 21))) || (kind == 1 && (g_force_dbg & (1 << 22)));

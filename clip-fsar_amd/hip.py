@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (imported first so that torch's libamdhip64.so.7 is the HIP runtime the library binds to)
 
 F32, BF16, F16 = 0, 1, 2
-ABI_VERSION = 6          # CFSAR_ABI_VERSION of include/clipfsar_hip.h this file's SIGNATURES were written against
+ABI_VERSION = 7          # CFSAR_ABI_VERSION of include/clipfsar_hip.h this file's SIGNATURES were written against
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -58,6 +58,7 @@ SIGNATURES = {
     "cfsar_vit_attention": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_vit_attention_means": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_vit_attention_cls": [_c_p, _c_i64, _c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_frame_gemm": [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_class_text_logits": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_build_sequences": [_c_p, _c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p],
     "cfsar_seq_attention": [_c_p, _c_p] + [_c_int] * 6 + [_c_f, _c_int, _c_p],
@@ -220,16 +221,29 @@ def gemm(A, W, out, bias=None, residual=None, act=ACT_NONE, M=None, N=None, K=No
 _gemm_unwrapped = gemm
 
 
+def _frame_gemm_ok(K, N):
+    """cfsar_frame_gemm's shape contract; a tower whose widths miss it takes cfsar_gemm for EVERY call (the choice depends on the architecture
+    alone, never on the batch: an episode's bits do not depend on the batch it is served in)."""
+    return K % 128 == 0 and N % 16 == 0
+
+
 def mean_update_gemm(meanA, w, bias, xbar):
     """xbar [frames, N] bf16 += meanA [frames, K] bf16 @ w [N, K]^T bf16 + bias: the per-frame mean of the residual stream follows the stream's
-    update x += A W^T + b (linear in the frame's token mean).  Unwrapped like corr_gemm."""
-    _gemm_unwrapped(meanA, w, xbar, bias=bias, residual=xbar)
+    update x += A W^T + b (linear in the frame's token mean).  cfsar_frame_gemm (bf16 form, in place)."""
+    if not _frame_gemm_ok(w.shape[1], w.shape[0]):
+        return _gemm_unwrapped(meanA, w, xbar, bias=bias, residual=xbar)
+    _check(lib().cfsar_frame_gemm(_dev(meanA, torch.bfloat16, "meanA"), _dev(w, torch.bfloat16, "w"), _dev(xbar, torch.bfloat16, "xbar"),
+                                  _dev(bias, torch.float32, "bias"), _dev(xbar, torch.bfloat16, "xbar"), meanA.shape[0], w.shape[0], w.shape[1],
+                                  BF16, _stream()), "cfsar_frame_gemm")
 
 
 def corr_gemm(meanA, w_lo, out):
-    """out [frames, N] fp32 = meanA [frames, K] bf16 @ w_lo [N, K]^T bf16: the per-frame low-word correction's small GEMM (cfsar_gemm).  A name
-    of its own so that bench.py's per-launch timer, which wraps `gemm`, does not count it among the path's algorithmic GEMM launches."""
-    _gemm_unwrapped(meanA, w_lo, out)
+    """out [frames, N] fp32 = meanA [frames, K] bf16 @ w_lo [N, K]^T bf16: the per-frame low-word correction's small GEMM (cfsar_frame_gemm, fp32
+    form).  Not among the path's algorithmic GEMM launches that bench.py's per-launch timer counts."""
+    if not _frame_gemm_ok(w_lo.shape[1], w_lo.shape[0]):
+        return _gemm_unwrapped(meanA, w_lo, out)
+    _check(lib().cfsar_frame_gemm(_dev(meanA, torch.bfloat16, "meanA"), _dev(w_lo, torch.bfloat16, "w_lo"), _dev(out, torch.float32, "out"),
+                                  None, None, meanA.shape[0], w_lo.shape[0], w_lo.shape[1], F32, _stream()), "cfsar_frame_gemm")
 
 
 def gemm_lnfold(x, Wg, out, cvec, dvec, rowstats, act=ACT_NONE, M=None):

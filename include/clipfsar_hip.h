@@ -46,7 +46,7 @@ typedef void* cfsar_stream_t;
 int cfsar_version(void);
 /* ABI revision: bumped whenever an exported signature changes or is added; a binding compares it with the CFSAR_ABI_VERSION it was
  * written against at load time (clip-fsar_amd/hip.py does) instead of calling through a stale prototype. */
-#define CFSAR_ABI_VERSION 6
+#define CFSAR_ABI_VERSION 7
 int cfsar_abi_version(void);
 const char* cfsar_last_error(void);
 
@@ -295,6 +295,14 @@ int cfsar_vit_attention_means(const void* qkv, void* out, void* omean, int F, in
  * [frames tokens, 4] (the token mean of LayerNorm(x) before its affine, few_shot.py:605-611) or (0, 1) when rowstats == NULL.
  * A [frames tokens, lda] fp16, out [frames, K] bf16. */
 int cfsar_frame_col_means(const void* A, int lda, const float* rowstats, void* out, int frames, int tokens, int K, cfsar_stream_t stream);
+/* Round 5: the per-frame GEMMs of the fp16 numerics mode -- out[f][n] = sum_k A[f][k] W[n][k] (+ bias[n]) (+ res[f][n]) with A [M, K] bf16 the
+ * per-frame token means of a block GEMM's operand (cfsar_frame_col_means, cfsar_vit_attention_means, cfsar_gemm_lnfold_hp's colmean_out), W [N, K]
+ * bf16 in nn.Linear layout.  out_dtype CFSAR_F32: the low-word correction corr [M, N] fp32 that cfsar_gemm_lnfold_hp / cfsar_gemm_residual_wide
+ * add to every row of a frame (W = the weights' second word; bias, res NULL).  out_dtype CFSAR_BF16: out bf16 = A W^T + bias + res, res [M, N] bf16
+ * or NULL and allowed to alias out: the residual stream's per-frame mean following the update x += A W^T + b of few_shot.py:637-640.
+ * K % 128 == 0, N % 16 == 0.  A row's result does not depend on M (fixed K-summation order): batch-size invariance of the mode. */
+int cfsar_frame_gemm(const void* A, const void* W, void* out, const float* bias, const void* res, int M, int N, int K, int out_dtype,
+                     cfsar_stream_t stream);
 /* out[i] = (float)hi[i] + (float)lo[i], i < n (the two-word stream -> fp32, e.g. in front of ln_post, few_shot.py:683). */
 int cfsar_f16_pair_to_f32(const void* hi, const void* lo, float* out, int64_t n, cfsar_stream_t stream);
 /* dst[r][0 .. row_bytes) = src[r][0 .. row_bytes), rows at byte strides src_stride / dst_stride (row_bytes % 4 == 0): the

@@ -1177,3 +1177,28 @@ def test_vit_attention_means(hip, F_, ntok, H):
     assert not torch.isnan(om.float()).any()
     # bf16 output + the means are taken of the unrounded fp32 rows (fp16 rounding noise of the stored rows averages out)
     assert maxdiff(om.float(), ref) < 2.0 ** -8 * max(0.05, float(ref.abs().max())) + 2e-4, maxdiff(om.float(), ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 768, 768), (80, 768, 768), (81, 2304, 768), (200, 768, 3072), (1280, 3072, 768), (1283, 1024, 4096)])
+def test_frame_gemm_matches_fp32_and_is_row_invariant(hip, M, N, K):
+    """cfsar_frame_gemm (the fp16 numerics mode's per-frame GEMMs, round 5): fp32 form == the fp32 product of the bf16 operands; bf16 form ==
+    bf16(A W^T + bias + res) in place; and a row's bits do not depend on how many rows the call carries (batch-size invariance of the mode)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = A.float() @ W.float().t()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    hip.corr_gemm(A, W, out)
+    assert float((out - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())) + 1e-5
+    xb = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    want = (ref + bias + xb.float()).to(torch.bfloat16)
+    got = xb.clone()
+    hip.mean_update_gemm(A, W, bias, got)
+    assert float((got.float() - want.float()).abs().max()) <= 2.0 ** -7 * max(1.0, float(want.float().abs().max()))     # one bf16 ulp of the largest value
+    assert (got != want).float().mean() < 0.02                                                 # (a different fp32 summation order flips a rounding now and then)
+    # rows 0 .. m-1 alone give the same bits
+    for m in {1, min(M, 17), min(M, 80)}:
+        o2 = torch.full((m, N), float("nan"), device="cuda")
+        hip.corr_gemm(A[:m].contiguous(), W, o2)
+        assert torch.equal(o2, out[:m]), m
