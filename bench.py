@@ -229,7 +229,7 @@ def golden_parity(logits0, precision, config="cfg2"):
                          "fp16": "statistic, not a bound: rms <= 3.5e-4 and p99 <= 1e-3 of |dlogits| over 65 reference logit rows per configuration, standard "
                                  "and high-contrast episodes (measured rms 2.6-3.0e-4, p99 6.0-7.0e-4); an episode's largest deviation exceeds 1e-3 in about one "
                                  "episode of 13-60 (max seen 1.14e-3)",
-                         "bf16": "throughput mode, NOT inside 1e-3: rms 2.3-2.5e-3, max 9.4e-3 over 65 rows per configuration"}[precision],
+                         "bf16": "throughput mode, NOT inside 1e-3: rms 2.3-3.9e-3, max 1.0e-2 over 65 rows per configuration"}[precision],
             "tolerance_note": "this mode's own regression bound on the full-size configurations (profiles/r05_parity_table.md, "
                               "tests/test_gpu_e2e.py::test_modes_against_multi_episode_reference_goldens); the north-star bound is 1e-3"}
 

@@ -12,16 +12,16 @@ __version__ = "0.5.0"
 # per configuration at the generator's standard contrast (logits spread ~1) AND at high contrast (spread 3-4.5, as trained CLIP features give):
 # profiles/r05_parity_table.md, tests/test_gpu_e2e.py::test_modes_against_multi_episode_reference_goldens:
 #   fp32 -- a HARD per-episode bound: every logit of every episode within NORTH_STAR_TOLERANCE (measured <= 7.6e-6);
-#   fp16 -- a STATISTIC, not a bound: rms <= 3.5e-4 and 99th percentile <= 1e-3 of |dlogits| over >= 64 logit rows per configuration
-#           (measured rms 2.6-3.0e-4, p99 6.0-7.0e-4, the same at spread 0.9 and 3.1: the deviation does not grow with the contrast).  An
+#   fp16 -- a STATISTIC, not a bound: rms <= 4e-4 and 99th percentile <= 1e-3 of |dlogits| over >= 64 logit rows per configuration
+#           (measured rms 1.9-3.4e-4, p99 4.5-8.8e-4; ViT-B/16: the same at spread 0.9 and 3.1; ViT-L/14 at spread 4.4 is the upper end).  An
 #           episode's LARGEST deviation exceeds 1e-3 in about 1 episode of 13-60 (max seen 1.14e-3): LOGITS_TOLERANCE["fp16"] is that tail's
 #           regression bound, 1.5e-3.  A caller that needs every episode inside 1e-3 uses "fp32";
-#   bf16 -- the throughput mode: rms 2.3-2.5e-3, max 9.4e-3 over the same episodes, no argmax flip; regression bound 1.5e-2.  NOT inside the
-#           north star.
+#   bf16 -- the throughput mode: rms 2.3-3.9e-3, p99 6.5-8.5e-3, max 1.0e-2 over the same episodes; 1 argmax flip in 325 rows (a near-tie of
+#           ViT-L/14 at standard contrast); regression bounds rms 5e-3, p99 1.2e-2, max 1.5e-2.  NOT inside the north star.
 # One constant per mode for the head's warning, bench.py's `parity` object and the tests (per-case bounds of the small cases: tests/_cases.py).
 NORTH_STAR_TOLERANCE = 1e-3
 LOGITS_TOLERANCE = {"fp32": 1e-3, "fp16": 1.5e-3, "bf16": 1.5e-2}
-LOGITS_STATISTIC = {"fp16": {"rms": 3.5e-4, "p99": 1e-3}, "bf16": {"rms": 4e-3, "p99": 1.2e-2}}
+LOGITS_STATISTIC = {"fp16": {"rms": 4e-4, "p99": 1e-3}, "bf16": {"rms": 5e-3, "p99": 1.2e-2}}
 # CLIP RN50 tower (N3): three equal error sources and no coherent term to remove (profiles/r04_rn50_fp16.md) -- fp16 mode rms 8e-4 / max 2.5e-3,
 # bf16 6e-3 / 1.7e-2 on high-contrast 8-frame episodes; bounds = 2 x measured.  "fp32" is RN50's mode for the 1e-3 contract.
 LOGITS_TOLERANCE_RN50 = {"fp32": 1e-3, "fp16": 5e-3, "bf16": 3.5e-2}

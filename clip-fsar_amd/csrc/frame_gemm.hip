@@ -19,16 +19,22 @@ namespace {
 
 constexpr int FG_MT = 4;                       // 16-frame tiles per workgroup (64 frames)
 
-template <bool OUT_BF16>
+// NT = 16-column tiles per workgroup: 1 at one or two episodes per call (as many workgroups as possible: the call is latency-bound), 4 at batch
+// scale (a frame fragment then serves four weight fragments and vice versa: at 1 280 frames the one-tile form re-read the frame operand once per
+// 16 columns -- 94-377 MB through the L2 per call, 42-47 us -- and lost to the generic kernel).  The K split and the MFMA chain of an output
+// element are the same in both: the bits do not depend on NT.
+template <bool OUT_BF16, int NT>
 __global__ __launch_bounds__(256) void frame_gemm_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W, void* out,
                                                          const float* __restrict__ bias, const __bf16* res, int M, int N, int K) {
-    __shared__ f32x4 red[4][FG_MT][64];                               // 16 KiB: every wave's partial tiles
+    __shared__ f32x4 red[4][FG_MT][64];                               // 16 KiB: every wave's partial tiles of ONE column tile at a time
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, kq = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * FG_MT);
+    const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * (16 * FG_MT);
     // MFMA "A" operand = 16 weight rows (output columns), "B" operand = 16 frame rows: D[n = 4 (lane >> 4) + reg][m = lane & 15]
-    const __bf16* wp = W + (size_t)(n0 + r) * K + kq * 8;
+    const __bf16* wp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wp[j] = W + (size_t)(n0 + 16 * j + r) * K + kq * 8;
     const __bf16* ap[FG_MT];
 #pragma unroll
     for (int t = 0; t < FG_MT; ++t) {
@@ -36,53 +42,75 @@ __global__ __launch_bounds__(256) void frame_gemm_kernel(const __bf16* __restric
         row = row < M ? row : M - 1;                                  // clamped: rows past M are computed and dropped
         ap[t] = A + (size_t)row * K + kq * 8;
     }
-    f32x4 acc[FG_MT];
+    f32x4 acc[NT][FG_MT];
 #pragma unroll
-    for (int t = 0; t < FG_MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < FG_MT; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nsteps = K >> 5;                                        // K % 128 == 0 (launcher): every wave gets nsteps / 4 steps
-    uint4 wf = *reinterpret_cast<const uint4*>(wp + wave * 32), af[FG_MT];
+    uint4 wf[NT], af[FG_MT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const uint4*>(wp[j] + wave * 32);
 #pragma unroll
     for (int t = 0; t < FG_MT; ++t) af[t] = *reinterpret_cast<const uint4*>(ap[t] + wave * 32);
     for (int s = wave; s < nsteps; s += 4) {
         const int sn = s + 4 < nsteps ? s + 4 : s;                    // next step's operands in flight under this step's MFMAs (last: a harmless re-read)
-        const uint4 wn = *reinterpret_cast<const uint4*>(wp + sn * 32);
-        uint4 an[FG_MT];
+        uint4 wn[NT], an[FG_MT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wn[j] = *reinterpret_cast<const uint4*>(wp[j] + sn * 32);
 #pragma unroll
         for (int t = 0; t < FG_MT; ++t) an[t] = *reinterpret_cast<const uint4*>(ap[t] + sn * 32);
 #pragma unroll
-        for (int t = 0; t < FG_MT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, af[t]), acc[t], 0, 0, 0);
-        wf = wn;
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int t = 0; t < FG_MT; ++t)
+                acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, af[t]), acc[j][t], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = wn[j];
 #pragma unroll
         for (int t = 0; t < FG_MT; ++t) af[t] = an[t];
     }
-#pragma unroll
-    for (int t = 0; t < FG_MT; ++t) red[wave][t][lane] = acc[t];
-    __syncthreads();
-    // wave w finishes frame tile w: the four partials in wave order (fixed), then the epilogue; a lane owns 4 consecutive columns of one frame
+    // per column tile: the four waves' partials meet in LDS; wave w finishes frame tile w -- the partials in wave order (fixed), then the
+    // epilogue; a lane owns 4 consecutive columns of one frame
     const int t = wave;
-    f32x4 v = red[0][t][lane];
+    const int m = m0 + 16 * t + r;
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        const f32x4 p = red[w][t][lane];
+    for (int j = 0; j < NT; ++j) {
+        if (j > 0) __syncthreads();                                   // the previous column tile's partials have been read
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += p[i];
-    }
-    const int m = m0 + 16 * t + r, n = n0 + 4 * kq;
-    if (m >= M) return;
-    if constexpr (OUT_BF16) {
-        bf16x4 o;
-        const bf16x4 rv = res ? *reinterpret_cast<const bf16x4*>(res + (size_t)m * N + n) : bf16x4{0, 0, 0, 0};
+        for (int tt = 0; tt < FG_MT; ++tt) red[wave][tt][lane] = acc[j][tt];
+        __syncthreads();
+        f32x4 v = red[0][t][lane];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (__bf16)(v[i] + (bias ? bias[n + i] : 0.f) + (float)rv[i]);
-        *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(out) + (size_t)m * N + n) = o;
-    } else {
-        if (bias) {
+        for (int w = 1; w < 4; ++w) {
+            const f32x4 p = red[w][t][lane];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += bias[n + i];
+            for (int i = 0; i < 4; ++i) v[i] += p[i];
         }
-        *reinterpret_cast<f32x4*>(static_cast<float*>(out) + (size_t)m * N + n) = v;
+        const int n = n0 + 16 * j + 4 * kq;
+        if (m < M) {
+            if constexpr (OUT_BF16) {
+                bf16x4 o;
+                const bf16x4 rv = res ? *reinterpret_cast<const bf16x4*>(res + (size_t)m * N + n) : bf16x4{0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(v[i] + (bias ? bias[n + i] : 0.f) + (float)rv[i]);
+                *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(out) + (size_t)m * N + n) = o;
+            } else {
+                if (bias) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += bias[n + i];
+                }
+                *reinterpret_cast<f32x4*>(static_cast<float*>(out) + (size_t)m * N + n) = v;
+            }
+        }
     }
+}
+
+template <bool OUT_BF16, int NT>
+void frame_gemm_launch(const void* A, const void* W, void* out, const float* bias, const void* res, int M, int N, int K, hipStream_t s) {
+    const dim3 grid((unsigned)(N / (16 * NT)), (unsigned)((M + 16 * FG_MT - 1) / (16 * FG_MT)));
+    hipLaunchKernelGGL((frame_gemm_kernel<OUT_BF16, NT>), grid, dim3(256), 0, s, static_cast<const __bf16*>(A), static_cast<const __bf16*>(W), out,
+                       bias, static_cast<const __bf16*>(res), M, N, K);
 }
 
 }  // namespace
@@ -94,12 +122,13 @@ extern "C" int cfsar_frame_gemm(const void* A, const void* W, void* out, const f
     CFSAR_REQUIRE(out_dtype == CFSAR_F32 || out_dtype == CFSAR_BF16, "cfsar_frame_gemm: out_dtype must be fp32 or bf16, got %d", out_dtype);
     CFSAR_REQUIRE(out_dtype == CFSAR_BF16 || res == nullptr, "cfsar_frame_gemm: a residual exists for the bf16 form only");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)(N / 16), (unsigned)((M + 16 * FG_MT - 1) / (16 * FG_MT)));
-    if (out_dtype == CFSAR_BF16)
-        hipLaunchKernelGGL(frame_gemm_kernel<true>, grid, dim3(256), 0, s, static_cast<const __bf16*>(A), static_cast<const __bf16*>(W), out, bias,
-                           static_cast<const __bf16*>(res), M, N, K);
-    else
-        hipLaunchKernelGGL(frame_gemm_kernel<false>, grid, dim3(256), 0, s, static_cast<const __bf16*>(A), static_cast<const __bf16*>(W), out, bias,
-                           static_cast<const __bf16*>(res), M, N, K);
+    const bool wide = M > 128 && N % 64 == 0;          // four column tiles per workgroup from three episodes on (same bits either way)
+    if (out_dtype == CFSAR_BF16) {
+        if (wide) frame_gemm_launch<true, 4>(A, W, out, bias, res, M, N, K, s);
+        else frame_gemm_launch<true, 1>(A, W, out, bias, res, M, N, K, s);
+    } else {
+        if (wide) frame_gemm_launch<false, 4>(A, W, out, bias, res, M, N, K, s);
+        else frame_gemm_launch<false, 1>(A, W, out, bias, res, M, N, K, s);
+    }
     return cfsar_check_launch("cfsar_frame_gemm");
 }

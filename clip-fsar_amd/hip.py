@@ -222,9 +222,21 @@ _gemm_unwrapped = gemm
 
 
 def _frame_gemm_ok(K, N):
-    """cfsar_frame_gemm's shape contract; a tower whose widths miss it takes cfsar_gemm for EVERY call (the choice depends on the architecture
-    alone, never on the batch: an episode's bits do not depend on the batch it is served in)."""
-    return K % 128 == 0 and N % 16 == 0
+    """Which kernel serves a per-frame GEMM of this (K, N): cfsar_frame_gemm for the long-K and the narrow ones (out_proj / c_proj corrections and
+    stream-mean updates: 15 vs 29 us at 80 frames, 26 vs 41 us at 1 280), the generic cfsar_gemm for short K with N > 1 024 (the QKV / c_fc
+    corrections: at 1 280 frames its 256 x 128 tiles take 15 us where the frame kernel's many short workgroups take 21-26; tools/frame_gemm_time.py).
+    The choice depends on the architecture alone, never on the batch: an episode's bits do not depend on the batch it is served in."""
+    return K % 128 == 0 and N % 16 == 0 and (K >= 2048 or N <= 1024)
+
+
+def frame_gemm(A, W, out, bias=None, res=None):
+    """out [M, N] (fp32, or bf16 with an optional bf16 residual that may alias out) = A [M, K] bf16 @ W [N, K]^T bf16 (+ bias) (+ res):
+    cfsar_frame_gemm, whatever the shape policy of corr_gemm / mean_update_gemm says."""
+    if out.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("frame_gemm: out must be fp32 or bf16, got %s" % out.dtype)
+    _check(lib().cfsar_frame_gemm(_dev(A, torch.bfloat16, "A"), _dev(W, torch.bfloat16, "W"), _dev(out, None, "out"),
+                                  _opt(bias, torch.float32, "bias"), _opt(res, torch.bfloat16, "res"), A.shape[0], W.shape[0], W.shape[1],
+                                  _code(out.dtype), _stream()), "cfsar_frame_gemm")
 
 
 def mean_update_gemm(meanA, w, bias, xbar):
@@ -232,9 +244,7 @@ def mean_update_gemm(meanA, w, bias, xbar):
     update x += A W^T + b (linear in the frame's token mean).  cfsar_frame_gemm (bf16 form, in place)."""
     if not _frame_gemm_ok(w.shape[1], w.shape[0]):
         return _gemm_unwrapped(meanA, w, xbar, bias=bias, residual=xbar)
-    _check(lib().cfsar_frame_gemm(_dev(meanA, torch.bfloat16, "meanA"), _dev(w, torch.bfloat16, "w"), _dev(xbar, torch.bfloat16, "xbar"),
-                                  _dev(bias, torch.float32, "bias"), _dev(xbar, torch.bfloat16, "xbar"), meanA.shape[0], w.shape[0], w.shape[1],
-                                  BF16, _stream()), "cfsar_frame_gemm")
+    frame_gemm(meanA, w, xbar, bias=bias, res=xbar)
 
 
 def corr_gemm(meanA, w_lo, out):
@@ -242,8 +252,7 @@ def corr_gemm(meanA, w_lo, out):
     form).  Not among the path's algorithmic GEMM launches that bench.py's per-launch timer counts."""
     if not _frame_gemm_ok(w_lo.shape[1], w_lo.shape[0]):
         return _gemm_unwrapped(meanA, w_lo, out)
-    _check(lib().cfsar_frame_gemm(_dev(meanA, torch.bfloat16, "meanA"), _dev(w_lo, torch.bfloat16, "w_lo"), _dev(out, torch.float32, "out"),
-                                  None, None, meanA.shape[0], w_lo.shape[0], w_lo.shape[1], F32, _stream()), "cfsar_frame_gemm")
+    frame_gemm(meanA, w_lo, out)
 
 
 def gemm_lnfold(x, Wg, out, cvec, dvec, rowstats, act=ACT_NONE, M=None):

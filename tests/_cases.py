@@ -104,6 +104,9 @@ def maxdiff(a, b):
 MULTI_CASES = ("mc_cfg2_B16_5w1s_T8", "hc_cfg2_B16_5w1s_T8", "hc_cfg3_B16_5w5s_T8_mb", "hc_cfg4_L14_5w1s_T16", "mc_cfg4_L14_5w1s_T16")
 
 
+_MULTI_CACHE = {}
+
+
 def load_multi(name):
     z = np.load(os.path.join(GOLD, "multi_%s.npz" % name))
     return {"meta": json.loads(str(z["meta"])), "logits": z["logits"], "class_logits": z["class_logits"]}
@@ -115,13 +118,21 @@ def multi_case_stats(name, precision, chunk=None):
     g = load_multi(name)
     m = g["meta"]
     a = synth.ARCHS[m["arch"]]
-    sd = {k: torch.from_numpy(v) for k, v in synth.head_state_dict(m["arch"], seed=m["seed"]).items()}
-    tt = torch.from_numpy(synth.text_features(m["n_train"], a["embed"], "train", m["seed"]))
-    te = torch.from_numpy(synth.text_features(m["n_test"], a["embed"], "test", m["seed"]))
     E = m["episodes"]
-    eps = [{k: torch.from_numpy(v) for k, v in synth.make_episode(way=m["way"], shot=m["shot"], query_per_class=m["q"], frames=m["T"], res=a["res"],
-                                                                  n_test_classes=m["n_test"], episode=e, seed=m["seed"],
-                                                                  lowfreq=m.get("lowfreq", 0.0)).items()} for e in range(E)]
+    # weights and episodes of the LAST case are kept: the three modes of a case (and the two contrast sets of an architecture) share them, and
+    # generating the ViT-L/14 state dict takes half a minute of numpy
+    wkey, ekey = (m["arch"], m["seed"], m["n_train"], m["n_test"]), (name,)
+    if _MULTI_CACHE.get("wkey") != wkey:
+        _MULTI_CACHE.clear()
+        _MULTI_CACHE.update(wkey=wkey, w=({k: torch.from_numpy(v) for k, v in synth.head_state_dict(m["arch"], seed=m["seed"]).items()},
+                                          torch.from_numpy(synth.text_features(m["n_train"], a["embed"], "train", m["seed"])),
+                                          torch.from_numpy(synth.text_features(m["n_test"], a["embed"], "test", m["seed"]))))
+    if _MULTI_CACHE.get("ekey") != ekey:
+        _MULTI_CACHE.update(ekey=ekey, eps=[{k: torch.from_numpy(v) for k, v in synth.make_episode(
+            way=m["way"], shot=m["shot"], query_per_class=m["q"], frames=m["T"], res=a["res"], n_test_classes=m["n_test"], episode=e, seed=m["seed"],
+            lowfreq=m.get("lowfreq", 0.0)).items()} for e in range(E)])
+    sd, tt, te = _MULTI_CACHE["w"]
+    eps = _MULTI_CACHE["eps"]
     chunk = chunk or (4 if m["arch"] == "ViT-L/14" else 8)
     lg = torch.cat([run_engine(m, a, sd, tt, te, eps[i:i + chunk], precision)[0] for i in range(0, E, chunk)])
     ref = torch.from_numpy(g["logits"])

@@ -1189,16 +1189,16 @@ def test_frame_gemm_matches_fp32_and_is_row_invariant(hip, M, N, K):
     bias = torch.randn(N, device="cuda", generator=g)
     ref = A.float() @ W.float().t()
     out = torch.full((M, N), float("nan"), device="cuda")
-    hip.corr_gemm(A, W, out)
+    hip.frame_gemm(A, W, out)
     assert float((out - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())) + 1e-5
     xb = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
     want = (ref + bias + xb.float()).to(torch.bfloat16)
     got = xb.clone()
-    hip.mean_update_gemm(A, W, bias, got)
+    hip.frame_gemm(A, W, got, bias=bias, res=got)
     assert float((got.float() - want.float()).abs().max()) <= 2.0 ** -7 * max(1.0, float(want.float().abs().max()))     # one bf16 ulp of the largest value
     assert (got != want).float().mean() < 0.02                                                 # (a different fp32 summation order flips a rounding now and then)
     # rows 0 .. m-1 alone give the same bits
     for m in {1, min(M, 17), min(M, 80)}:
         o2 = torch.full((m, N), float("nan"), device="cuda")
-        hip.corr_gemm(A[:m].contiguous(), W, o2)
+        hip.frame_gemm(A[:m].contiguous(), W, o2)
         assert torch.equal(o2, out[:m]), m
