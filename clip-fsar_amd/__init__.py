@@ -13,7 +13,7 @@ __version__ = "0.5.0"
 # profiles/r05_parity_table.md, tests/test_gpu_e2e.py::test_modes_against_multi_episode_reference_goldens:
 #   fp32 -- a HARD per-episode bound: every logit of every episode within NORTH_STAR_TOLERANCE (measured <= 7.6e-6);
 #   fp16 -- a STATISTIC, not a bound: rms <= 4e-4 and 99th percentile <= 1e-3 of |dlogits| over >= 64 logit rows per configuration
-#           (measured rms 1.9-3.4e-4, p99 4.5-8.8e-4; ViT-B/16: the same at spread 0.9 and 3.1; ViT-L/14 at spread 4.4 is the upper end).  An
+#           (measured rms 1.9-3.5e-4, p99 4.6-9.0e-4; ViT-B/16: the same at spread 0.9 and 3.1; ViT-L/14 at spread 4.4 is the upper end).  An
 #           episode's LARGEST deviation exceeds 1e-3 in about 1 episode of 13-60 (max seen 1.14e-3): LOGITS_TOLERANCE["fp16"] is that tail's
 #           regression bound, 1.5e-3.  A caller that needs every episode inside 1e-3 uses "fp32";
 #   bf16 -- the throughput mode: rms 2.3-3.9e-3, p99 6.5-8.5e-3, max 1.0e-2 over the same episodes; 1 argmax flip in 325 rows (a near-tie of
