@@ -63,6 +63,8 @@ MULTI_CASES = {
     "hc_cfg3_B16_5w5s_T8_mb": dict(arch="ViT-B/16", way=5, shot=5, q=1, T=8, merge_before=True, episodes=13, lowfreq=2.0),
     "hc_cfg4_L14_5w1s_T16": dict(arch="ViT-L/14", way=5, shot=1, q=1, T=16, episodes=13, lowfreq=2.0),
     "mc_cfg4_L14_5w1s_T16": dict(arch="ViT-L/14", way=5, shot=1, q=1, T=16, episodes=13),
+    # N3: the CLIP RN50 tower through the reference head's own "RN50" branch, 8 frames, high contrast (the tower needs class signal below its stem's cut-off)
+    "hc_rn50_5w1s_T8": dict(arch="RN50", way=5, shot=1, q=1, T=8, episodes=13, lowfreq=2.0),
 }
 
 

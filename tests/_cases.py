@@ -101,7 +101,8 @@ def maxdiff(a, b):
 
 
 # ---- multi-episode reference goldens (round 5; oracle/make_golden.py --multi): name -> file tests/golden/multi_<name>.npz
-MULTI_CASES = ("mc_cfg2_B16_5w1s_T8", "hc_cfg2_B16_5w1s_T8", "hc_cfg3_B16_5w5s_T8_mb", "hc_cfg4_L14_5w1s_T16", "mc_cfg4_L14_5w1s_T16")
+MULTI_CASES = ("mc_cfg2_B16_5w1s_T8", "hc_cfg2_B16_5w1s_T8", "hc_cfg3_B16_5w5s_T8_mb", "hc_cfg4_L14_5w1s_T16", "mc_cfg4_L14_5w1s_T16",
+               "hc_rn50_5w1s_T8")
 
 
 _MULTI_CACHE = {}

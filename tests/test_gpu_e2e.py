@@ -353,25 +353,27 @@ def test_forward_is_bit_stable_run_to_run(episodes):
             assert torch.equal(lo, ref[0]) and torch.equal(cl, ref[1]), (it, float((lo - ref[0]).abs().max()))
 
 
-@pytest.mark.parametrize("name", ["mc_cfg2_B16_5w1s_T8", "hc_cfg2_B16_5w1s_T8", "hc_cfg3_B16_5w5s_T8_mb", "hc_cfg4_L14_5w1s_T16", "mc_cfg4_L14_5w1s_T16"])
+@pytest.mark.parametrize("name", ["mc_cfg2_B16_5w1s_T8", "hc_cfg2_B16_5w1s_T8", "hc_cfg3_B16_5w5s_T8_mb", "hc_cfg4_L14_5w1s_T16", "mc_cfg4_L14_5w1s_T16",
+                                  "hc_rn50_5w1s_T8"])
 def test_modes_against_multi_episode_reference_goldens(name):
     """What each numerics mode guarantees, asserted on what it actually controls: 13 episodes = 65 logit rows per
     full-size configuration, produced by the REFERENCE itself (oracle/make_golden.py --multi), at the generator's standard contrast (`mc_`,
     logits spread ~1) and at high contrast (`hc_`, spread 3-4.5).  fp32: a hard bound on every logit of every episode.  fp16: a statistic
     (rms and 99th percentile over all rows) plus the regression bound of the tail, no argmax flip.  bf16: its regression bounds (a near-tie may flip)."""
-    from clip_fsar_amd import LOGITS_STATISTIC
+    from clip_fsar_amd import LOGITS_STATISTIC, LOGITS_STATISTIC_RN50, LOGITS_TOLERANCE_RN50
+    stat, tol = (LOGITS_STATISTIC_RN50, LOGITS_TOLERANCE_RN50) if "rn50" in name else (LOGITS_STATISTIC, LOGITS_TOLERANCE)    # the RN50 tower has its own (looser) bounds
     if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "multi_%s.npz" % name)):
         pytest.skip("fixture not generated")
     st = multi_case_stats(name, "fp32")
     assert st["worst_episode_max"] < 1e-4 and st["argmax_equal"] == st["rows"], st        # (the north star is 1e-3; measured 4e-6)
     st = multi_case_stats(name, "fp16")
     print(name, "fp16", st)
-    assert st["rms"] <= LOGITS_STATISTIC["fp16"]["rms"] and st["p99"] <= LOGITS_STATISTIC["fp16"]["p99"], st
-    assert st["max"] < LOGITS_TOLERANCE["fp16"] and st["argmax_equal"] == st["rows"], st
+    assert st["rms"] <= stat["fp16"]["rms"] and st["p99"] <= stat["fp16"]["p99"], st
+    assert st["max"] < tol["fp16"] and st["argmax_equal"] == st["rows"], st
     st = multi_case_stats(name, "bf16")
     print(name, "bf16", st)
-    assert st["rms"] <= LOGITS_STATISTIC["bf16"]["rms"] and st["p99"] <= LOGITS_STATISTIC["bf16"]["p99"], st
-    assert st["max"] < LOGITS_TOLERANCE["bf16"] and st["argmax_equal"] >= st["rows"] - 2, st      # (a near-tie may flip: 1 of 325 rows measured)
+    assert st["rms"] <= stat["bf16"]["rms"] and st["p99"] <= stat["bf16"]["p99"], st
+    assert st["max"] < tol["bf16"] and st["argmax_equal"] >= st["rows"] - 2, st      # (a near-tie may flip: 1 of 325 rows measured)
 
 
 def test_fp16_mode_b16_equals_b1():
