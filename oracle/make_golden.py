@@ -65,13 +65,17 @@ MULTI_CASES = {
     "mc_cfg4_L14_5w1s_T16": dict(arch="ViT-L/14", way=5, shot=1, q=1, T=16, episodes=13),
     # N3: the CLIP RN50 tower through the reference head's own "RN50" branch, 8 frames, high contrast (the tower needs class signal below its stem's cut-off)
     "hc_rn50_5w1s_T8": dict(arch="RN50", way=5, shot=1, q=1, T=8, episodes=13, lowfreq=2.0),
+    # trained-CLIP-like activation statistics at FULL size: two ln_pre channels scaled to |x| ~ 100 with a non-zero row mean (the outlier channels of
+    # trained CLIP ViTs), high contrast: the LayerNorm-folded GEMMs' cancellation and the fp16 stream's range under realistic conditions
+    "oc_cfg2_B16_5w1s_T8": dict(arch="ViT-B/16", way=5, shot=1, q=1, T=8, episodes=13, lowfreq=2.0,
+                                outliers=dict(channels=[5, 77], gain=40.0, shift=60.0)),
 }
 
 
 def run_multi_case(name, p):
     arch = p["arch"]
     a = synth.ARCHS[arch]
-    sd = synth.head_state_dict(arch, seed=SEED)
+    sd = synth.head_state_dict(arch, seed=SEED, outliers=p.get("outliers"))
     tt = synth.text_features(N_TRAIN, a["embed"], "train", SEED)
     te = synth.text_features(N_TEST, a["embed"], "test", SEED)
     cfg = rh.make_cfg(arch, way=p["way"], shot=p["shot"], frames=p["T"], n_train=N_TRAIN, n_test=N_TEST,

@@ -102,7 +102,7 @@ def maxdiff(a, b):
 
 # ---- multi-episode reference goldens (round 5; oracle/make_golden.py --multi): name -> file tests/golden/multi_<name>.npz
 MULTI_CASES = ("mc_cfg2_B16_5w1s_T8", "hc_cfg2_B16_5w1s_T8", "hc_cfg3_B16_5w5s_T8_mb", "hc_cfg4_L14_5w1s_T16", "mc_cfg4_L14_5w1s_T16",
-               "hc_rn50_5w1s_T8")
+               "hc_rn50_5w1s_T8", "oc_cfg2_B16_5w1s_T8")
 
 
 _MULTI_CACHE = {}
@@ -122,10 +122,10 @@ def multi_case_stats(name, precision, chunk=None):
     E = m["episodes"]
     # weights and episodes of the LAST case are kept: the three modes of a case (and the two contrast sets of an architecture) share them, and
     # generating the ViT-L/14 state dict takes half a minute of numpy
-    wkey, ekey = (m["arch"], m["seed"], m["n_train"], m["n_test"]), (name,)
+    wkey, ekey = (m["arch"], m["seed"], m["n_train"], m["n_test"], json.dumps(m.get("outliers"), sort_keys=True)), (name,)
     if _MULTI_CACHE.get("wkey") != wkey:
         _MULTI_CACHE.clear()
-        _MULTI_CACHE.update(wkey=wkey, w=({k: torch.from_numpy(v) for k, v in synth.head_state_dict(m["arch"], seed=m["seed"]).items()},
+        _MULTI_CACHE.update(wkey=wkey, w=({k: torch.from_numpy(v) for k, v in synth.head_state_dict(m["arch"], seed=m["seed"], outliers=m.get("outliers")).items()},
                                           torch.from_numpy(synth.text_features(m["n_train"], a["embed"], "train", m["seed"])),
                                           torch.from_numpy(synth.text_features(m["n_test"], a["embed"], "test", m["seed"]))))
     if _MULTI_CACHE.get("ekey") != ekey:

@@ -354,7 +354,7 @@ def test_forward_is_bit_stable_run_to_run(episodes):
 
 
 @pytest.mark.parametrize("name", ["mc_cfg2_B16_5w1s_T8", "hc_cfg2_B16_5w1s_T8", "hc_cfg3_B16_5w5s_T8_mb", "hc_cfg4_L14_5w1s_T16", "mc_cfg4_L14_5w1s_T16",
-                                  "hc_rn50_5w1s_T8"])
+                                  "hc_rn50_5w1s_T8", "oc_cfg2_B16_5w1s_T8"])
 def test_modes_against_multi_episode_reference_goldens(name):
     """What each numerics mode guarantees, asserted on what it actually controls: 13 episodes = 65 logit rows per
     full-size configuration, produced by the REFERENCE itself (oracle/make_golden.py --multi), at the generator's standard contrast (`mc_`,

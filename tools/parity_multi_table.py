@@ -4,7 +4,8 @@ import json, sys
 d = json.load(open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/parity_multi.json"))
 names = {"mc_cfg2_B16_5w1s_T8": "cfg2 (ViT-B/16, 5-way 1-shot, 8 frames), standard contrast", "hc_cfg2_B16_5w1s_T8": "cfg2, high contrast",
          "hc_cfg3_B16_5w5s_T8_mb": "cfg3 (5-way 5-shot, MERGE_BEFORE), high contrast", "hc_cfg4_L14_5w1s_T16": "cfg4 (ViT-L/14, 16 frames), high contrast",
-         "mc_cfg4_L14_5w1s_T16": "cfg4, standard contrast", "hc_rn50_5w1s_T8": "CLIP RN50 tower (N3), 5-way 1-shot, 8 frames, lowfreq 2.0"}
+         "mc_cfg4_L14_5w1s_T16": "cfg4, standard contrast", "hc_rn50_5w1s_T8": "CLIP RN50 tower (N3), 5-way 1-shot, 8 frames, lowfreq 2.0",
+         "oc_cfg2_B16_5w1s_T8": "cfg2 with trained-CLIP-like outlier channels (|x| ~ 100 in two ln_pre channels), high contrast"}
 print("| configuration (13 reference episodes = 65 logit rows each) | mean logits spread | mode | rms | p99 | max | episodes whose largest deviation > 1e-3 | max / spread | argmax equal |")
 print("|---|---|---|---|---|---|---|---|---|")
 for n in names:
