@@ -234,6 +234,21 @@ def golden_parity(logits0, precision, config="cfg2"):
                               "tests/test_gpu_e2e.py::test_modes_against_multi_episode_reference_goldens); the north-star bound is 1e-3"}
 
 
+def default_episodes_per_step(cfgname, dry=False):
+    """The batch the product harness itself picks for a config without TEST.EPISODES_PER_STEP (datasets/base/builder.py::auto_episodes_per_step):
+    ViT towers -> clip_fsar_amd.utils.batching (full rounds of the persistent GEMM grid within 2 880 frames and the 32-bit offset limit), RN50 -> 16."""
+    if dry:
+        return 16
+    from clip_fsar_amd.utils.batching import FRAME_CAP, pick_episodes_per_step
+    c = CONFIGS[cfgname]
+    a = synth.ARCHS[c["arch"]]
+    if a.get("kind") == "rn":
+        return 16
+    ntok = (a["res"] // a["patch"]) ** 2 + 1
+    fpe = (WAY * c["shot"] + WAY * QPC) * c["T"]
+    return pick_episodes_per_step(fpe, ntok, a["width"], max_frames=min(FRAME_CAP, (2 ** 32 - 1) // (ntok * 4 * a["width"] * 2) - 1))
+
+
 def executed_gflop_per_frame(arch, gflop, pruned):
     """the last ViT block is computed for the class-token rows only (engine.py: prune_last; few_shot.py:683 reads nothing else of it):
     (N - 1) (20 D^2 + 4 N D) FLOPs per frame fewer than the reference path's figure"""
@@ -305,7 +320,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--episodes-per-step", type=int, default=16)
+    ap.add_argument("--episodes-per-step", type=int, default=0,
+                    help="episodes per step and GPU; 0 (default) = the product harness's own choice (clip_fsar_amd.utils.batching: the batch that fills the "
+                         "rounds of the persistent GEMM grid, 36 for cfg2; RN50: 16)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--pool", type=int, default=0, help="distinct synthetic episodes resident in HBM per rank (0 = one per slot of a step: "
                                                         "every step holds episodes-per-step DISTINCT episodes)")
@@ -454,8 +471,8 @@ def run(args):
             raise SystemExit("bench.py rank %d of %d: process-group rendezvous at %s:%s failed within %d s: %s" % (
                 rank, world, os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"], args.rendezvous_timeout, exc))
 
-    B = args.episodes_per_step
     frames_per_ep = (WAY * SHOT + WAY * QPC) * T
+    B = args.episodes_per_step or default_episodes_per_step(args.config, dry)
     timer = None
     first_logits = {}
     if dry:
@@ -587,7 +604,7 @@ def run(args):
         fp16_mode = timed_leg(args.config, "fp16", B, max(4, min(args.steps, 10)), dev, timer, weights=(sd, tt, te), batches=batches)
     if (not dry and rank == 0 and world == 1 and args.precision == "bf16" and args.config == "cfg2" and not args.no_config_legs
             and B * frames_per_ep > 160):
-        # BASELINE configs[2..3] in front of the driver: 3 timed steps of 8 episodes each, bf16 and fp16, with golden parity
+        # BASELINE configs[2..3] in front of the driver: 3 timed steps of the harness's batch (12 / 11 episodes), bf16 and fp16, with golden parity
         config_legs = {}
         for cname in ("cfg3", "cfg4"):
             cc = CONFIGS[cname]
@@ -597,7 +614,7 @@ def run(args):
                 w = ({k: torch.from_numpy(v) for k, v in synth.head_state_dict(cc["arch"], SEED).items()},
                      synth.text_features(N_TRAIN, aa["embed"], "train", SEED), synth.text_features(N_TEST, aa["embed"], "test", SEED))
             for prec in ("bf16", "fp16"):
-                config_legs["%s_%s" % (cname, prec)] = timed_leg(cname, prec, 8, 3, dev, timer, weights=w)
+                config_legs["%s_%s" % (cname, prec)] = timed_leg(cname, prec, default_episodes_per_step(cname), 3, dev, timer, weights=w)
             del w
 
     if rank == 0:

@@ -48,17 +48,20 @@ def build_dataset(name, cfg, split):
 
 
 _LOGGED_K = set()
-AUTO_EPISODES_PER_STEP_MAX = 16      # the tower's GEMMs run at their batch-scale rate from ~1 000 frames per launch
+AUTO_EPISODES_PER_STEP_MAX = 36      # ViT towers: utils/batching.py picks k <= this so that the persistent GEMM grid's rounds come out full
 
 
 def auto_episodes_per_step(cfg, n_local):
     """Episodes per model call when the config does not say (a reference-shaped config has no TEST.EPISODES_PER_STEP: the reference
-    feeds ONE episode per iteration, runs/test_net_few_shot.py:57-64, which leaves 20 % of this tower's throughput on the table).
-    The loader collates k episodes -- per-episode results do not depend on k (tests/test_gpu_e2e.py: batch invariance) -- with k
-    bounded by the rank's episode count, by 16, and by a quarter of the device's TOTAL HBM over an upper estimate of one episode's footprint
-    (two upload buffers of fp32 frames + the tower's activation workspace): deterministic per device and config, logged once."""
+    feeds ONE episode per iteration, runs/test_net_few_shot.py:57-64, which leaves a quarter of this tower's throughput on the table).
+    The loader collates k episodes -- per-episode results do not depend on k (tests/test_gpu_e2e.py: batch invariance).  ViT towers:
+    utils/batching.py::pick_episodes_per_step -- the k that fills the rounds of the persistent GEMM grid best within the frames one tower
+    launch may carry (cfg2: 36 episodes = 2 880 frames); RN50: 16.  Bounded by the rank's episode count and by a quarter of the device's
+    TOTAL HBM over an upper estimate of one episode's footprint (two upload buffers of fp32 frames + the tower's activation workspace):
+    deterministic per device and config, logged once."""
     if not (torch.cuda.is_available() and int(getattr(cfg, "NUM_GPUS", 1) or 0) > 0):
         return 1
+    from ...utils.batching import FRAME_CAP, pick_episodes_per_step
     arch = synth.ARCHS.get(cfg.VIDEO.HEAD.BACKBONE_NAME, None)
     way = int(getattr(cfg.TRAIN, "WAT_TEST", 0) or cfg.TRAIN.WAY)
     shot = int(getattr(cfg.TRAIN, "SHOT_TEST", getattr(cfg.TRAIN, "SHOT", 1)))
@@ -66,7 +69,8 @@ def auto_episodes_per_step(cfg, n_local):
     frames = way * (shot + qpc) * int(cfg.DATA.NUM_INPUT_FRAMES)
     res = int(getattr(cfg.DATA, "TEST_CROP_SIZE", arch["res"] if arch else 224))
     per_frame = 2 * 3 * res * res * 4
-    if arch and arch.get("kind") != "rn":
+    vit = bool(arch) and arch.get("kind") != "rn"
+    if vit:
         ntok = (arch["res"] // arch["patch"]) ** 2 + 1
         per_frame += ntok * arch["width"] * 28          # x (two words), qkv, o, u, patches, statistics: < 28 bytes per token-channel
     else:
@@ -77,8 +81,13 @@ def auto_episodes_per_step(cfg, n_local):
         total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
     except Exception:
         return 1
-    k = int(0.25 * total // max(1, per_frame * frames))
-    k = max(1, min(AUTO_EPISODES_PER_STEP_MAX, k, max(1, int(n_local))))
+    kmem = int(0.25 * total // max(1, per_frame * frames))
+    kcap = max(1, min(AUTO_EPISODES_PER_STEP_MAX, kmem, max(1, int(n_local))))
+    if vit:
+        launch_frames = min(int(getattr(cfg.VIDEO.HEAD, "MAX_FRAMES_PER_LAUNCH", FRAME_CAP)), (2 ** 32 - 1) // (ntok * 4 * arch["width"] * 2) - 1)
+        k = pick_episodes_per_step(frames, ntok, arch["width"], max_frames=max(frames, launch_frames), max_episodes=kcap)
+    else:
+        k = min(16, kcap)
     key = (frames, res, k)
     if key not in _LOGGED_K:
         _LOGGED_K.add(key)

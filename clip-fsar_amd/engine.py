@@ -723,7 +723,7 @@ class ClipFsarEngine:
     """Full episodic forward A0 -> A15 for a batch of B episodes with identical (way, shot, query, T)."""
 
     def __init__(self, arch: dict, head_sd: dict, text_train, text_test, depth: int = 1, precision: str = "bf16",
-                 device="cuda", max_frames: int = 1280, fp16_split=None, fp16_mcorr=None, vit_options=None):
+                 device="cuda", max_frames: int = 2880, fp16_split=None, fp16_mcorr=None, vit_options=None):
         self.dev = torch.device(device)
         self.arch = dict(arch)
         if arch.get("kind") == "rn":

@@ -189,7 +189,7 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             self._engine = ClipFsarEngine(self.arch, sd, self.text_features_train, self.text_features_test,
                                           depth=self.depth, precision=self.precision, device=device,
-                                          max_frames=int(getattr(self.args.VIDEO.HEAD, "MAX_FRAMES_PER_LAUNCH", 1280)),
+                                          max_frames=int(getattr(self.args.VIDEO.HEAD, "MAX_FRAMES_PER_LAUNCH", 2880)),      # utils/batching.py FRAME_CAP: 36 cfg2 episodes per tower launch
                                           fp16_split=getattr(self.args.VIDEO.HEAD, "FP16_SPLIT", None),
                                           fp16_mcorr=getattr(self.args.VIDEO.HEAD, "FP16_MCORR", None))
             self._engine_key = key

@@ -46,7 +46,7 @@ def test_epoch(val_loader, model, val_meter, cur_epoch, cfg, writer=None):
                 return {"_labels_validated_way": head.validate_labels_host(host["support_labels"], host["real_support_labels"])}
             return None
         # A loader that yields ONE episode per item (the reference's own: TEST.BATCH_SIZE / NUM_GPUS = 1, :57-64) under a config that
-        # does not set TEST.EPISODES_PER_STEP: the prefetcher collates k items per model call (k <= 16, fixed per device and config: auto_episodes_per_step); per-episode
+        # does not set TEST.EPISODES_PER_STEP: the prefetcher collates k items per model call (k <= 36, fixed per device and config: auto_episodes_per_step); per-episode
         # results do not depend on k.  build_loader's own loaders already come batched (datasets/base/builder.py).
         k = 1
         if not int(getattr(cfg.TEST, "EPISODES_PER_STEP", 0) or 0) and int(getattr(val_loader, "batch_size", 0) or 0) == 1:

@@ -435,13 +435,14 @@ def test_prefetcher_collate_rejects_mismatched_items_and_survives_a_growing_batc
 def test_reference_shaped_cfg_reaches_the_batched_rate():
     """a reference-shaped config (no TEST.EPISODES_PER_STEP) over a loader that yields ONE episode per item -- what the
     reference's own harness feeds (runs/test_net_few_shot.py:57-64) -- must deliver the batched rate: test_epoch collates k items per
-    model call.  Resident synthetic cfg2 episodes (ViT-B/16, bf16): >= 0.93 x the rate of the same harness over pre-built 16-episode steps."""
+    model call (36 for cfg2: utils/batching.py, the batch that fills the rounds of the persistent GEMM grid).  Resident synthetic cfg2 episodes
+    (ViT-B/16, bf16): >= 0.93 x the rate of the same harness over pre-built 16-episode steps."""
     import time
     from clip_fsar_amd.models.base.builder import build_model
     from clip_fsar_amd.runs.test_net_few_shot import test_epoch
     from clip_fsar_amd.utils.meters import ValMeter
     from clip_fsar_amd.datasets.base.builder import auto_episodes_per_step
-    B, n = 16, 96
+    B, n = 16, 144
     a = synth.ARCHS["ViT-B/16"]
 
     def cfg_of(**test_extra):
@@ -452,7 +453,7 @@ def test_reference_shaped_cfg_reaches_the_batched_rate():
                   DATA=NS(NUM_INPUT_FRAMES=8, TEST_CROP_SIZE=a["res"]), MODEL=NS(NAME="BaseVideoModel", EMA=NS(ENABLE=False)),
                   BN=NS(FREEZE=False), NUM_GPUS=1, NUM_SHARDS=1, RANDOM_SEED=18, LOG_PERIOD=100, OUTPUT_DIR="")
     cfg_ref, cfg_b = cfg_of(), cfg_of(EPISODES_PER_STEP=B)
-    assert auto_episodes_per_step(cfg_ref, n) == B
+    assert auto_episodes_per_step(cfg_ref, n) == 36 and auto_episodes_per_step(cfg_ref, 20) == 18
     model, _ = build_model(cfg_ref)
     eps = [{k: torch.from_numpy(v).unsqueeze(0).cuda() for k, v in synth.make_episode(5, 1, 1, 8, a["res"], N_TEST, e, 18).items()} for e in range(4)]
     steps16 = [{k: torch.cat([eps[(j + i) % 4][k] for i in range(B)]) for k in eps[0]} for j in range(2)]

@@ -9,7 +9,7 @@ TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-EPS=${EPS:-16}
+EPS=${EPS:-36}
 CMD="python bench.py --steps 4 --warmup 2 --episodes-per-step $EPS --no-cpu-baseline --no-kernel-events --no-fp16-leg --no-config-legs ${CMD_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 python tools/trace_summary.py $OUT/trace/t_kernel_trace.csv 0 > $OUT/kernel_summary.txt
