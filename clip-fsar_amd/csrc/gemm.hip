@@ -758,6 +758,166 @@ int launch_p3(const GemmArgs& a0, hipStream_t s) {
     }
 }
 
+// compile-time loop: indices are constants in the AST, so the register arrays of the kernels below are split by the FIRST SROA pass
+// (a `#pragma unroll` loop index is still dynamic there and leaves them to the size-limited alloca promotion -> scratch)
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// ============================================================================================================
+// K1 (few_shot.py:659, 672-676): the patch embedding in ONE launch -- conv1 as a GEMM whose X operand is gathered straight from the
+// fp32 NCHW frames (no im2col matrix: at 36 episodes that was 0.87 GB written and read back, two launches of 240 us), + pos[1 + p], rows scattered
+// behind each frame's class token, and the class-token rows cls + pos[0] themselves.  P = 16: a 64-wide K slice is 4 image rows x 16 pixels of
+// one channel of a patch, a lane's 16-byte LDS chunk = 8 consecutive pixels = two 16-byte fp32 loads, rounded to the operand type in registers
+// and written where the LDS-DMA of gemm_kernel_p3 would have put them -- same tile (256 x 128), same ring, same fragment reads and MFMA
+// order: an output element is bit-identical to the im2col + cfsar_gemm form.  W still arrives by LDS-DMA.
+// Pipeline: the fp32 loads of slice s are issued three iterations ahead (two register sets alternate), written to stage s % 3 one iteration
+// ahead; W of slice s is DMA'd two iterations ahead.  The register loads are plain C++ loads (no compiler-invisible register destinations:
+// profiles/r04_fault_audit.md) and the K loop is FULLY unrolled (K = 768 = 12 slices): in straight-line code hipcc's wait for a register set
+// is exact in its own loads -- vmcnt(8): the next set may still be in flight -- where, across a loop's back edge, it drained to vmcnt(0) at
+// every use (one iteration of latency cover instead of two).  Its count ignores the asm DMA instructions in between, so the wait is at
+// least as strict as the exact one, and it also covers W of the slice the barrier behind it publishes (issued before the set it waits for).
+// ============================================================================================================
+struct PatchArgs {
+    GemmArgs g;               // M = F * npatch rows, N = D, K = 768, W / ldw, out / ldo, res = pos (fp32), remap fields set
+    const float* frames;      // [F, 3, H, W]
+    const float* cls;         // [D]
+    int H, Wd, gw, npatch, F;
+};
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(NTHREADS2) void patch_embed_kernel(PatchArgs q) {
+    const GemmArgs& p = q.g;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int qq = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int lin = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (b >> 3);
+    const int tm = lin / p.tiles_n, tn = lin - tm * p.tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    // class-token rows of the frames whose first patch row lies in this tile (few_shot.py:675-676), this tile's columns
+    if (tid < BN2 && n0 + tid < p.N) {
+        const int ntok = q.npatch + 1;
+        for (int f = (m0 + q.npatch - 1) / q.npatch; f < q.F && f * q.npatch < m0 + BM2; ++f)
+            reinterpret_cast<TO*>(p.out)[(size_t)f * ntok * p.ldo + n0 + tid] = (TO)(q.cls[n0 + tid] + reinterpret_cast<const float*>(p.res)[n0 + tid]);
+    }
+
+    // X pieces: piece i of this wave = rows (8 i + wave) 8 + lane / 8 of the tile; every piece of a lane has the same chunk (swz: see CONV above)
+    const int chunk = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
+    const float* srcX[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int gm = m0 + (i * 8 + wave) * 8 + (lane >> 3);
+        gm = gm < p.M ? gm : p.M - 1;
+        const int f = gm / q.npatch, pp = gm - f * q.npatch;
+        const int py = pp / q.gw, px = pp - py * q.gw;
+        srcX[i] = q.frames + ((size_t)f * 3 * q.H + py * 16 + (chunk >> 1)) * q.Wd + px * 16 + (chunk & 1) * 8;
+    }
+    const char* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+        int gn = n0 + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        srcW[i] = p.W + ((size_t)gn * p.ldw) * sizeof(TI) + ((lane & 7) ^ swz(row)) * 16;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+    char* const wrX = smem + wave * 1024 + lane * 16;                       // + stage * STAGE2 + i * 8192: where the DMA form writes
+    auto issue_w = [&](int stage, int kt) __attribute__((always_inline)) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(ldsw + (unsigned)stage * (unsigned)STAGE2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_asm(srcW[i] + (size_t)kt * ROWB, base + BM2 * ROWB + i * 8192);
+    };
+    // slice kt = channel kt / 4, image rows 4 (kt % 4) .. + 3 of the patch
+    auto load_x = [&](int kt, f32x4 (&xr)[8]) __attribute__((always_inline)) {
+        const size_t off = ((size_t)(kt >> 2) * q.H + (kt & 3) * 4) * q.Wd;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xr[2 * i] = *reinterpret_cast<const f32x4*>(srcX[i] + off);
+            xr[2 * i + 1] = *reinterpret_cast<const f32x4*>(srcX[i] + off + 4);
+        }
+    };
+    auto write_x = [&](int stage, const f32x4 (&xr)[8]) __attribute__((always_inline)) {
+        typedef typename Vec2B<TI>::v8 TI8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 a = xr[2 * i], c = xr[2 * i + 1];
+            TI8 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (TI)a[j];
+                o[4 + j] = (TI)c[j];
+            }
+            *reinterpret_cast<TI8*>(wrX + stage * STAGE2 + i * 8192) = o;
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, hi = lane >> 5;
+    int offX[2], offW[2], sxX[2], sxW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rx = wm * 64 + i * 32 + lr;
+        const int rw = wn * 64 + i * 32 + lr;
+        offX[i] = rx * ROWB;
+        sxX[i] = swz(rx);
+        offW[i] = rw * ROWB;
+        sxW[i] = swz(rw);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    constexpr int nk = 12;                       // K = 768 (launcher)
+    f32x4 xa[8], xb[8];                          // even / odd slices
+    issue_w(0, 0);
+    issue_w(1, 1);
+    load_x(0, xa);
+    load_x(1, xb);
+    write_x(0, xa);
+    load_x(2, xa);
+    // iteration kt: X of slice kt + 1 goes from its registers into stage (kt + 1) % 3 (free since the barrier of iteration kt - 1), barrier
+    // (slice kt complete, slice kt - 1 read by everyone), W of slice kt + 2 and the registers of slice kt + 3 are requested, slice kt is computed
+    static_for<nk>([&](auto kt_c) __attribute__((always_inline)) {
+        constexpr int kt = decltype(kt_c)::value;
+        constexpr int st = kt % NSTAGE2, st1 = (kt + 1) % NSTAGE2, st2 = (kt + 2) % NSTAGE2;
+        f32x4 (&xnext)[8] = (kt & 1) ? xa : xb;                             // registers of slice kt + 1, then of slice kt + 3
+        if constexpr (kt + 1 < nk) write_x(st1, xnext);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // last slice: its W
+        __syncthreads();
+        if constexpr (kt + 2 < nk) issue_w(st2, kt + 2);
+        if constexpr (kt + 3 < nk) load_x(kt + 3, xnext);
+        const char* sX = smem + st * STAGE2;
+        mma_slice_db<TI, 2>(acc, sX, sX + BM2 * ROWB, offX, offW, sxX, sxW, hi);
+    });
+    __syncthreads();                 // every wave is done with the ring: reuse it as per-wave transpose buffers
+    const int mb = m0 + wm * 64, nb = n0 + wn * 64;
+    f32x16 (*accp)[2] = acc;
+    const bool full = mb + 64 <= p.M && nb + 64 <= p.N;
+    if (full) epilogue_lds<TO, CFSAR_ACT_NONE, true, true, true>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+    else epilogue_lds<TO, CFSAR_ACT_NONE, true, true, false>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
+}
+
+template <typename TI, typename TO>
+int launch_patch_embed(const PatchArgs& a, hipStream_t s) {
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&patch_embed_kernel<TI, TO>), NSTAGE2 * STAGE2, "cfsar_patch_embed")) return rc;
+    const int tiles_m = (a.g.M + BM2 - 1) / BM2;
+    hipLaunchKernelGGL((patch_embed_kernel<TI, TO>), dim3(tiles_m * a.g.tiles_n), dim3(NTHREADS2), NSTAGE2 * STAGE2, s, a);
+    return cfsar_check_launch("cfsar_patch_embed");
+}
+
 // fp16 output (the bf16 mode's residual stream): no activation + residual, with or without the patch-embed row remap
 int launch_p3_f16(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
@@ -811,16 +971,6 @@ constexpr int kVitGroup = 8, kVitColfast = 0;
 
 // ---- helpers shared by the register-staged kernels (p10, p12)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: loads/stores stay SSA values (no memcpy)
-// compile-time loop: indices are constants in the AST, so the register arrays below are split by the FIRST SROA pass
-// (a `#pragma unroll` loop index is still dynamic there and leaves them to the size-limited alloca promotion -> scratch)
-template <typename F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
 
 // ============================================================================================================
 // v4 ("p10"): ONE wave per SIMD (256 threads, 2 x 2 waves, 128 x 128 wave tiles, 256 accumulators in AGPRs), register-staged
@@ -1666,6 +1816,32 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     if (in_dtype == CFSAR_BF16)
         return out_dtype == CFSAR_BF16 ? launch<__bf16, __bf16>(a, s) : launch<__bf16, float>(a, s);
     return out_dtype == CFSAR_BF16 ? launch<float, __bf16>(a, s) : launch<float, float>(a, s);
+}
+
+extern "C" int cfsar_patch_embed(const float* frames, const void* W, int w_dtype, const float* pos, const float* cls, void* x, int x_dtype,
+                                 int F, int H, int Wd, int P, int D, int ldw, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(frames && W && pos && cls && x, "cfsar_patch_embed: null pointer");
+    CFSAR_REQUIRE(P == 16, "cfsar_patch_embed: patch size %d (the fused gather exists for 16 x 16 patches; other sizes: cfsar_im2col_patches + cfsar_gemm_ex)", P);
+    CFSAR_REQUIRE(F > 0 && H > 0 && Wd > 0 && H % 16 == 0 && Wd % 16 == 0, "cfsar_patch_embed: bad geometry F=%d H=%d W=%d", F, H, Wd);
+    CFSAR_REQUIRE(D > 0 && D % 4 == 0 && ldw >= 768 && ldw % 8 == 0, "cfsar_patch_embed: bad D=%d / ldw=%d", D, ldw);
+    CFSAR_REQUIRE(w_dtype == CFSAR_BF16 || w_dtype == CFSAR_F16, "cfsar_patch_embed: weights must be bf16 or fp16, got %d", w_dtype);
+    CFSAR_REQUIRE(x_dtype == CFSAR_F16, "cfsar_patch_embed: x must be the fp16 residual stream, got dtype %d", x_dtype);
+    PatchArgs a;
+    a.frames = frames; a.cls = cls; a.H = H; a.Wd = Wd; a.gw = Wd / 16; a.npatch = (H / 16) * (Wd / 16); a.F = F;
+    CFSAR_REQUIRE((long long)F * a.npatch < (1ll << 31) / 2 && (long long)F * 3 * H * Wd < (1ll << 40), "cfsar_patch_embed: too many frames");
+    GemmArgs& g = a.g;
+    g.A = nullptr; g.W = static_cast<const char*>(W); g.out = x; g.bias = nullptr; g.res = pos; g.res_kind = 0; g.relu = 0;
+    g.M = F * a.npatch; g.N = D; g.K = 768;
+    g.lda = 768; g.ldw = ldw; g.ldo = D; g.ldr = D;
+    g.act = CFSAR_ACT_NONE;
+    g.row_group = a.npatch; g.row_gap = 1; g.row_off = 1; g.res_mod = a.npatch; g.res_off = 1;
+    g.tiles_n = (D + BN2 - 1) / BN2; g.ntiles = 0;
+    g.conv_H = g.conv_W = g.conv_lgC = 0;
+#ifdef CFSAR_DEV
+    g.dbg = 0;
+#endif
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return w_dtype == CFSAR_F16 ? launch_patch_embed<_Float16, _Float16>(a, s) : launch_patch_embed<__bf16, _Float16>(a, s);
 }
 
 extern "C" int cfsar_gemm(const void* A, const void* W, void* out, const float* bias, const float* residual, int M,

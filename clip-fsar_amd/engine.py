@@ -43,7 +43,8 @@ class HipViT:
     # developer options (tools/*.py; every default is the product setting and has a GPU test): ablations of the fp16 numerics mode and the
     # statistics fusion.  They are constructor arguments -- the product path reads four environment variables only (CFSAR_LN_FOLD,
     # CFSAR_FULL_LAST_BLOCK, CFSAR_FP16_SPLIT, CFSAR_FP16_MCORR).
-    OPTIONS = {"fp16_wide": True, "fp16_lo": True, "fp16_rawmeans": True, "fused_umeans": True, "fused_omeans": True, "fuse_stats": True}
+    OPTIONS = {"fp16_wide": True, "fp16_lo": True, "fp16_rawmeans": True, "fused_umeans": True, "fused_omeans": True, "fuse_stats": True,
+               "fused_patch": True}
 
     def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda", stream_dtype=None, fp16_split=None, fp16_mcorr=None,
                  options=None):
@@ -91,6 +92,10 @@ class HipViT:
         wc = torch.zeros(D, self.kpad, device=self.dev, dtype=torch.float32)
         wc[:, :3 * P * P] = g("conv1.weight").reshape(D, -1)
         self.w_patch = wc.to(cd).contiguous()
+        # patch gather inside the patch-embed GEMM (16 x 16 patches, 16-bit operands, 16-bit stream); "fused_patch": False keeps the
+        # three-launch form (the A/B and bit-equality tests)
+        self.fused_patch = bool(opt["fused_patch"] and P == 16 and self.kpad == 768 and cd in (torch.bfloat16, torch.float16)
+                                and self.xd == torch.float16)
         self.cls = g("class_embedding")
         self.pos = g("positional_embedding")
         self.ln_pre = (g("ln_pre.weight"), g("ln_pre.bias"))
@@ -244,13 +249,14 @@ class HipViT:
         if F_ > cap:
             M, D, cd, dev = F_ * self.ntok, self.D, self.cd, self.dev
             ws = dict(
-                patches=torch.empty(F_ * (self.ntok - 1), self.kpad, device=dev, dtype=cd),
                 x=torch.empty(M, D, device=dev, dtype=self.xd),
                 h=torch.empty(M, D, device=dev, dtype=cd),
                 qkv=torch.empty(M, 3 * D, device=dev, dtype=cd),
                 o=torch.empty(M, D, device=dev, dtype=cd),
                 u=torch.empty(M, 4 * D, device=dev, dtype=cd),
                 c=torch.empty(F_, D, device=dev, dtype=torch.float32))
+            if not self.fused_patch:                                                         # the im2col matrix of the unfused patch embedding
+                ws["patches"] = torch.empty(F_ * (self.ntok - 1), self.kpad, device=dev, dtype=cd)
             if self.fold:
                 ws["part"] = torch.empty(M, D // 64, 2, device=dev, dtype=torch.float32)    # partial row statistics
                 ws["rstat"] = torch.empty(M, 4, device=dev, dtype=torch.float32)            # (mean, std, 1/std, -)
@@ -295,16 +301,22 @@ class HipViT:
         N, D, npatch = self.ntok, self.D, self.ntok - 1
         M = F_ * N
         x, h, qkv, o, u = ws["x"], ws["h"], ws["qkv"], ws["o"], ws["u"]
-        # A2: patch gather -> GEMM with the epilogue scattering rows behind each class token and adding pos[1+p]
+        # A2 (few_shot.py:672-676).  16 x 16 patches, 16-bit operands: ONE launch per frame set -- the GEMM gathers its rows from the fp32 frames,
+        # adds pos[1 + p], scatters them behind each class token and writes the class-token rows (cfsar_patch_embed).  Otherwise
+        # (ViT-L/14, the fp32 mode): patch gather -> GEMM with the scattering epilogue -> class-token rows; the results are bit-identical.
         off = 0
         for fr, c in zip(frame_sets, counts):
             if fr.shape[1:] != (3, self.arch["res"], self.arch["res"]):
                 raise RuntimeError("frames must be [F,3,%d,%d], got %s" % (self.arch["res"], self.arch["res"], tuple(fr.shape)))
-            hip.im2col_patches(fr, ws["patches"][off * npatch:(off + c) * npatch], self.P)
+            if self.fused_patch:
+                hip.patch_embed(fr, self.w_patch, self.pos, self.cls, x[off * N:(off + c) * N], self.P)
+            else:
+                hip.im2col_patches(fr, ws["patches"][off * npatch:(off + c) * npatch], self.P)
             off += c
-        hip.gemm(ws["patches"], self.w_patch, x, residual=self.pos, M=F_ * npatch, N=D, K=self.kpad, ldo=D, ldr=D,
-                 row_group=npatch, row_gap=1, row_off=1, res_mod=npatch, res_off=1)
-        hip.cls_rows(x, self.cls, self.pos, F_, N, D)
+        if not self.fused_patch:
+            hip.gemm(ws["patches"], self.w_patch, x, residual=self.pos, M=F_ * npatch, N=D, K=self.kpad, ldo=D, ldr=D,
+                     row_group=npatch, row_gap=1, row_off=1, res_mod=npatch, res_off=1)
+            hip.cls_rows(x, self.cls, self.pos, F_, N, D)
         hip.layernorm(x, x, self.ln_pre[0], self.ln_pre[1], M, D)                     # ln_pre (:677), in place
         if taps is not None:
             taps["ln_pre"] = x[:M].clone()

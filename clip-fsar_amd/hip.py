@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (imported first so that torch's libamdhip64.so.7 is the HIP runtime the library binds to)
 
 F32, BF16, F16 = 0, 1, 2
-ABI_VERSION = 7          # CFSAR_ABI_VERSION of include/clipfsar_hip.h this file's SIGNATURES were written against
+ABI_VERSION = 8          # CFSAR_ABI_VERSION of include/clipfsar_hip.h this file's SIGNATURES were written against
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -29,6 +29,7 @@ SIGNATURES = {
     "cfsar_version": [],
     "cfsar_preprocess_frames": [_c_p, _c_p] + [_c_int] * 8 + [_c_p, _c_p, _c_p],
     "cfsar_im2col_patches": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_patch_embed": [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_cls_rows": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_layernorm": [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p],
     "cfsar_layernorm_ex": [_c_p, _c_int, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p],
@@ -177,6 +178,24 @@ def im2col_patches(frames, out, patch):
     assert C == 3
     _check(lib().cfsar_im2col_patches(_dev(frames, torch.float32, "frames"), _dev(out, None, "out"), _code(out.dtype),
                                       F_, H, W, patch, out.shape[1], _stream()), "cfsar_im2col_patches")
+
+
+def patch_embed_ok(patch, w, x):
+    """cfsar_patch_embed serves 16 x 16 patches with bf16 / fp16 weights [D, >= 768] into the fp16 residual stream."""
+    return patch == 16 and w.dtype in (torch.bfloat16, torch.float16) and w.shape[1] >= 768 and x.dtype == torch.float16
+
+
+def patch_embed(frames, w, pos, cls, x, patch=16):
+    """x[f*ntok + 1 + p] = patch(f, p) @ w.T + pos[1 + p], x[f*ntok] = cls + pos[0] in one launch, gathered straight from the fp32 frames
+    (include/clipfsar_hip.h: cfsar_patch_embed; few_shot.py:672-676)."""
+    F_, C, H, W = frames.shape
+    assert C == 3
+    D = pos.shape[1]
+    if x.shape[-1] != D or not x.is_contiguous():
+        raise RuntimeError("patch_embed: x must be contiguous [.., %d]" % D)
+    _check(lib().cfsar_patch_embed(_dev(frames, torch.float32, "frames"), _dev(w, None, "w"), _code(w.dtype), _dev(pos, torch.float32, "pos"),
+                                   _dev(cls, torch.float32, "cls"), _dev(x, None, "x"), _code(x.dtype), F_, H, W, patch, D, w.stride(0),
+                                   _stream()), "cfsar_patch_embed")
 
 
 def cls_rows(x, cls, pos, F_, ntok, D):

@@ -46,7 +46,7 @@ typedef void* cfsar_stream_t;
 int cfsar_version(void);
 /* ABI revision: bumped whenever an exported signature changes or is added; a binding compares it with the CFSAR_ABI_VERSION it was
  * written against at load time (clip-fsar_amd/hip.py does) instead of calling through a stale prototype. */
-#define CFSAR_ABI_VERSION 7
+#define CFSAR_ABI_VERSION 8
 int cfsar_abi_version(void);
 const char* cfsar_last_error(void);
 
@@ -63,6 +63,16 @@ int cfsar_preprocess_frames(const uint8_t* frames, float* out, int T, int H, int
  * columns >= 3*P*P are zero-filled.  P must be even. */
 int cfsar_im2col_patches(const float* frames, void* out, int out_dtype, int F, int H, int W, int P, int k_pad,
                          cfsar_stream_t stream);
+
+/* ---- A2 in ONE launch (few_shot.py:659, 672-676) for 16 x 16 patches and 16-bit operands: conv1 as a GEMM whose rows are gathered
+ * straight from the fp32 NCHW frames (no patch matrix), + pos[1 + p], scattered behind each frame's class-token row, and the class-token rows
+ * cls + pos[0] themselves:  x[f*ntok + 1 + p, :] = patch(f, p) @ W.T + pos[1 + p],  x[f*ntok, :] = cls + pos[0],  ntok = (H/16)*(W/16) + 1.
+ * frames [F,3,H,W] fp32; W [D, ldw >= 768] (w_dtype CFSAR_BF16 | CFSAR_F16; column k = c*256 + dy*16 + dx = conv1.weight.reshape(D, 768));
+ * pos [ntok, D] fp32, cls [D] fp32; x [F*ntok, D] (x_dtype CFSAR_F16: the 16-bit modes' residual stream).  Frames are rounded to w_dtype in
+ * registers; every output element is bit-identical to cfsar_im2col_patches + cfsar_gemm_ex (row remap) + cfsar_cls_rows_ex, which remain the
+ * path for other patch sizes and for fp32 operands.  Replaces: self.conv1(x) ... x + positional_embedding (few_shot.py:672-676). */
+int cfsar_patch_embed(const float* frames, const void* W, int w_dtype, const float* pos, const float* cls, void* x, int x_dtype,
+                      int F, int H, int Wd, int P, int D, int ldw, cfsar_stream_t stream);
 
 /* ---- A2 stage 3: class-token rows.  x[f*ntok*D + d] = cls[d] + pos[d]  (few_shot.py:675-676). */
 int cfsar_cls_rows(float* x, const float* cls, const float* pos, int F, int ntok, int D, cfsar_stream_t stream);

@@ -412,6 +412,19 @@ def test_developer_options_are_constructor_arguments():
     assert maxdiff(lo[0], g["logits"]) < 2.5e-3                   # round 3's one-word, packed-add mode: 5e-4 ... 1.8e-3 on the goldens
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_fused_patch_embedding_leaves_the_logits_bit_identical(precision):
+    """the 16-bit modes of the ViT-B/16 tower gather the patch-embed GEMM's rows from the frames inside the GEMM (cfsar_patch_embed,
+    one launch instead of three, no patch matrix); the developer option fused_patch=False keeps the im2col form.  Same roundings, same MFMA
+    order: the episode's logits are the same bits."""
+    g = load_golden("cfg2_B16_5w1s_T8")
+    m = g["meta"]
+    a, sd, tt, te, ep = case_inputs(m)
+    l_f, c_f = run_engine(m, a, sd, tt, te, [ep], precision)
+    l_u, c_u = run_engine(m, a, sd, tt, te, [ep], precision, vit_options={"fused_patch": False})
+    assert torch.equal(l_f, l_u) and torch.equal(c_f, c_u), (maxdiff(l_f, l_u), maxdiff(c_f, c_u))
+
+
 def test_fp16_raw_stream_correction_switch(monkeypatch):
     """The fp16 mode's LN-folded GEMMs take their per-frame correction in the raw-stream form by default (no pass over x: the stream's per-frame
     mean follows its updates through two [frames, K] x [K, D] GEMMs per block); the developer option fp16_rawmeans=False (tests/_cases.py maps CFSAR_FP16_RAWMEANS=0 to it) restores the normalised-mean form with its

@@ -158,6 +158,45 @@ def test_im2col_and_cls_rows(hip, P, res):
     assert torch.all(got[:, 1:] == 0)
 
 
+@pytest.mark.parametrize("wd,xd", [("bf16", "f16"), ("f16", "f16")])
+@pytest.mark.parametrize("F_,res,D", [(7, 224, 768), (3, 32, 128), (5, 64, 192), (80, 224, 768)])
+def test_patch_embed_fused_equals_the_three_launch_form_bitwise(hip, wd, xd, F_, res, D):
+    """SURVEY K1 (few_shot.py:672-676): cfsar_patch_embed gathers the GEMM's rows from the fp32 frames itself.  Same rounding of the frames, same
+    K order of the MFMA chain: every element equals cfsar_im2col_patches + cfsar_gemm (row remap, pos residual) + cfsar_cls_rows bit for bit
+    (ragged row tiles, a partial column tile (D = 192), 1 ... 196 patches per frame); and the whole thing against an fp32 reference."""
+    tw, tx = {"bf16": torch.bfloat16, "f16": torch.float16}[wd], {"bf16": torch.bfloat16, "f16": torch.float16}[xd]
+    g = res // 16
+    npatch, ntok = g * g, g * g + 1
+    frames = _rand(F_, 3, res, res, seed=31).cuda()
+    w = (_rand(D, 768, seed=32) * 768 ** -0.5).to(tw).cuda()
+    pos, cls = (_rand(ntok, D, seed=33) * 0.3).cuda(), _rand(D, seed=34).cuda()
+    assert hip.patch_embed_ok(16, w, torch.empty(1, D, device="cuda", dtype=tx))
+    x = torch.full((F_ * ntok, D), 7.0, device="cuda", dtype=tx)
+    hip.patch_embed(frames, w, pos, cls, x)
+    patches = torch.empty(F_ * npatch, 768, device="cuda", dtype=tw)
+    hip.im2col_patches(frames, patches, 16)
+    y = torch.full((F_ * ntok, D), 7.0, device="cuda", dtype=tx)
+    hip.gemm(patches, w, y, residual=pos, M=F_ * npatch, N=D, K=768, ldo=D, ldr=D, row_group=npatch, row_gap=1, row_off=1, res_mod=npatch, res_off=1)
+    hip.cls_rows(y, cls, pos, F_, ntok, D)
+    torch.cuda.synchronize()
+    assert torch.equal(x.view(torch.int16), y.view(torch.int16)), maxdiff(x.float().cpu(), y.float().cpu())
+    ref = (patches.float() @ w.float().t()).reshape(F_, npatch, D) + pos[1:]
+    ref = torch.cat([(cls + pos[0]).expand(F_, 1, D), ref], 1).reshape(F_ * ntok, D)
+    assert maxdiff(x.float().cpu(), ref.cpu()) < 6e-3
+
+
+def test_patch_embed_rejects_what_it_does_not_serve(hip):
+    frames = _rand(2, 3, 28, 28, seed=35).cuda()
+    w = _rand(64, 768, seed=36).to(torch.bfloat16).cuda()
+    pos, cls = _rand(5, 64, seed=37).cuda(), _rand(64, seed=38).cuda()
+    x = torch.empty(2 * 5, 64, device="cuda", dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="patch size 14"):
+        hip.patch_embed(frames, w, pos, cls, x, patch=14)
+    assert not hip.patch_embed_ok(14, w, x) and not hip.patch_embed_ok(16, w.float(), x) and not hip.patch_embed_ok(16, w, x.bfloat16())
+    with pytest.raises(RuntimeError, match="fp16 residual stream"):
+        hip.patch_embed(_rand(2, 3, 32, 32, seed=39).cuda(), w, pos, cls, x.bfloat16())
+
+
 def _ref_attention(qkv, F_, ntok, D, heads):
     q, k, v = qkv.float().reshape(F_, ntok, 3, heads, 64).permute(2, 0, 3, 1, 4)
     att = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
