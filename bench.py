@@ -99,6 +99,21 @@ class GemmTimer:
         # 2 M N K of the reference op: a split-weight launch executes twice that on the matrix cores)
         for name in ("gemm", "gemm_lnfold", "gemm_lnfold_partials", "gemm_residual_stats", "gemm_lnfold_hp", "gemm_residual_wide"):
             wrap(name)
+        # the patch-embed GEMM that gathers its rows from the frames (cfsar_patch_embed): 2 x (frames x patches) x D x 768
+        orig_pe = self.hip.patch_embed
+
+        def timed_pe(frames, w, pos, cls, x, *a, **k):
+            if not self.enabled:
+                return orig_pe(frames, w, pos, cls, x, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_pe(frames, w, pos, cls, x, *a, **k)
+            e.record()
+            self.events.append((s, e))
+            self.flops += 2.0 * frames.shape[0] * (pos.shape[0] - 1) * w.shape[0] * 768
+            self.launches += 1
+            return r
+        self.hip.patch_embed = timed_pe
 
     def result(self):
         ms = sum(s.elapsed_time(e) for s, e in self.events)

@@ -37,12 +37,12 @@ w = agg("$OUT/write/p_counter_collection.csv")
 traffic = {}
 tot = n = 0
 for k in f:
-    if "gemm" not in k: continue
+    if "gemm" not in k and "patch_embed" not in k: continue
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM)
     fv, wv = f[k]["FETCH_SIZE"], w.get(k, {}).get("WRITE_SIZE", [0.0])
     fb, wb = sum(fv) * 1024 * 2, sum(wv) * 1024
     traffic[k] = {"launches": len(fv), "fetch_bytes_per_launch": fb / len(fv), "write_bytes_per_launch": wb / max(len(wv), 1)}
-    if "vit_gemm" in k or "gemm_kernel_p" in k:
+    if "vit_gemm" in k or "gemm_kernel_p" in k or "patch_embed_kernel" in k:
         tot += fb + wb; n += len(fv)
 import hashlib, socket
 h = hashlib.sha256()
