@@ -7,6 +7,10 @@
 
 #include "common.h"
 
+#ifdef CFSAR_DEV
+extern int g_cfsar_walk_enable, g_cfsar_walk_phase;      // experiment: gemm_vit.hip (dbg bit 25 of cfsar_debug_set_vit_dbg)
+#endif
+
 namespace {
 
 typedef unsigned att_u32x4 __attribute__((ext_vector_type(4)));
@@ -260,7 +264,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const T* __
     char* sK = smem;
     char* sV = smem + KROWS * 128;
 
-    const int h = blockIdx.x, f = blockIdx.y;
+    const int h = blockIdx.x;
+#ifdef CFSAR_DEV
+    const int f = (dbg & 64) ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;      // experiment: frames from the end (see gemm_vit.hip, dbg bit 24)
+#else
+    const int f = blockIdx.y;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t ld = (size_t)3 * D;
@@ -728,6 +737,7 @@ int g_attn_dbg = 0;
 #endif
 static inline int attn_dbg() {
 #ifdef CFSAR_DEV
+    if (g_cfsar_walk_enable) return g_attn_dbg | ((g_cfsar_walk_phase++ & 1) << 6);
     return g_attn_dbg;
 #else
     return 0;

@@ -31,6 +31,10 @@
 
 #include "gemm_vit_epi.h"
 
+#ifdef CFSAR_DEV
+int g_cfsar_walk_enable = 0, g_cfsar_walk_phase = 0;      // experiment (dbg bit 25 of cfsar_debug_set_vit_dbg): see attention.hip too
+#endif
+
 namespace {
 
 // OPATH 0: register-staged operands (global_load_dwordx4 -> VGPR -> ds_write_b128), loads two K tiles ahead.
@@ -73,6 +77,9 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
         int tm, tn;
         tile_of(lin, tiles_m, p.tiles_n, p.group, p.colfast, tm, tn);
+#ifdef CFSAR_DEV
+        if (p.dbg & (1 << 24)) tm = tiles_m - 1 - tm;      // experiment: row bands walked from the end (the producer's most recent rows first: Infinity Cache)
+#endif
         m0 = tm * TMv;
         n0 = tn * TN;
 #ifdef CFSAR_DEV
@@ -736,6 +743,7 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
         return cfsar_fail("cfsar_gemm_residual_stats: head-blocked A needs M a multiple of tokens");
 #ifdef CFSAR_DEV
     a.dbg = c.dbg;
+    if (g_cfsar_walk_enable) a.dbg |= ((g_cfsar_walk_phase++ & 1) << 24);      // experiment: alternate the walk direction launch by launch
     a.stagger_unit = g_stagger_unit;
     a.trace = g_trace;
 #endif
@@ -805,7 +813,7 @@ int cfsar_vit_policy_opath(int K) { return vit_policy_opath(K); }      // the cf
 #include "../../include/clipfsar_hip_dev.h"
 // dev builds only: operand path / store policy of cfsar_gemm_lnfold and cfsar_gemm_residual_stats; -1 = product policy
 extern "C" void cfsar_debug_set_vit_paths(int opath, int store) { g_force_opath = opath; g_force_store = store; }
-extern "C" void cfsar_debug_set_vit_dbg(int dbg) { g_force_dbg = dbg; }
+extern "C" void cfsar_debug_set_vit_dbg(int dbg) { g_force_dbg = dbg & ~(1 << 25); g_cfsar_walk_enable = (dbg >> 25) & 1; g_cfsar_walk_phase = 0; }
 // trace buffer ([grid][64][4] long long, device memory; NULL = off) and stagger unit (x 64 cycles) for dbg bit 128
 extern "C" void cfsar_debug_set_vit_trace(void* trace, int stagger_unit) { g_trace = static_cast<long long*>(trace); g_stagger_unit = stagger_unit; }
 #endif
