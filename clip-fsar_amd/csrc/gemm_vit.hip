@@ -803,7 +803,8 @@ int vit_policy_opath(int K, int kind = -1) {
 }
 int vit_policy_store(int dflt) {
 #ifdef CFSAR_DEV
-    if (g_force_store >= 0) return g_force_store;
+    // (dflt names the kind of launch: 2 = LN-folded, 0 = residual; ablation bits 21 / 22 keep the product policy for that kind)
+    if (g_force_store >= 0 && !((dflt == 2 && (g_force_dbg & (1 << 21))) || (dflt == 0 && (g_force_dbg & (1 << 22))))) return g_force_store;
 #endif
     return dflt;
 }

@@ -191,8 +191,11 @@ def patch_embed(frames, w, pos, cls, x, patch=16):
     F_, C, H, W = frames.shape
     assert C == 3
     D = pos.shape[1]
-    if x.shape[-1] != D or not x.is_contiguous():
-        raise RuntimeError("patch_embed: x must be contiguous [.., %d]" % D)
+    ntok = (H // patch) * (W // patch) + 1
+    if pos.shape[0] != ntok or cls.numel() != D or w.shape[0] != D:
+        raise RuntimeError("patch_embed: pos must be [%d, D], cls [D], w [D, >= 768]; got pos %s, cls %s, w %s" % (ntok, tuple(pos.shape), tuple(cls.shape), tuple(w.shape)))
+    if x.shape[-1] != D or not x.is_contiguous() or x.numel() < F_ * ntok * D:
+        raise RuntimeError("patch_embed: x must be contiguous with at least %d rows of %d, got %s" % (F_ * ntok, D, tuple(x.shape)))
     _check(lib().cfsar_patch_embed(_dev(frames, torch.float32, "frames"), _dev(w, None, "w"), _code(w.dtype), _dev(pos, torch.float32, "pos"),
                                    _dev(cls, torch.float32, "cls"), _dev(x, None, "x"), _code(x.dtype), F_, H, W, patch, D, w.stride(0),
                                    _stream()), "cfsar_patch_embed")

@@ -193,6 +193,10 @@ def test_patch_embed_rejects_what_it_does_not_serve(hip):
     with pytest.raises(RuntimeError, match="patch size 14"):
         hip.patch_embed(frames, w, pos, cls, x, patch=14)
     assert not hip.patch_embed_ok(14, w, x) and not hip.patch_embed_ok(16, w.float(), x) and not hip.patch_embed_ok(16, w, x.bfloat16())
+    with pytest.raises(RuntimeError, match="at least 10 rows"):                     # a stream too short for the frames: refused before the launch
+        hip.patch_embed(_rand(2, 3, 32, 32, seed=39).cuda(), w, pos, cls, x[:9])
+    with pytest.raises(RuntimeError, match="pos must be"):
+        hip.patch_embed(_rand(2, 3, 64, 64, seed=39).cuda(), w, pos, cls, x)
     with pytest.raises(RuntimeError, match="fp16 residual stream"):
         hip.patch_embed(_rand(2, 3, 32, 32, seed=39).cuda(), w, pos, cls, x.bfloat16())
 
