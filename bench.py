@@ -251,14 +251,15 @@ def golden_parity(logits0, precision, config="cfg2"):
 
 def default_episodes_per_step(cfgname, dry=False):
     """The batch the product harness itself picks for a config without TEST.EPISODES_PER_STEP (datasets/base/builder.py::auto_episodes_per_step):
-    ViT towers -> clip_fsar_amd.utils.batching (full rounds of the persistent GEMM grid within 2 880 frames and the 32-bit offset limit), RN50 -> 16."""
+    ViT towers -> clip_fsar_amd.utils.batching (full rounds of the persistent GEMM grid within 2 880 frames and the 32-bit offset limit), RN50 -> what
+    2 560 frames hold (32)."""
     if dry:
         return 16
     from clip_fsar_amd.utils.batching import FRAME_CAP, pick_episodes_per_step
     c = CONFIGS[cfgname]
     a = synth.ARCHS[c["arch"]]
     if a.get("kind") == "rn":
-        return 16
+        return max(1, 2560 // ((WAY * c["shot"] + WAY * QPC) * c["T"]))     # datasets/base/builder.py: RN_FRAME_CAP
     ntok = (a["res"] // a["patch"]) ** 2 + 1
     fpe = (WAY * c["shot"] + WAY * QPC) * c["T"]
     return pick_episodes_per_step(fpe, ntok, a["width"], max_frames=min(FRAME_CAP, (2 ** 32 - 1) // (ntok * 4 * a["width"] * 2) - 1))

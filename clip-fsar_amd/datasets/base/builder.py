@@ -48,6 +48,7 @@ def build_dataset(name, cfg, split):
 
 
 _LOGGED_K = set()
+RN_FRAME_CAP = 2560                  # RN50 tower: frames per launch the default policy goes up to
 AUTO_EPISODES_PER_STEP_MAX = 36      # ViT towers: utils/batching.py picks k <= this so that the persistent GEMM grid's rounds come out full
 
 
@@ -56,7 +57,7 @@ def auto_episodes_per_step(cfg, n_local):
     feeds ONE episode per iteration, runs/test_net_few_shot.py:57-64, which leaves a quarter of this tower's throughput on the table).
     The loader collates k episodes -- per-episode results do not depend on k (tests/test_gpu_e2e.py: batch invariance).  ViT towers:
     utils/batching.py::pick_episodes_per_step -- the k that fills the rounds of the persistent GEMM grid best within the frames one tower
-    launch may carry (cfg2: 36 episodes = 2 880 frames); RN50: 16.  Bounded by the rank's episode count and by a quarter of the device's
+    launch may carry (cfg2: 36 episodes = 2 880 frames); RN50: what 2 560 frames hold (32 episodes of 80 frames).  Bounded by the rank's episode count and by a quarter of the device's
     TOTAL HBM over an upper estimate of one episode's footprint (two upload buffers of fp32 frames + the tower's activation workspace):
     deterministic per device and config, logged once."""
     if not (torch.cuda.is_available() and int(getattr(cfg, "NUM_GPUS", 1) or 0) > 0):
@@ -87,7 +88,10 @@ def auto_episodes_per_step(cfg, n_local):
         launch_frames = min(int(getattr(cfg.VIDEO.HEAD, "MAX_FRAMES_PER_LAUNCH", FRAME_CAP)), (2 ** 32 - 1) // (ntok * 4 * arch["width"] * 2) - 1)
         k = pick_episodes_per_step(frames, ntok, arch["width"], max_frames=max(frames, launch_frames), max_episodes=kcap)
     else:
-        k = min(16, kcap)
+        # RN50: as many episodes as one tower launch carries inside its 32-bit activation offsets, up to 2 560 frames (32 cfg-rn50 episodes:
+        # 635 episodes/s against 609 at 16, profiles/r05_bench_rn50_epoch_size.txt)
+        rn_frames = min(RN_FRAME_CAP, (2 ** 32 - 1) // (max(1, res // 2) ** 2 * int(arch["width"] if arch else 64) * 2) - 1)
+        k = max(1, min(kcap, rn_frames // max(1, frames)))
     key = (frames, res, k)
     if key not in _LOGGED_K:
         _LOGGED_K.add(key)

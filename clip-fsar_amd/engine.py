@@ -509,6 +509,10 @@ class HipResNet:
         self.kq = 32 if precision == "fp32" else 64
         self.E = arch["embed"]
         self.width, self.layers, self.heads = arch["width"], arch["layers"], arch["heads"]
+        # frames per tower launch: the widest activation (stem output / layer1 output: (res / 2)^2 x width, respectively (res / 4)^2 x 4 width
+        # elements per frame) must stay addressable with 32-bit byte offsets -- beyond it the convs fall back to slower forms (36 cfg-rn50
+        # episodes per call: 577 episodes/s against 635 at 32, profiles/r05_bench_rn50_epoch_size.txt); ClipFsarEngine chunks at this bound
+        self.max_frames_32bit = (2 ** 32 - 1) // ((arch["res"] // 2) ** 2 * self.width * (4 if precision == "fp32" else 2)) - 1
         if (self.width * 32) % self.heads or (self.width * 32) // self.heads > 128:
             raise ValueError("attention-pool head_dim must be <= 128")
 

@@ -454,6 +454,9 @@ def test_reference_shaped_cfg_reaches_the_batched_rate():
                   BN=NS(FREEZE=False), NUM_GPUS=1, NUM_SHARDS=1, RANDOM_SEED=18, LOG_PERIOD=100, OUTPUT_DIR="")
     cfg_ref, cfg_b = cfg_of(), cfg_of(EPISODES_PER_STEP=B)
     assert auto_episodes_per_step(cfg_ref, n) == 36 and auto_episodes_per_step(cfg_ref, 20) == 18
+    cfg_rn = cfg_of()
+    cfg_rn.VIDEO.HEAD.BACKBONE_NAME = "RN50"
+    assert auto_episodes_per_step(cfg_rn, 200) == 32 and auto_episodes_per_step(cfg_rn, 7) == 7      # RN50: 2 560 frames per launch (32-bit activation offsets)
     model, _ = build_model(cfg_ref)
     eps = [{k: torch.from_numpy(v).unsqueeze(0).cuda() for k, v in synth.make_episode(5, 1, 1, 8, a["res"], N_TEST, e, 18).items()} for e in range(4)]
     steps16 = [{k: torch.cat([eps[(j + i) % 4][k] for i in range(B)]) for k in eps[0]} for j in range(2)]
