@@ -78,6 +78,11 @@ __global__ __launch_bounds__(512, 2) void vit_gemm_kernel(VitGemmArgs p) {
         int tm, tn;
         tile_of(lin, tiles_m, p.tiles_n, p.group, p.colfast, tm, tn);
 #ifdef CFSAR_DEV
+        if (p.dbg & (1 << 26)) {                           // experiment: row bands INTERLEAVED over the XCDs (band = 8 * (i / tiles_n) + xcd: the chip works on one
+            const int i = b >> 3;                          // contiguous front of ~85 bands instead of 8 distant ranges); needs tiles_m % 8 == 0
+            tm = (i / p.tiles_n) * 8 + (b & 7);
+            tn = i - (i / p.tiles_n) * p.tiles_n;
+        }
         if (p.dbg & (1 << 24)) tm = tiles_m - 1 - tm;      // experiment: row bands walked from the end (the producer's most recent rows first: Infinity Cache)
 #endif
         m0 = tm * TMv;
@@ -801,6 +806,12 @@ int vit_policy_opath(int K, int kind = -1) {
     (void)kind;
     return K <= 1024 ? 2 : 0;
 }
+// Tile walk of the residual launches inside an XCD's range (tile_of): the long-K one (c_proj: three or four column tiles per row band, a weight matrix
+// larger than the L2) takes its tiles column-fastest in groups of 16 bands -- 2.4-3 % faster than the band-fastest groups of 8 that the short-K
+// launches keep (same-box A/B at 16 and 36 episodes, profiles/r05_forms_s31_colfast.log; out_proj, QKV and c_fc lose 1-3 % with it).  The walk
+// changes which workgroup computes a tile, never a value.
+int vit_policy_colfast(int K) { return K > 1024 ? 1 : 0; }
+int vit_policy_group(int K) { return K > 1024 ? 16 : 8; }
 int vit_policy_store(int dflt) {
 #ifdef CFSAR_DEV
     // (dflt names the kind of launch: 2 = LN-folded, 0 = residual; ablation bits 21 / 22 keep the product policy for that kind)
@@ -963,7 +974,7 @@ static int gemm_residual_stats_impl(const void* A, const void* W, void* x, const
     c.part = nullptr; c.part_slots = 0; c.part_eps = 0.f;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldx; c.ldr = ldx;
     c.out_dtype = CFSAR_F16; c.in_dtype = in_dtype; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
-    c.opath = vit_policy_opath(K, 1); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;
+    c.opath = vit_policy_opath(K, 1); c.store = vit_policy_store(0); c.group = vit_policy_group(K); c.colfast = vit_policy_colfast(K); c.dbg = 0;
     c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = ha_tokens;
 #ifdef CFSAR_DEV
     c.dbg = g_force_dbg & ((1 << 17) | (1 << 18));       // tile-height overrides only
@@ -992,7 +1003,7 @@ extern "C" int cfsar_gemm_residual_wide(const void* A, const void* W, void* x_hi
     c.part = nullptr; c.part_slots = 0; c.part_eps = 0.f;
     c.M = M; c.N = N; c.K = Kt; c.lda = lda; c.ldw = ldw; c.ldo = ldx; c.ldr = ldx;
     c.out_dtype = CFSAR_F16; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
-    c.opath = vit_policy_opath(Kt, 1); c.store = vit_policy_store(0); c.group = 8; c.colfast = 0; c.dbg = 0;
+    c.opath = vit_policy_opath(Kt, 1); c.store = vit_policy_store(0); c.group = vit_policy_group(Kt); c.colfast = vit_policy_colfast(Kt); c.dbg = 0;
     c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = 0;
     c.ka = K; c.wide = 1; c.res_lo = x_lo; c.corr = corr; c.corr_tokens = corr_tokens;
 #ifdef CFSAR_DEV
