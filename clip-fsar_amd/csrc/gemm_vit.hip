@@ -808,10 +808,12 @@ int vit_policy_opath(int K, int kind = -1) {
 }
 // Tile walk of the residual launches inside an XCD's range (tile_of): the long-K one (c_proj: three or four column tiles per row band, a weight matrix
 // larger than the L2) takes its tiles column-fastest in groups of 16 bands -- 2.4-3 % faster than the band-fastest groups of 8 that the short-K
-// launches keep (same-box A/B at 16 and 36 episodes, profiles/r05_forms_s31_colfast.log; out_proj, QKV and c_fc lose 1-3 % with it).  The walk
-// changes which workgroup computes a tile, never a value.
+// launches keep (same-box A/B at 16 and 36 episodes, profiles/r05_forms_s31_colfast.log; out_proj, QKV and c_fc lose 1-3 % with it).  The short-K
+// launches (QKV, c_fc, out_proj) walk band-fastest in groups of SIX bands: against groups of 8, c_fc -1.6 ... -2.2 %, out_proj 0 ... -2.4 %, QKV
+// 0 ... -0.9 % at 16 / 36 episodes, ViT-L/14 shapes 0 ... -1 % (groups of 2 / 3 / 4 / 16 / 32 are worse somewhere; profiles/r05_forms_s33_groups.log).
+// The walk changes which workgroup computes a tile, never a value.
 int vit_policy_colfast(int K) { return K > 1024 ? 1 : 0; }
-int vit_policy_group(int K) { return K > 1024 ? 16 : 8; }
+int vit_policy_group(int K) { return K > 1024 ? 16 : 6; }
 int vit_policy_store(int dflt) {
 #ifdef CFSAR_DEV
     // (dflt names the kind of launch: 2 = LN-folded, 0 = residual; ablation bits 21 / 22 keep the product policy for that kind)
@@ -870,7 +872,7 @@ static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const floa
     c.part = partial; c.part_slots = slots; c.part_eps = eps;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = 0;
     c.out_dtype = out_dtype; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F32; c.act = act; c.relu = 0;
-    c.opath = vit_policy_opath(K, 0); c.store = vit_policy_store(2); c.group = 8; c.colfast = 0; c.dbg = 0;
+    c.opath = vit_policy_opath(K, 0); c.store = vit_policy_store(2); c.group = vit_policy_group(K); c.colfast = vit_policy_colfast(K); c.dbg = 0;
     c.hb_tokens = hb_tokens; c.hb_heads = hb_heads; c.ha_tokens = 0;
 #ifdef CFSAR_DEV
     c.dbg = g_force_dbg;

@@ -1,8 +1,8 @@
 #!/bin/bash
-# r05 session 32: the long-K residual launch (c_proj) on the column-fastest tile walk: the default bench line with the previous library and with this one, alternated.
+# r05 session 32 (reused for every walk-policy step): the default bench line with the previous library and with this one, alternated.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r05_s32; mkdir -p $O
+O=gpurun_out/${OUTDIR:-r05_s32}; mkdir -p $O
 for i in 1 2 3; do
   CFSAR_LIB_PATH=clip-fsar_amd/libclipfsar_hip_prev.so timeout 900 python bench.py --no-cpu-baseline > $O/prev_$i.json 2> $O/prev_$i.err
   timeout 900 python bench.py --no-cpu-baseline > $O/new_$i.json 2> $O/new_$i.err
