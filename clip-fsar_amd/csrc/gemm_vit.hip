@@ -792,18 +792,23 @@ namespace {
 #ifdef CFSAR_DEV
 int g_force_opath = -1, g_force_store = -1, g_force_dbg = 0;
 #endif
-// Operand path by K (same-box A/B at 16 episodes, profiles/r03_gemm_anatomy.md): short K -- QKV, out_proj, c_fc -- takes the LDS-DMA
-// path with the pieces issued right behind the previous step's barrier (2); the long-K c_proj the register-staged path (0).
-// kind: 0 = LN-folded launch, 1 = residual launch (developer builds: ablation bits 21 / 22 keep the product policy for the LN-folded / the residual
+// Operand path (same-box A/B, profiles/r03_gemm_anatomy.md and round 5 below): the LN-folded short-K launches -- QKV, c_fc -- take the LDS-DMA
+// path with the pieces issued right behind the previous step's barrier (2); the residual launches of the one-word stream (out_proj, c_proj) and the
+// long-K c_proj of the two-word stream the register-staged path (0).
+// kind: 0 = LN-folded launch, 1 = residual launch, 2 = wide residual launch of the fp16 mode (developer builds: ablation bits 21 / 22 keep the product policy for the LN-folded / the residual
 // launches, so a forced form can be A/B'd on one kind of launch alone)
 int vit_policy_opath(int K, int kind = -1) {
 #ifdef CFSAR_DEV
-    const bool keep = (kind == 0 && (g_force_dbg & (1 << 21))) || (kind == 1 && (g_force_dbg & (1 << 22)));
+    const bool keep = (kind == 0 && (g_force_dbg & (1 << 21))) || ((kind == 1 || kind == 2) && (g_force_dbg & (1 << 22)));
     if (keep) { }
     else if (g_force_opath >= 10) { if (K <= 1024) return g_force_opath - 10; }     // 10 + path: short-K launches only
     else if (g_force_opath >= 0) return g_force_opath;
 #endif
-    (void)kind;
+    // kind 1 = the one-word residual launch (cfsar_gemm_residual_stats): register-staged for every K.  out_proj (K <= 1 024) is 4-5 % faster there
+    // than on the LDS-DMA path stand-alone at 1 ... 36 episodes and on the ViT-L/14 shape (profiles/r05_forms_s37_outproj_paths.log) and +0.3 % in the
+    // bench line of cfg2 and cfg4 (every one of nine alternations, profiles/r05_outproj_path_ab.log).  The wide instance of the fp16 mode (kind 2) LOSES
+    // 0.8 % with it (its register-staged form spills) and keeps the rule by K.
+    if (kind == 1) return 0;
     return K <= 1024 ? 2 : 0;
 }
 // Tile walk of the residual launches inside an XCD's range (tile_of): the long-K one (c_proj: three or four column tiles per row band, a weight matrix
@@ -1005,7 +1010,7 @@ extern "C" int cfsar_gemm_residual_wide(const void* A, const void* W, void* x_hi
     c.part = nullptr; c.part_slots = 0; c.part_eps = 0.f;
     c.M = M; c.N = N; c.K = Kt; c.lda = lda; c.ldw = ldw; c.ldo = ldx; c.ldr = ldx;
     c.out_dtype = CFSAR_F16; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
-    c.opath = vit_policy_opath(Kt, 1); c.store = vit_policy_store(0); c.group = vit_policy_group(Kt); c.colfast = vit_policy_colfast(Kt); c.dbg = 0;
+    c.opath = vit_policy_opath(Kt, 2); c.store = vit_policy_store(0); c.group = vit_policy_group(Kt); c.colfast = vit_policy_colfast(Kt); c.dbg = 0;
     c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = 0;
     c.ka = K; c.wide = 1; c.res_lo = x_lo; c.corr = corr; c.corr_tokens = corr_tokens;
 #ifdef CFSAR_DEV
