@@ -804,11 +804,12 @@ int vit_policy_opath(int K, int kind = -1) {
     else if (g_force_opath >= 10) { if (K <= 1024) return g_force_opath - 10; }     // 10 + path: short-K launches only
     else if (g_force_opath >= 0) return g_force_opath;
 #endif
-    // kind 1 = the one-word residual launch (cfsar_gemm_residual_stats): register-staged for every K.  out_proj (K <= 1 024) is 4-5 % faster there
-    // than on the LDS-DMA path stand-alone at 1 ... 36 episodes and on the ViT-L/14 shape (profiles/r05_forms_s37_outproj_paths.log) and +0.3 % in the
-    // bench line of cfg2 and cfg4 (every one of nine alternations, profiles/r05_outproj_path_ab.log).  The wide instance of the fp16 mode (kind 2) LOSES
-    // 0.8 % with it (its register-staged form spills) and keeps the rule by K.
-    if (kind == 1) return 0;
+    // (Round 5 measured the register-staged path on the short-K launches again: out_proj +0.3 %, the bf16 mode's QKV / c_fc +0.35 ... +0.66 % in the
+    // bench legs of the DEVELOPER library -- and +0.1 % / -1.3 % with the PRODUCT library, previous build against new build in separate processes:
+    // the two builds allocate registers differently (product: 21 spilled registers in the register-staged LN-folded instance, 0 in the LDS-DMA one;
+    // developer: 8 and 0; the developer DMA residual instance spills 4 where the product's spills none).  The rule by K stays; an operand-path A/B is
+    // only valid between product builds.  profiles/r05_lnfold_path_ab.log, r05_outproj_path_ab.log, r05_bench_outproj_path_ab.txt, r05_bench_lnfold_path_ab.txt)
+    (void)kind;
     return K <= 1024 ? 2 : 0;
 }
 // Tile walk of the residual launches inside an XCD's range (tile_of): the long-K one (c_proj: three or four column tiles per row band, a weight matrix
