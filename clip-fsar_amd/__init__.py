@@ -20,8 +20,8 @@ __version__ = "0.5.0"
 #           ViT-L/14 at standard contrast); regression bounds rms 5e-3, p99 1.2e-2, max 1.5e-2.  NOT inside the north star.
 # One constant per mode for the head's warning, bench.py's `parity` object and the tests (per-case bounds of the small cases: tests/_cases.py).
 NORTH_STAR_TOLERANCE = 1e-3
-LOGITS_TOLERANCE = {"fp32": 1e-3, "fp16": 1.5e-3, "bf16": 1.5e-2}
-LOGITS_STATISTIC = {"fp16": {"rms": 4e-4, "p99": 1e-3}, "bf16": {"rms": 5e-3, "p99": 1.2e-2}}
+LOGITS_TOLERANCE = {"fp32": 1e-3, "fp16_strict": 1e-3, "fp16": 1.5e-3, "bf16": 1.5e-2}
+LOGITS_STATISTIC = {"fp16_strict": {"rms": 3.2e-4, "p99": 8.5e-4}, "fp16": {"rms": 4e-4, "p99": 1e-3}, "bf16": {"rms": 5e-3, "p99": 1.2e-2}}
 # CLIP RN50 tower (N3): three equal error sources and no coherent term to remove (profiles/r04_rn50_fp16.md) -- over 13 reference episodes (8 frames,
 # high contrast; profiles/r05_parity_table.md) fp16 mode rms 9.4e-4 / p99 2.7e-3 / max 3.3e-3, bf16 7.5e-3 / 2.1e-2 / 2.5e-2; bounds ~ 1.5-2 x measured.
 # "fp32" (6e-6) is RN50's ONLY mode for the 1e-3 contract.

@@ -40,6 +40,42 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ f
     }
 }
 
+// Round 6 (the fp16_strict mode): the same gather with the fp32 pixel kept as TWO fp16 words, laid out for a three-pass GEMM against
+// [W_hi | W_hi | W_lo]: out row = [hi(k_pad) | lo(k_pad) | hi(k_pad)], hi = fp16(v), lo = fp16(v - hi).  The product hi W_hi + lo W_hi + hi W_lo
+// carries ~22 bits of both operands (the lo x lo term is 2^-24 of the result) in one fp32 accumulation chain of the ordinary fp16 MFMA GEMM.
+__global__ __launch_bounds__(256) void im2col_split_kernel(const float* __restrict__ frames, _Float16* __restrict__ out, int F,
+                                                           int H, int W, int P, int k_pad, long long total_pairs) {
+    const int gw = W / P, gh = H / P;
+    const int kp2 = k_pad >> 1;
+    const int kreal = 3 * P * P;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_pairs;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long row = idx / kp2;
+        const int k = (int)(idx - row * kp2) * 2;
+        float2 v = make_float2(0.f, 0.f);
+        if (k < kreal) {
+            const int px = (int)(row % gw);
+            const long long t = row / gw;
+            const int py = (int)(t % gh);
+            const long long f = t / gh;
+            const int c = k / (P * P);
+            const int rem = k - c * P * P;
+            const int dy = rem / P, dx = rem - dy * P;
+            v = *reinterpret_cast<const float2*>(frames + ((f * 3 + c) * H + (py * P + dy)) * (long long)W + px * P + dx);
+        }
+        h2 hi, lo;
+        hi[0] = (_Float16)v.x;
+        hi[1] = (_Float16)v.y;
+        lo[0] = (_Float16)(v.x - (float)hi[0]);
+        lo[1] = (_Float16)(v.y - (float)hi[1]);
+        _Float16* dst = out + row * (3LL * k_pad) + k;
+        *reinterpret_cast<h2*>(dst) = hi;
+        *reinterpret_cast<h2*>(dst + k_pad) = lo;
+        *reinterpret_cast<h2*>(dst + 2 * k_pad) = hi;
+    }
+}
+
 // P = 16 (ViT-B/16), bf16 rows: one thread moves one image-row segment of a patch, 16 floats (four 16-byte loads = one 64-byte
 // sector) -> 16 bf16 (two 16-byte stores).  Lane = dy + 16 * (patch within a group of 4): 16 consecutive lanes write 512 contiguous
 // bytes of one output row, a wave instruction writes 4 x 512 B and reads 64 whole 64-byte sectors.  No division in the inner path
@@ -427,6 +463,62 @@ __global__ __launch_bounds__(256) void f16_pair_to_f32_kernel(const _Float16* __
     if (i < n) out[i] = (float)hi[i] + (float)lo[i];
 }
 
+// Round 6 (fp16_strict): everything between the patch-embed GEMM and the first block in ONE pass, with no 16-bit rounding before the two-word stream:
+// row (f, t) = (t == 0 ? cls : tok[f (ntok - 1) + t - 1]) + pos[t]  (few_shot.py:675-676)  ->  ln_pre (:677, fp32, two-pass variance)  ->
+// x_hi = fp16(y), x_lo = fp16(y - x_hi).  One wave per row, the row in registers (D <= 1 024: <= 4 float4 per lane).
+__global__ __launch_bounds__(256) void embed_finish_pair_kernel(const float* __restrict__ tok, const float* __restrict__ cls,
+                                                                const float* __restrict__ pos, const float* __restrict__ w,
+                                                                const float* __restrict__ b, _Float16* __restrict__ xhi,
+                                                                _Float16* __restrict__ xlo, long long rows, int ntok, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long f = row / ntok;
+    const int t = (int)(row - f * ntok);
+    const float* src = t == 0 ? cls : tok + (f * (ntok - 1) + (t - 1)) * (long long)D;
+    const float* pr = pos + (long long)t * D;
+    const int nv = D >> 2;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = i * 64 + lane;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < nv) {
+            const float4 a = *reinterpret_cast<const float4*>(src + 4 * j), p4 = *reinterpret_cast<const float4*>(pr + 4 * j);
+            v[i] = make_float4(a.x + p4.x, a.y + p4.y, a.z + p4.z, a.w + p4.w);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i * 64 + lane < nv) {
+            const float a = v[i].x - mean, bq = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            ss += (a * a + bq * bq) + (c * c + d * d);
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = i * 64 + lane;
+        if (j < nv) {
+            const float4 w4 = *reinterpret_cast<const float4*>(w + 4 * j), b4 = *reinterpret_cast<const float4*>(b + 4 * j);
+            const float o[4] = {(v[i].x - mean) * rstd * w4.x + b4.x, (v[i].y - mean) * rstd * w4.y + b4.y,
+                                (v[i].z - mean) * rstd * w4.z + b4.z, (v[i].w - mean) * rstd * w4.w + b4.w};
+            h4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (_Float16)o[e];
+                l[e] = (_Float16)(o[e] - (float)h[e]);
+            }
+            *reinterpret_cast<h4*>(xhi + row * D + 4 * j) = h;
+            *reinterpret_cast<h4*>(xlo + row * D + 4 * j) = l;
+        }
+    }
+}
+
 // strided row gather in 4-byte words: one workgroup per row
 __global__ __launch_bounds__(256) void copy_rows_strided_kernel(const char* __restrict__ src, long long src_stride, char* __restrict__ dst,
                                                                 long long dst_stride, int words) {
@@ -488,6 +580,16 @@ extern "C" int cfsar_f16_pair_to_f32(const void* hi, const void* lo, float* out,
     return cfsar_check_launch("cfsar_f16_pair_to_f32");
 }
 
+extern "C" int cfsar_embed_finish_pair(const float* tok, const float* cls, const float* pos, const float* ln_w, const float* ln_b, void* x_hi,
+                                       void* x_lo, int F, int ntok, int D, float eps, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(tok && cls && pos && ln_w && ln_b && x_hi && x_lo, "cfsar_embed_finish_pair: null pointer");
+    CFSAR_REQUIRE(F > 0 && ntok > 1 && D > 0 && D % 4 == 0 && D <= 1024, "cfsar_embed_finish_pair: bad shape F=%d ntok=%d D=%d (D %% 4 == 0, D <= 1024)", F, ntok, D);
+    const long long rows = (long long)F * ntok;
+    hipLaunchKernelGGL(embed_finish_pair_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), tok, cls, pos,
+                       ln_w, ln_b, static_cast<_Float16*>(x_hi), static_cast<_Float16*>(x_lo), rows, ntok, D, eps);
+    return cfsar_check_launch("cfsar_embed_finish_pair");
+}
+
 extern "C" int cfsar_copy_rows_strided(const void* src, int64_t src_stride, void* dst, int64_t dst_stride, int rows, int row_bytes,
                                        cfsar_stream_t stream) {
     CFSAR_REQUIRE(src && dst && rows > 0 && row_bytes > 0 && row_bytes % 4 == 0 && src_stride % 4 == 0 && dst_stride % 4 == 0,
@@ -535,6 +637,19 @@ extern "C" int cfsar_im2col_patches(const float* frames, void* out, int out_dtyp
     else
         return cfsar_fail("cfsar_im2col_patches: bad dtype %d", out_dtype);
     return cfsar_check_launch("cfsar_im2col_patches");
+}
+
+extern "C" int cfsar_im2col_patches_split(const float* frames, void* out, int F, int H, int W, int P, int k_pad, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(frames && out, "cfsar_im2col_patches_split: null pointer");
+    CFSAR_REQUIRE(F > 0 && P > 0 && P % 2 == 0 && H % P == 0 && W % P == 0, "cfsar_im2col_patches_split: bad geometry");
+    CFSAR_REQUIRE(k_pad >= 3 * P * P && k_pad % 2 == 0, "cfsar_im2col_patches_split: k_pad too small / odd");
+    const long long rows = (long long)F * (H / P) * (W / P);
+    const long long pairs = rows * (k_pad / 2);
+    long long blocks = (pairs + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(im2col_split_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), frames,
+                       static_cast<_Float16*>(out), F, H, W, P, k_pad, pairs);
+    return cfsar_check_launch("cfsar_im2col_patches_split");
 }
 
 extern "C" int cfsar_cls_rows(float* x, const float* cls, const float* pos, int F, int ntok, int D,

@@ -48,8 +48,12 @@ class HipViT:
 
     def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda", stream_dtype=None, fp16_split=None, fp16_mcorr=None,
                  options=None):
+        # "fp16_strict" (round 6): the fp16 mode with the cheap error sources of profiles/r06_strict_budget.md removed -- see self.strict below
+        self.strict = precision == "fp16_strict"
+        if self.strict:
+            precision = "fp16"
         if precision not in ("bf16", "fp16", "fp32"):
-            raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
+            raise ValueError("precision must be 'bf16', 'fp16', 'fp16_strict' or 'fp32'")
         opt = dict(self.OPTIONS)
         for k, v in (options or {}).items():
             if k not in opt:
@@ -238,8 +242,22 @@ class HipViT:
                 blk["wb_pr"] = g(bb + "mlp.c_proj.weight").to(torch.bfloat16).contiguous()
         if self.mcorr & {"qkv", "fc"}:
             self.fuse_stats = False          # the token means of LayerNorm(x) need the finalized statistics in front of the GEMM
+        # fp16_strict (budget: tools/numerics_lab.py feats, profiles/r06_strict_budget.md).  Of the fp16 mode's feature-error variance
+        # a third enters BEFORE the first block: the patch embedding's 11-bit pixels and weights (0.7 % of the tower's FLOPs) and the two one-word
+        # stores of the stream in front of the blocks.  Strict: the patch-embed GEMM runs three fp16 passes [hi | lo | hi] x [W_hi | W_hi | W_lo]
+        # into an fp32 token matrix, and class token + pos + ln_pre write the two-word stream directly (cfsar_embed_finish_pair).
+        if self.strict:
+            if not (self.two_word and self.fold and D % 4 == 0 and D <= 1024):
+                raise ValueError("precision 'fp16_strict' needs the two-word stream (options fp16_wide / fp16_lo) and a width <= 1024")
+            self.fused_patch = False
+            w32 = wc
+            w_hi = w32.to(torch.float16)
+            w_lo = (w32 - w_hi.float()).to(torch.float16)
+            self.w_patch3 = torch.cat([w_hi, w_hi, w_lo], 1).contiguous()          # [D, 3 kpad]
         self._slots = {}
         self.max_frames_32bit = (2 ** 32 - 1) // (self.ntok * 4 * self.D * 2) - 1
+        if self.strict:                                                            # ... and of the three-word patch matrix [F (ntok - 1), 3 kpad]
+            self.max_frames_32bit = min(self.max_frames_32bit, (2 ** 32 - 1) // ((self.ntok - 1) * 3 * self.kpad * 2) - 1)
 
     # ------------------------------------------------------------------ workspace (caller-owned device buffers)
     def _workspace(self, F_, slot=0):
@@ -255,7 +273,10 @@ class HipViT:
                 o=torch.empty(M, D, device=dev, dtype=cd),
                 u=torch.empty(M, 4 * D, device=dev, dtype=cd),
                 c=torch.empty(F_, D, device=dev, dtype=torch.float32))
-            if not self.fused_patch:                                                         # the im2col matrix of the unfused patch embedding
+            if self.strict:                                                                  # three-word patch matrix, fp32 patch tokens
+                ws["patches"] = torch.empty(F_ * (self.ntok - 1), 3 * self.kpad, device=dev, dtype=cd)
+                ws["tok32"] = torch.empty(F_ * (self.ntok - 1), D, device=dev, dtype=torch.float32)
+            elif not self.fused_patch:                                                       # the im2col matrix of the unfused patch embedding
                 ws["patches"] = torch.empty(F_ * (self.ntok - 1), self.kpad, device=dev, dtype=cd)
             if self.fold:
                 ws["part"] = torch.empty(M, D // 64, 2, device=dev, dtype=torch.float32)    # partial row statistics
@@ -310,16 +331,23 @@ class HipViT:
                 raise RuntimeError("frames must be [F,3,%d,%d], got %s" % (self.arch["res"], self.arch["res"], tuple(fr.shape)))
             if self.fused_patch:
                 hip.patch_embed(fr, self.w_patch, self.pos, self.cls, x[off * N:(off + c) * N], self.P)
+            elif self.strict:
+                hip.im2col_patches_split(fr, ws["patches"][off * npatch:(off + c) * npatch], self.P)
             else:
                 hip.im2col_patches(fr, ws["patches"][off * npatch:(off + c) * npatch], self.P)
             off += c
-        if not self.fused_patch:
-            hip.gemm(ws["patches"], self.w_patch, x, residual=self.pos, M=F_ * npatch, N=D, K=self.kpad, ldo=D, ldr=D,
-                     row_group=npatch, row_gap=1, row_off=1, res_mod=npatch, res_off=1)
-            hip.cls_rows(x, self.cls, self.pos, F_, N, D)
-        hip.layernorm(x, x, self.ln_pre[0], self.ln_pre[1], M, D)                     # ln_pre (:677), in place
+        if self.strict:
+            # fp16_strict: patches [hi | lo | hi] x [W_hi | W_hi | W_lo]^T -> fp32 tokens; class token + pos + ln_pre -> x_hi, x_lo in one pass
+            hip.gemm(ws["patches"], self.w_patch3, ws["tok32"], M=F_ * npatch, N=D, K=3 * self.kpad, ldo=D)
+            hip.embed_finish_pair(ws["tok32"], self.cls, self.pos, self.ln_pre[0], self.ln_pre[1], x, ws["xlo"], F_, N, D)
+        else:
+            if not self.fused_patch:
+                hip.gemm(ws["patches"], self.w_patch, x, residual=self.pos, M=F_ * npatch, N=D, K=self.kpad, ldo=D, ldr=D,
+                         row_group=npatch, row_gap=1, row_off=1, res_mod=npatch, res_off=1)
+                hip.cls_rows(x, self.cls, self.pos, F_, N, D)
+            hip.layernorm(x, x, self.ln_pre[0], self.ln_pre[1], M, D)                 # ln_pre (:677), in place
         if taps is not None:
-            taps["ln_pre"] = x[:M].clone()
+            taps["ln_pre"] = (x[:M].float() + ws["xlo"][:M].float()) if self.strict else x[:M].clone()
         xc_final = None
         es = x.element_size()
 
@@ -330,7 +358,7 @@ class HipViT:
         if self.fold:
             part, rstat, S = ws["part"], ws["rstat"], D // 64
             xlo = ws["xlo"] if self.two_word else None
-            if xlo is not None:
+            if xlo is not None and not self.strict:
                 xlo[:M].zero_()                                                       # memset: the stream enters the blocks as ln_pre's fp16 output
             hip.row_stats(x, rstat, M, D)                                             # statistics of ln_pre's output
             prune = self.prune_last and taps is None
@@ -496,6 +524,8 @@ class HipResNet:
     IMPLICIT_MIN_TILES = 128          # 256x256 output tiles below which the implicit-GEMM conv would leave CUs idle
 
     def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda"):
+        if precision == "fp16_strict":
+            raise ValueError("precision 'fp16_strict' exists for the ViT towers; the RN50 tower's mode for the 1e-3 contract is 'fp32'")
         if precision not in ("bf16", "fp16", "fp32"):
             raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
         self.arch = dict(arch)

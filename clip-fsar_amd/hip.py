@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (imported first so that torch's libamdhip64.so.7 is the HIP runtime the library binds to)
 
 F32, BF16, F16 = 0, 1, 2
-ABI_VERSION = 8          # CFSAR_ABI_VERSION of include/clipfsar_hip.h this file's SIGNATURES were written against
+ABI_VERSION = 9          # CFSAR_ABI_VERSION of include/clipfsar_hip.h this file's SIGNATURES were written against
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -29,6 +29,8 @@ SIGNATURES = {
     "cfsar_version": [],
     "cfsar_preprocess_frames": [_c_p, _c_p] + [_c_int] * 8 + [_c_p, _c_p, _c_p],
     "cfsar_im2col_patches": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_im2col_patches_split": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_embed_finish_pair": [_c_p] * 7 + [_c_int, _c_int, _c_int, _c_f, _c_p],
     "cfsar_patch_embed": [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_cls_rows": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_p],
     "cfsar_layernorm": [_c_p, _c_i64, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_int, _c_int, _c_f, _c_p],
@@ -178,6 +180,24 @@ def im2col_patches(frames, out, patch):
     assert C == 3
     _check(lib().cfsar_im2col_patches(_dev(frames, torch.float32, "frames"), _dev(out, None, "out"), _code(out.dtype),
                                       F_, H, W, patch, out.shape[1], _stream()), "cfsar_im2col_patches")
+
+
+def im2col_patches_split(frames, out, patch):
+    """frames [F,3,H,W] f32 -> out [F*(H/P)*(W/P), 3 k_pad] fp16 = [hi | lo | hi] of every pixel (cfsar_im2col_patches_split: the fp16_strict
+    mode's three-pass patch-embed GEMM against [W_hi | W_hi | W_lo])."""
+    F_, C, H, W = frames.shape
+    assert C == 3 and out.shape[1] % 3 == 0
+    _check(lib().cfsar_im2col_patches_split(_dev(frames, torch.float32, "frames"), _dev(out, torch.float16, "out"), F_, H, W, patch,
+                                            out.shape[1] // 3, _stream()), "cfsar_im2col_patches_split")
+
+
+def embed_finish_pair(tok, cls, pos, ln_w, ln_b, x_hi, x_lo, F_, ntok, D, eps=1e-5):
+    """(class token | patch-embed rows) + pos -> ln_pre -> the two-word fp16 stream, no 16-bit rounding in between (cfsar_embed_finish_pair)."""
+    if tok.shape[0] < F_ * (ntok - 1) or tok.shape[1] != D or x_hi.shape[-1] != D or x_lo.shape[-1] != D:
+        raise RuntimeError("embed_finish_pair: tok must be [>= %d, %d], x_hi / x_lo [*, %d]" % (F_ * (ntok - 1), D, D))
+    _check(lib().cfsar_embed_finish_pair(_dev(tok, torch.float32, "tok"), _dev(cls, torch.float32, "cls"), _dev(pos, torch.float32, "pos"),
+                                         _dev(ln_w, torch.float32, "ln_w"), _dev(ln_b, torch.float32, "ln_b"), _dev(x_hi, torch.float16, "x_hi"),
+                                         _dev(x_lo, torch.float16, "x_lo"), F_, ntok, D, eps, _stream()), "cfsar_embed_finish_pair")
 
 
 def patch_embed_ok(patch, w, x):

@@ -46,7 +46,7 @@ typedef void* cfsar_stream_t;
 int cfsar_version(void);
 /* ABI revision: bumped whenever an exported signature changes or is added; a binding compares it with the CFSAR_ABI_VERSION it was
  * written against at load time (clip-fsar_amd/hip.py does) instead of calling through a stale prototype. */
-#define CFSAR_ABI_VERSION 8
+#define CFSAR_ABI_VERSION 9
 int cfsar_abi_version(void);
 const char* cfsar_last_error(void);
 
@@ -63,6 +63,12 @@ int cfsar_preprocess_frames(const uint8_t* frames, float* out, int T, int H, int
  * columns >= 3*P*P are zero-filled.  P must be even. */
 int cfsar_im2col_patches(const float* frames, void* out, int out_dtype, int F, int H, int W, int P, int k_pad,
                          cfsar_stream_t stream);
+
+/* Round 6 (the fp16_strict numerics mode): cfsar_im2col_patches with each fp32 pixel kept as TWO fp16 words, laid out for ONE three-pass fp16 GEMM
+ * against [W_hi | W_hi | W_lo]:  out [F*(H/P)*(W/P), 3 k_pad] fp16, row = [hi | lo | hi], hi = fp16(v), lo = fp16(v - hi) (pad columns zero).
+ * conv1 (few_shot.py:659, 672-674) then reaches the stream with ~22-bit operands instead of 11: the patch embedding is a quarter of the fp16
+ * mode's logits error (profiles/r06_strict_budget.md) and 0.7 % of the tower's FLOPs. */
+int cfsar_im2col_patches_split(const float* frames, void* out, int F, int H, int W, int P, int k_pad, cfsar_stream_t stream);
 
 /* ---- A2 in ONE launch (few_shot.py:659, 672-676) for 16 x 16 patches and 16-bit operands: conv1 as a GEMM whose rows are gathered
  * straight from the fp32 NCHW frames (no patch matrix), + pos[1 + p], scattered behind each frame's class-token row, and the class-token rows
@@ -315,6 +321,12 @@ int cfsar_frame_gemm(const void* A, const void* W, void* out, const float* bias,
                      cfsar_stream_t stream);
 /* out[i] = (float)hi[i] + (float)lo[i], i < n (the two-word stream -> fp32, e.g. in front of ln_post, few_shot.py:683). */
 int cfsar_f16_pair_to_f32(const void* hi, const void* lo, float* out, int64_t n, cfsar_stream_t stream);
+/* Round 6 (fp16_strict): class token + positional embedding + ln_pre (few_shot.py:675-677) in one pass with NO 16-bit rounding in front of the
+ * two-word stream: row (f, t) = (t == 0 ? cls : tok[f (ntok - 1) + t - 1]) + pos[t] -> LayerNorm(ln_w, ln_b; fp32) -> x_hi = fp16(y),
+ * x_lo = fp16(y - x_hi).  tok [F (ntok - 1), D] fp32 = the patch-embed GEMM's output (cfsar_im2col_patches_split + cfsar_gemm), cls [D],
+ * pos [ntok, D], x_hi / x_lo [F ntok, D] fp16.  D % 4 == 0, D <= 1024. */
+int cfsar_embed_finish_pair(const float* tok, const float* cls, const float* pos, const float* ln_w, const float* ln_b, void* x_hi, void* x_lo,
+                            int F, int ntok, int D, float eps, cfsar_stream_t stream);
 /* dst[r][0 .. row_bytes) = src[r][0 .. row_bytes), rows at byte strides src_stride / dst_stride (row_bytes % 4 == 0): the
  * class-token rows x[:, 0, :] of few_shot.py:683 and their statistics, gathered for the last block's class-token-only tail. */
 int cfsar_copy_rows_strided(const void* src, int64_t src_stride, void* dst, int64_t dst_stride, int rows, int row_bytes,

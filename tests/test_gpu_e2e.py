@@ -3,9 +3,11 @@ the real reference and (b) the CPU oracle, for every golden case; layer-by-layer
 consistency; the registry/builder drop-in surface.
 
 Tolerances: fp32 mode -- logits within 1e-3 of the reference (north star); observed ~1e-5.
-            fp16 mode -- the 16-bit mode that meets the north star on the ViT-B/16 configurations: cfg2 / cfg3 asserted < 1e-3 (measured
-            7.6e-4 / 7.5e-4); ViT-L/14 (cfg4, 24 layers, an extension the reference head rejects) and the tiny test architectures are
-            bounded at 2 x their measured deviation (tests/_cases.py: MEASURED_DLOGITS).
+            fp16_strict mode (round 6) -- the 16-bit mode held to the NORTH-STAR 1e-3 as a bound on every reference golden: each of the 455 logit
+            rows of the six multi-episode ViT sets and the three single goldens asserted < 1e-3 (test_strict_mode_*).
+            fp16 mode -- a STATISTIC (rms <= 4e-4, p99 <= 1e-3 over 65 rows per configuration), its tail bounded at LOGITS_TOLERANCE["fp16"] = 1.5e-3
+            on the multi-episode sets; the single goldens (deterministic, measured 3.8e-4 ... 7.6e-4) are asserted < 1e-3; the tiny test
+            architectures are bounded at 2 x their measured deviation (tests/_cases.py: MEASURED_DLOGITS).
             bf16 mode -- deviation is REPORTED; every case is bounded at 2 x its measured deviation (3e-3 ... 2.3e-2 on
             logits whose spread is ~1-3), and the fp32-mode argmax must be reproduced on clearly separated queries.
 """
@@ -230,32 +232,76 @@ def test_cfg2_full_size_fp32_and_bf16():
     lb, _ = run_engine(m, a, sd, tt, te, [ep], "bf16")
     assert maxdiff(lb[0], g["logits"]) < LOGITS_TOLERANCE["bf16"]
     lh, ch = run_engine(m, a, sd, tt, te, [ep], "fp16")
-    assert maxdiff(lh[0], g["logits"]) < LOGITS_TOLERANCE["fp16"]            # the 16-bit mode that meets the north star (measured 6.1e-4 ... 7.6e-4 on this episode over the round's builds; rms over 16 episodes 2.4e-4)
+    assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE                # single golden, deterministic: measured 6.1e-4 ... 7.6e-4 over the rounds' builds (the 1.5e-3 tail bound is for the multi-episode max only)
     assert torch.equal(lh[0].argmax(1), torch.from_numpy(g["logits"]).argmax(1))
 
 
-def test_timed_configuration_b16_equals_b1_and_golden():
-    """The configuration bench.py times (cfg2, 16 episodes per step, bf16): every episode of the batch gives the logits the same
-    episode gives alone (the single-episode call takes the two-stream small-batch path, the batch the one-stream path: row results
-    do not depend on the tile a row lands in), episode 0 is within the bf16 bound of the reference's logits, and the fp32 mode
-    at 16 episodes per step meets the 1e-3 tolerance against the reference golden."""
+def _harness_batch(cfgname):
+    """episodes per model call the product harness (utils/batching.py, datasets/base/builder.py) and bench.py pick: cfg2 36, cfg3 12, cfg4 11"""
+    import bench
+    return bench.default_episodes_per_step(cfgname)
+
+
+def test_timed_configuration_b36_equals_b1_and_golden():
+    """The configuration bench.py times (cfg2 at the harness's batch: 36 episodes = 2 880 frames per step, M = 567 360 rows -- the first regime
+    where activation buffers pass 2^31 bytes: u 3.49 GB, qkv 2.6 GB; VERDICT r5 item 5 / ADVICE r5): the FIRST, a MIDDLE and the LAST episode
+    of the batch give the logits the same episode gives alone, in bf16, fp16 and fp16_strict (the single-episode call takes the two-stream
+    small-batch path and 192-row tiles, the batch the one-stream path and 256-row tiles: row results do not depend on the tile a row lands
+    in); episode 0 is the reference golden; the fp32 mode at the same batch meets 1e-3 against it."""
+    B = _harness_batch("cfg2")
+    assert B == 36
     g = load_golden("cfg2_B16_5w1s_T8")
     m = g["meta"]
     a, sd, tt, te, ep0 = case_inputs(m)
-    eps = [ep0] + [case_inputs(m, episode=m["episode"] + e)[4] for e in range(1, 16)]
-    lb16, cb16 = run_engine(m, a, sd, tt, te, eps, "bf16")
-    assert maxdiff(lb16[0], g["logits"]) < LOGITS_TOLERANCE["bf16"]
-    lh16, _ = run_engine(m, a, sd, tt, te, eps, "fp16")
-    assert maxdiff(lh16[0], g["logits"]) < LOGITS_TOLERANCE["fp16"]          # fp16 mode at 16 episodes per step
-    for i in (0, 5, 15):
-        l1, c1 = run_engine(m, a, sd, tt, te, [eps[i]], "bf16")
-        # the ViT tower is bit-identical at any batch size; the fp32 tail picks its GEMM kernel by row count (skinny FMA kernel for
-        # one episode, MFMA kernel for 16): a different fp32 summation order = a few ulps of a logit of magnitude ~10
-        assert maxdiff(lb16[i], l1[0]) <= 4e-6, i
-        assert maxdiff(cb16[i], c1[0]) <= 4e-6, i
-    lf16, cf16 = run_engine(m, a, sd, tt, te, eps, "fp32")
-    assert maxdiff(lf16[0], g["logits"]) < 1e-3
-    assert maxdiff(cf16[0], g["class_logits"]) < 1e-3
+    eps = [ep0] + [case_inputs(m, episode=m["episode"] + e)[4] for e in range(1, B)]
+    for prec, tol in (("bf16", LOGITS_TOLERANCE["bf16"]), ("fp16", NORTH_STAR_TOLERANCE), ("fp16_strict", NORTH_STAR_TOLERANCE)):
+        lb, cb = run_engine(m, a, sd, tt, te, eps, prec)
+        assert maxdiff(lb[0], g["logits"]) < tol, prec
+        for i in (0, B // 2 - 1, B - 1):
+            l1, c1 = run_engine(m, a, sd, tt, te, [eps[i]], prec)
+            # the ViT tower is bit-identical at any batch size; the fp32 tail picks its GEMM kernel by row count (skinny FMA kernel for
+            # one episode, MFMA kernel for 36): a different fp32 summation order = a few ulps of a logit of magnitude ~10
+            assert maxdiff(lb[i], l1[0]) <= 4e-6, (prec, i, maxdiff(lb[i], l1[0]))
+            assert maxdiff(cb[i], c1[0]) <= 4e-6, (prec, i)
+    lf, cf = run_engine(m, a, sd, tt, te, eps, "fp32")
+    assert maxdiff(lf[0], g["logits"]) < 1e-3
+    assert maxdiff(cf[0], g["class_logits"]) < 1e-3
+
+
+@pytest.mark.parametrize("cfgname,case", [("cfg3", "cfg3_B16_5w5s_T8_mb"), ("cfg4", "cfg4_L14_5w1s_T16")])
+def test_harness_batch_cfg3_cfg4_last_episode_equals_b1(cfgname, case):
+    """cfg3 at 12 and cfg4 at 11 episodes per call (cfg4: M x 4 096 x 2 B = 86 % of the 32-bit byte-offset range of the hidden matrix): episode 0
+    against the reference golden, the LAST episode of the batch equal to the same episode alone (bf16 and fp16)."""
+    B = _harness_batch(cfgname)
+    assert B == {"cfg3": 12, "cfg4": 11}[cfgname]
+    g = load_golden(case)
+    m = g["meta"]
+    a, sd, tt, te, ep0 = case_inputs(m)
+    eps = [ep0] + [case_inputs(m, episode=m["episode"] + e)[4] for e in range(1, B)]
+    for prec, tol in (("bf16", bound(case, "bf16")), ("fp16", NORTH_STAR_TOLERANCE)):
+        lb, cb = run_engine(m, a, sd, tt, te, eps, prec)
+        assert maxdiff(lb[0], g["logits"]) < tol, prec
+        l1, c1 = run_engine(m, a, sd, tt, te, [eps[B - 1]], prec)
+        assert maxdiff(lb[B - 1], l1[0]) <= 4e-6, (prec, maxdiff(lb[B - 1], l1[0]))
+        assert maxdiff(cb[B - 1], c1[0]) <= 4e-6, prec
+
+
+def test_rn50_harness_batch_last_episode_equals_b1():
+    """RN50 tower at the harness's 32 episodes per call (2 560 frames: the stem output is 4.11e9 bytes, 4 % below 2^32): the last
+    episode of the batch equals the same episode alone, bf16 and fp16; episode 0 inside the tower's bounds of the reference golden."""
+    B = _harness_batch("rn50")
+    assert B == 32
+    g = load_golden("rn50_5w1s_T2")
+    m = dict(g["meta"])
+    m["T"] = 8
+    eps = [case_inputs(m, episode=300 + e)[4] for e in range(B)]
+    a, sd, tt, te, _ = case_inputs(m)
+    for prec in ("bf16", "fp16"):
+        lb, cb = run_engine(m, a, sd, tt, te, eps, prec)
+        for i in (0, B - 1):
+            l1, c1 = run_engine(m, a, sd, tt, te, [eps[i]], prec)
+            assert maxdiff(lb[i], l1[0]) <= 4e-6, (prec, i, maxdiff(lb[i], l1[0]))
+            assert maxdiff(cb[i], c1[0]) <= 4e-6, (prec, i)
 
 
 def test_cfg3_four_episodes_per_step():
@@ -270,7 +316,7 @@ def test_cfg3_four_episodes_per_step():
     lb, _ = run_engine(m, a, sd, tt, te, eps, "bf16")
     assert maxdiff(lb[0], g["logits"]) < LOGITS_TOLERANCE["bf16"]
     lh, _ = run_engine(m, a, sd, tt, te, eps, "fp16")
-    assert maxdiff(lh[0], g["logits"]) < LOGITS_TOLERANCE["fp16"]                      # round 4: 3.7e-4 ... 5.1e-4 over builds (r3's fp16 mode: 1.06e-3)
+    assert maxdiff(lh[0], g["logits"]) < NORTH_STAR_TOLERANCE                          # single golden: 3.7e-4 ... 5.1e-4 over builds (r3's fp16 mode: 1.06e-3)
     l1, _ = run_engine(m, a, sd, tt, te, [eps[2]], "bf16")
     assert maxdiff(lb[2], l1[0]) <= 4e-6
 
@@ -295,10 +341,10 @@ def test_cfg3_cfg4_full_size(name, tol_feat):
     assert maxdiff(lb[0], g["logits"]) < bound(name, "bf16")
     if True:                                                       # every tower has its fp16 mode (RN50: round 4)
         lh, _ = run_engine(m, a, sd, tt, te, [ep], "fp16")
-        # Round 4: the fp16 mode (single-rounding residual add, two-word stream, per-frame low-word correction of all four GEMMs' weights) is
-        # held to the NORTH-STAR 1e-3 on every full-size configuration: goldens 5.8e-4 (cfg2), 4.7e-4 (cfg3), 3.8e-4 (cfg4); over 64 fresh
-        # episodes each rms 2.7e-4 / 2.1e-4 / 2.3e-4 (an episode's largest deviation over 1e-3 in 2 / 0 / 1 of 64) -- profiles/r04_parity_table.md; round 3's fp16 mode: goldens 5.1e-4 / 1.06e-3 / 1.78e-3.
-        assert maxdiff(lh[0], g["logits"]) < LOGITS_TOLERANCE["fp16"], name
+        # The fp16 mode (single-rounding residual add, two-word stream, per-frame low-word correction of all four GEMMs' weights) on the single
+        # goldens: 5.8e-4 (cfg2), 4.7e-4 (cfg3), 3.8e-4 (cfg4) -- deterministic values, asserted at the north-star 1e-3 (the RN50 tower: its own
+        # bound); what the mode guarantees over MANY episodes is a statistic: test_modes_against_multi_episode_reference_goldens.
+        assert maxdiff(lh[0], g["logits"]) < (NORTH_STAR_TOLERANCE if "rn50" not in name else LOGITS_TOLERANCE["fp16"]), name
     print("%s: fp32 |dlogits| %.2e, bf16 |dlogits| %.3f" % (name, maxdiff(logits[0], g["logits"]), maxdiff(lb[0], g["logits"])))
 
 
@@ -376,6 +422,59 @@ def test_modes_against_multi_episode_reference_goldens(name):
     assert st["max"] < tol["bf16"] and st["argmax_equal"] >= st["rows"] - 2, st      # (a near-tie may flip: 1 of 325 rows measured)
 
 
+STRICT_SETS = ["mc_cfg2_B16_5w1s_T8", "hc_cfg2_B16_5w1s_T8", "hc_cfg3_B16_5w5s_T8_mb", "hc_cfg4_L14_5w1s_T16", "mc_cfg4_L14_5w1s_T16", "oc_cfg2_B16_5w1s_T8"]
+
+
+@pytest.mark.parametrize("name", STRICT_SETS)
+def test_strict_mode_every_reference_golden_row_inside_1e3(name):
+    """precision "fp16_strict" (VERDICT r5 item 1): the 16-bit mode whose contract is a BOUND on the reference's goldens -- every logit of every one
+    of the 13 reference episodes of each of the six full-size ViT sets (455 rows: standard and high contrast, 5-shot MERGE_BEFORE, ViT-L/14,
+    trained-CLIP-like outlier channels) within the north-star 1e-3, no episode over, no argmax flip; and tighter than the fp16 mode's statistic."""
+    from clip_fsar_amd import LOGITS_STATISTIC
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "multi_%s.npz" % name)):
+        pytest.skip("fixture not generated")
+    st = multi_case_stats(name, "fp16_strict")
+    print(name, "fp16_strict", st)
+    assert st["max"] < NORTH_STAR_TOLERANCE and st["episodes_over_1e-3"] == 0, st
+    assert st["argmax_equal"] == st["rows"], st
+    assert st["rms"] <= LOGITS_STATISTIC["fp16_strict"]["rms"] and st["p99"] <= LOGITS_STATISTIC["fp16_strict"]["p99"], st
+
+
+@pytest.mark.parametrize("name", ["cfg2_B16_5w1s_T8", "cfg3_B16_5w5s_T8_mb", "cfg4_L14_5w1s_T16"])
+def test_strict_mode_single_goldens(name):
+    g = load_golden(name)
+    m = g["meta"]
+    a, sd, tt, te, ep = case_inputs(m)
+    ls, _ = run_engine(m, a, sd, tt, te, [ep], "fp16_strict")
+    assert maxdiff(ls[0], g["logits"]) < NORTH_STAR_TOLERANCE, maxdiff(ls[0], g["logits"])
+    assert torch.equal(ls[0].argmax(1), torch.from_numpy(g["logits"]).argmax(1))
+
+
+def test_strict_mode_is_the_fp16_mode_plus_its_front_end():
+    """fp16_strict = the fp16 mode with the patch embedding in three fp16 passes ([hi | lo | hi] pixels x [W_hi | W_hi | W_lo]) into fp32 tokens and
+    class token + pos + ln_pre written straight into the two-word stream: ln_pre's tap is within 2e-6 of the fp32 mode's (the fp16 mode's:
+    one fp16 rounding, 5e-4), the RN50 tower refuses the mode by name."""
+    from clip_fsar_amd.engine import ClipFsarEngine, HipViT
+    g = load_golden("t197_5w1s_T2")
+    m = g["meta"]
+    a, hsd, tt, te, ep = case_inputs(m)
+    vsd = {k[len("backbone."):]: v for k, v in hsd.items() if k.startswith("backbone.")}
+    frames = ep["support_set"][:4].cuda()
+    taps32, taps16, tapss = {}, {}, {}
+    HipViT(a, vsd, precision="fp32").forward(frames, taps=taps32)
+    HipViT(a, vsd, precision="fp16").forward(frames, taps=taps16)
+    vs = HipViT(a, vsd, precision="fp16_strict")
+    assert vs.strict and vs.precision == "fp16" and not vs.fused_patch
+    vs.forward(frames, taps=tapss)
+    scale = float(taps32["ln_pre"].abs().max())
+    assert maxdiff(tapss["ln_pre"].cpu(), taps32["ln_pre"].cpu()) < 4e-6 * max(1.0, scale)
+    assert maxdiff(taps16["ln_pre"].float().cpu(), taps32["ln_pre"].cpu()) > 20 * maxdiff(tapss["ln_pre"].cpu(), taps32["ln_pre"].cpu())
+    gr = load_golden("rn_t_5w2s_T4")
+    ar, sdr, ttr, ter, _ = case_inputs(gr["meta"])
+    with pytest.raises(ValueError, match="fp16_strict"):
+        ClipFsarEngine(ar, sdr, ttr, ter, precision="fp16_strict", device="cuda")
+
+
 def test_fp16_mode_b16_equals_b1():
     """An episode's fp16-mode logits do not depend on the batch it is served in: the per-frame correction's k slot is chosen by the FRAME's
     parity (not by the tile a row falls into) and c_fc's per-frame means are summed per 32-row group (not per wave tile), so the 192- and
@@ -385,7 +484,7 @@ def test_fp16_mode_b16_equals_b1():
     a, sd, tt, te, ep0 = case_inputs(m)
     eps = [ep0] + [case_inputs(m, episode=m["episode"] + e)[4] for e in range(1, 16)]
     l16, c16 = run_engine(m, a, sd, tt, te, eps, "fp16")
-    assert maxdiff(l16[0], g["logits"]) < LOGITS_TOLERANCE["fp16"]
+    assert maxdiff(l16[0], g["logits"]) < NORTH_STAR_TOLERANCE
     for i in (0, 7, 15):
         l1, c1 = run_engine(m, a, sd, tt, te, [eps[i]], "fp16")
         assert maxdiff(l16[i], l1[0]) <= 4e-6, (i, maxdiff(l16[i], l1[0]))
@@ -436,5 +535,5 @@ def test_fp16_raw_stream_correction_switch(monkeypatch):
     l_raw, _ = run_engine(m, a, sd, tt, te, [ep], "fp16")
     monkeypatch.setenv("CFSAR_FP16_RAWMEANS", "0")
     l_norm, _ = run_engine(m, a, sd, tt, te, [ep], "fp16")
-    assert maxdiff(l_raw[0], g["logits"]) < LOGITS_TOLERANCE["fp16"] and maxdiff(l_norm[0], g["logits"]) < LOGITS_TOLERANCE["fp16"]
+    assert maxdiff(l_raw[0], g["logits"]) < NORTH_STAR_TOLERANCE and maxdiff(l_norm[0], g["logits"]) < NORTH_STAR_TOLERANCE
     assert not torch.equal(l_raw, l_norm)                       # the switch is live

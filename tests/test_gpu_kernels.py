@@ -185,6 +185,49 @@ def test_patch_embed_fused_equals_the_three_launch_form_bitwise(hip, wd, xd, F_,
     assert maxdiff(x.float().cpu(), ref.cpu()) < 6e-3
 
 
+@pytest.mark.parametrize("F_,res,P,D", [(3, 224, 16, 768), (2, 224, 14, 1024), (5, 32, 16, 192), (2, 28, 14, 64)])
+def test_strict_patch_embedding_front_end(hip, F_, res, P, D):
+    """fp16_strict (round 6; few_shot.py:672-677): cfsar_im2col_patches_split keeps every fp32 pixel as [hi | lo | hi] fp16 words, ONE fp16 GEMM
+    against [W_hi | W_hi | W_lo] gives the patch tokens in fp32, cfsar_embed_finish_pair adds class token / pos, applies ln_pre and writes the
+    two-word stream.  Against the fp32 op on the UNROUNDED operands: 22-bit operands leave ~1e-6 relative (the one-pass fp16 GEMM: 3e-4)."""
+    g = res // P
+    npatch, ntok = g * g, g * g + 1
+    kreal = 3 * P * P
+    kpad = (kreal + 63) // 64 * 64
+    frames = _rand(F_, 3, res, res, seed=61)
+    w32 = torch.zeros(D, kpad)
+    w32[:, :kreal] = _rand(D, kreal, seed=62) * kreal ** -0.5
+    pos, cls = _rand(ntok, D, seed=63) * 0.3, _rand(D, seed=64)
+    ln_w, ln_b = 1.0 + 0.1 * _rand(D, seed=65), 0.1 * _rand(D, seed=66)
+    patches = torch.empty(F_ * npatch, 3 * kpad, device="cuda", dtype=torch.float16)
+    hip.im2col_patches_split(frames.cuda(), patches, P)
+    pt = frames.reshape(F_, 3, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(F_ * npatch, kreal)
+    hi = pt.half()
+    lo = (pt - hi.float()).half()
+    pc = patches.cpu()
+    assert torch.equal(pc[:, :kreal], hi) and torch.equal(pc[:, 2 * kpad:2 * kpad + kreal], hi) and torch.equal(pc[:, kpad:kpad + kreal], lo)
+    if kpad > kreal:
+        assert float(pc[:, kreal:kpad].abs().max()) == 0.0 and float(pc[:, kpad + kreal:2 * kpad].abs().max()) == 0.0
+    w_hi = w32.half()
+    w3 = torch.cat([w_hi, w_hi, (w32 - w_hi.float()).half()], 1).contiguous().cuda()
+    tok = torch.empty(F_ * npatch, D, device="cuda", dtype=torch.float32)
+    hip.gemm(patches, w3, tok, M=F_ * npatch, N=D, K=3 * kpad, ldo=D)
+    ref_tok = pt.double() @ w32[:, :kreal].double().t()
+    scale = float(ref_tok.abs().max())
+    assert maxdiff(tok.cpu(), ref_tok.float()) < 4e-6 * max(1.0, scale), (maxdiff(tok.cpu(), ref_tok.float()), scale)
+    one_pass = hi.double() @ w_hi[:, :kreal].double().t()
+    assert maxdiff(one_pass.float(), ref_tok.float()) > 20 * maxdiff(tok.cpu(), ref_tok.float())           # what the extra passes buy
+    x_hi = torch.full((F_ * ntok, D), 7.0, device="cuda", dtype=torch.float16)
+    x_lo = torch.full((F_ * ntok, D), 7.0, device="cuda", dtype=torch.float16)
+    hip.embed_finish_pair(tok, cls.cuda(), pos.cuda(), ln_w.cuda(), ln_b.cuda(), x_hi, x_lo, F_, ntok, D)
+    rows = torch.cat([cls.expand(F_, 1, D), tok.cpu().reshape(F_, npatch, D)], 1) + pos
+    ref = orc.layer_norm(rows, ln_w, ln_b).reshape(F_ * ntok, D)
+    got = x_hi.float().cpu() + x_lo.float().cpu()
+    assert maxdiff(got, ref) < 3e-6 * max(1.0, float(ref.abs().max()))
+    assert maxdiff(x_hi.float().cpu(), ref) <= 1.01 * 2.0 ** -11 * float(ref.abs().max())       # hi alone is the fp16 rounding of the row
+    assert float(x_lo.float().abs().max()) <= 2.0 ** -11 * float(ref.abs().max())
+
+
 def test_patch_embed_rejects_what_it_does_not_serve(hip):
     frames = _rand(2, 3, 28, 28, seed=35).cuda()
     w = _rand(64, 768, seed=36).to(torch.bfloat16).cuda()
