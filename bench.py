@@ -241,7 +241,7 @@ def golden_parity(logits0, precision, config="cfg2"):
     if tuple(got.shape) != tuple(ref.shape):
         return {"checked": False, "reason": "shape %s vs golden %s" % (tuple(got.shape), tuple(ref.shape))}
     d = float((got - ref).abs().max())
-    from clip_fsar_amd import LOGITS_STATISTIC, LOGITS_TOLERANCE, NORTH_STAR_TOLERANCE
+    from clip_fsar_amd import FP16_TAIL_MAX_SEEN, LOGITS_STATISTIC, LOGITS_TOLERANCE, NORTH_STAR_TOLERANCE
     tol = LOGITS_TOLERANCE[precision]
     return {"checked": True, "against": "tests/golden/%s (reference fp32 logits)" % GOLDEN_FILE[config],
             "max_abs_dlogits": round(d, 6), "argmax_equal": bool(torch.equal(got.argmax(1), ref.argmax(1))),
@@ -251,7 +251,7 @@ def golden_parity(logits0, precision, config="cfg2"):
             "contract": {"fp32": "hard bound: every logit of every episode within 1e-3 (measured <= 7.6e-6)",
                          "fp16": "statistic, not a bound: rms <= %g and p99 <= %g of |dlogits| over 65 reference logit rows per configuration, standard "
                                  "and high-contrast episodes (measured rms 1.9-3.5e-4, p99 4.6-9.0e-4); an episode's largest deviation exceeds 1e-3 in about one "
-                                 "episode of 13-60 (max seen 1.16e-3)" % (LOGITS_STATISTIC["fp16"]["rms"], LOGITS_STATISTIC["fp16"]["p99"]),
+                                 "episode of 13-60 (max seen %.3g)" % (LOGITS_STATISTIC["fp16"]["rms"], LOGITS_STATISTIC["fp16"]["p99"], FP16_TAIL_MAX_SEEN),
                          "fp16_strict": "bound on the reference's goldens: every one of the 455 logit rows of the six 13-episode ViT sets (standard / high contrast, "
                                         "5-shot, ViT-L/14, outlier channels) within 1e-3, no episode over (tests/test_gpu_e2e.py::"
                                         "test_strict_mode_every_reference_golden_row_inside_1e3); fresh episodes: profiles/r06_strict_eval.md",
@@ -286,11 +286,12 @@ def executed_gflop_per_frame(arch, gflop, pruned):
     return gflop - (n_ - 1) * (20.0 * d_ * d_ + 4.0 * n_ * d_) / 1e9
 
 
-def timed_leg(cfgname, precision, B, steps, dev, timer, weights=None, batches=None, distinct=2, vit_options=None):
+def timed_leg(cfgname, precision, B, steps, dev, timer, weights=None, batches=None, distinct=2, vit_options=None, kernel_events=True):
     """A short extra measurement inside the default run: `steps` timed steps of B episodes of configuration
     `cfgname` in `precision` after two warm-up steps, with the GEMM launches' HIP events (-> roofline) and the configuration's golden
     parity (its first episode is the golden case).  `batches`: resident steps to reuse (the headline's); else `distinct` episodes are
-    generated and tiled to B per step.  `vit_options`: developer ablations (tools/fp16_stream_time.py), never set by this file.  Returns the leg's object."""
+    generated and tiled to B per step.  `vit_options`: developer ablations (tools/fp16_stream_time.py), never set by this file; `kernel_events` False (--no-kernel-events): no
+    HIP events around the launches, no roofline object.  Returns the leg's object."""
     from clip_fsar_amd import hip
     from clip_fsar_amd.engine import ClipFsarEngine
     c = CONFIGS[cfgname]
@@ -313,7 +314,7 @@ def timed_leg(cfgname, precision, B, steps, dev, timer, weights=None, batches=No
             torch.cuda.synchronize()
             if timer is not None:
                 timer.reset()
-                timer.enabled = True
+                timer.enabled = kernel_events
             t1 = time.perf_counter()
         b = batches[i % len(batches)]
         lg, _ = eng.forward(b["sup"], b["tgt"], b["sl"], b["rl"], way=WAY, T=c["T"], merge_before=c["merge_before"])
@@ -349,7 +350,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--episodes-per-step", type=int, default=0,
                     help="episodes per step and GPU; 0 (default) = the product harness's own choice (clip_fsar_amd.utils.batching: the batch that fills the "
-                         "rounds of the persistent GEMM grid, 36 for cfg2; RN50: 16)")
+                         "rounds of the persistent GEMM grid, 36 for cfg2, 12 for cfg3, 11 for cfg4; RN50: 32)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp16_strict", "fp32"])
     ap.add_argument("--pool", type=int, default=0, help="distinct synthetic episodes resident in HBM per rank (0 = one per slot of a step: "
                                                         "every step holds episodes-per-step DISTINCT episodes)")
@@ -629,10 +630,12 @@ def run(args):
         # The 16-bit mode that meets the north-star tolerance on the goldens (precision "fp16": IEEE-half operands everywhere, same kernels), timed
         # in the same process on the same resident steps: `value` stays BASELINE's bf16 configuration, this object says what the
         # conforming mode costs and where its GEMMs sit on the roofline.  `python bench.py --precision fp16` makes it the headline instead.
-        fp16_mode = timed_leg(args.config, "fp16", B, max(4, min(args.steps, 10)), dev, timer, weights=(sd, tt, te), batches=batches)
+        fp16_mode = timed_leg(args.config, "fp16", B, max(4, min(args.steps, 10)), dev, timer, weights=(sd, tt, te), batches=batches,
+                              kernel_events=not args.no_kernel_events)
         # ... and the 16-bit mode whose contract is a BOUND on the reference's goldens (precision "fp16_strict", round 6), same steps
         if ARCH.startswith("ViT"):
-            strict_mode = timed_leg(args.config, "fp16_strict", B, max(4, min(args.steps, 10)), dev, timer, weights=(sd, tt, te), batches=batches)
+            strict_mode = timed_leg(args.config, "fp16_strict", B, max(4, min(args.steps, 10)), dev, timer, weights=(sd, tt, te), batches=batches,
+                                    kernel_events=not args.no_kernel_events)
     if (not dry and rank == 0 and world == 1 and args.precision == "bf16" and args.config == "cfg2" and not args.no_config_legs
             and B * frames_per_ep > 160):
         # BASELINE configs[2..3] in front of the driver: 3 timed steps of the harness's batch (12 / 11 episodes), bf16 and fp16, with golden parity
@@ -645,7 +648,8 @@ def run(args):
                 w = ({k: torch.from_numpy(v) for k, v in synth.head_state_dict(cc["arch"], SEED).items()},
                      synth.text_features(N_TRAIN, aa["embed"], "train", SEED), synth.text_features(N_TEST, aa["embed"], "test", SEED))
             for prec in ("bf16", "fp16"):
-                config_legs["%s_%s" % (cname, prec)] = timed_leg(cname, prec, default_episodes_per_step(cname), 3, dev, timer, weights=w)
+                config_legs["%s_%s" % (cname, prec)] = timed_leg(cname, prec, default_episodes_per_step(cname), 3, dev, timer, weights=w,
+                                                                 kernel_events=not args.no_kernel_events)
             del w
 
     if rank == 0:
@@ -675,6 +679,7 @@ def run(args):
                        "parallelism": "episodes sharded over %d rank(s); one all-gather of accuracies" % world,
                        "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                                    ("bench.py self-spawn" if world > 1 else "single process")},
+            "episodes_per_step": B,
             "top1_acc_mean": round(float(gathered.mean().item()), 4),
             # per-rank rates of the timed region (value = all ranks' episodes / the slowest rank's time) and the collective's span
             "per_rank_episodes_per_s": {"min": round(args.steps * B / max(rank_elapsed), 3), "max": round(args.steps * B / min(rank_elapsed), 3),

@@ -14,12 +14,13 @@ __version__ = "0.5.0"
 #   fp32 -- a HARD per-episode bound: every logit of every episode within NORTH_STAR_TOLERANCE (measured <= 7.6e-6);
 #   fp16 -- a STATISTIC, not a bound: rms <= 4e-4 and 99th percentile <= 1e-3 of |dlogits| over >= 64 logit rows per configuration
 #           (measured rms 1.9-3.5e-4, p99 4.6-9.0e-4; ViT-B/16: the same at spread 0.9 and 3.1; ViT-L/14 at spread 4.4 is the upper end).  An
-#           episode's LARGEST deviation exceeds 1e-3 in about 1 episode of 13-60 (max seen 1.14e-3): LOGITS_TOLERANCE["fp16"] is that tail's
+#           episode's LARGEST deviation exceeds 1e-3 in about 1 episode of 13-60 (max seen: FP16_TAIL_MAX_SEEN): LOGITS_TOLERANCE["fp16"] is that tail's
 #           regression bound, 1.5e-3.  A caller that needs every episode inside 1e-3 uses "fp32";
 #   bf16 -- the throughput mode: rms 2.3-3.9e-3, p99 6.5-8.5e-3, max 1.0e-2 over the same episodes; 1 argmax flip in 325 rows (a near-tie of
 #           ViT-L/14 at standard contrast); regression bounds rms 5e-3, p99 1.2e-2, max 1.5e-2.  NOT inside the north star.
 # One constant per mode for the head's warning, bench.py's `parity` object and the tests (per-case bounds of the small cases: tests/_cases.py).
 NORTH_STAR_TOLERANCE = 1e-3
+FP16_TAIL_MAX_SEEN = 1.17e-3          # fp16 mode: the largest |dlogits| of any episode measured so far (profiles/r05_parity_fresh64.txt, 64 fresh cfg2 episodes); ONE place
 LOGITS_TOLERANCE = {"fp32": 1e-3, "fp16_strict": 1e-3, "fp16": 1.5e-3, "bf16": 1.5e-2}
 LOGITS_STATISTIC = {"fp16_strict": {"rms": 3.2e-4, "p99": 8.5e-4}, "fp16": {"rms": 4e-4, "p99": 1e-3}, "bf16": {"rms": 5e-3, "p99": 1.2e-2}}
 # CLIP RN50 tower (N3): three equal error sources and no coherent term to remove (profiles/r04_rn50_fp16.md) -- over 13 reference episodes (8 frames,

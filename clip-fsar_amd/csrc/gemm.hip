@@ -896,6 +896,10 @@ __global__ __launch_bounds__(NTHREADS2) void patch_embed_kernel(PatchArgs q) {
         f32x4 (&xnext)[8] = (kt & 1) ? xa : xb;                             // registers of slice kt + 1, then of slice kt + 3
         if constexpr (kt + 1 < nk) write_x(st1, xnext);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // last slice: its W
+        // The barrier publishes W of slice kt (two asm LDS-DMA pieces per wave, issued two iterations ago).  hipcc's own wait in front of write_x
+        // (for the registers of slice kt + 1, requested AFTER that DMA) already covers it -- but hipcc does not count the asm DMA, so the
+        // requirement is also stated explicitly: behind W(kt) this wave issued X(kt + 1): 8 loads, W(kt + 1): 2, X(kt + 2): 8.
+        if constexpr (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(10 + (kt + 2 < nk ? 8 : 0)) : "memory");
         __syncthreads();
         if constexpr (kt + 2 < nk) issue_w(st2, kt + 2);
         if constexpr (kt + 3 < nk) load_x(kt + 3, xnext);
@@ -1748,7 +1752,7 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
     if (in_dtype == CFSAR_F32 && out_dtype == CFSAR_F32 && res_dtype == CFSAR_F32 && res_mod == 0 && K % 128 == 0 && lda % 4 == 0 &&
         ldw % 4 == 0 && M <= 4096 && forced == 0 && (long)((M + 127) / 128) * ((N + 127) / 128) < 64)
         return launch_skinny2_inst<4>(a, s);       // (same-process A/B at 1 360 rows, us: N = 512, K = 512: 26 vs 39; K = 2 048: 80 vs 134; 640 x 512 x 768: 24 vs 54;
-                                                   //  N >= 1 536 stays on the fp32-MFMA kernel: 41 vs 73-90; tools/skinny_ab.py)
+                                                   //  N >= 1 536 stays on the fp32-MFMA kernel: 41 vs 73-90; skinny_ab.py (archived probe))
     // The ViT-block GEMMs at batch scale (bias [+ QuickGELU] -> bf16, or bias + fp16 residual -> fp16; >= two 256x256 tiles per
     // CU): the persistent kernel of gemm_vit.hip whose operand pipeline runs through the epilogues.  Dev builds: variant
     // 20 + 4 * opath + store forces it on any shape; dbg bit 256 = column-fastest tile walk, bits 9-11 = band group (see below).

@@ -341,7 +341,7 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[NMI][2], const VitGe
         if constexpr (COLSUM) {
             if (p.colsum != nullptr) {                       // kernel-uniform
                 // per element: a packed fp16 clamp, one v_fma_mix_f32 (half + magic) and ONE integer add of the raw bits (2.5 VALU slots; the
-                // fp32 clamp + selects form took 9, the masked two-accumulator form 5: the epilogue is instruction bound, tools/r04_runs/s23.sh)
+                // fp32 clamp + selects form took 9, the masked two-accumulator form 5: the epilogue is instruction bound, r04 session s23 (script archived))
                 typedef _Float16 cs_h2 __attribute__((ext_vector_type(2)));
                 const int j_ = mi * 4 + it;
                 if (j_ == cs_jb0 || j_ == cs_jb0 + 1) {               // wave-uniform: a lane of this wave may enter the second frame at this step

@@ -96,6 +96,17 @@ def auto_episodes_per_step(cfg, n_local):
     if key not in _LOGGED_K:
         _LOGGED_K.add(key)
         import logging
+        # k stays a function of the device's TOTAL memory (same on every rank, in every run); a device that is shared or partly occupied is
+        # told so up front instead of running out of memory inside the first step
+        try:
+            free = torch.cuda.mem_get_info()[0]
+            need = int(1.15 * per_frame * frames * k)
+            if free < need:
+                logging.getLogger(__name__).warning(
+                    "TEST.EPISODES_PER_STEP unset: %d episodes per model call need about %.1f GB, the device has %.1f GB free of %.0f GB -- set "
+                    "TEST.EPISODES_PER_STEP to a smaller batch if the first step runs out of memory", k, need / 2 ** 30, free / 2 ** 30, total / 2 ** 30)
+        except Exception:
+            pass
         logging.getLogger(__name__).info("TEST.EPISODES_PER_STEP unset: %d episodes per model call (%d frames each, %.0f GB device memory)",
                                          k, frames, total / 2 ** 30)
     return k

@@ -175,16 +175,18 @@ class CNN_OTAM_CLIPFSAR(CNN_FSHead):
         if self._engine is None or self._engine_key != key:
             if self.precision == "bf16" and not getattr(self, "_warned_bf16", False):
                 import logging
-                from ... import LOGITS_TOLERANCE, LOGITS_TOLERANCE_RN50, NORTH_STAR_TOLERANCE
+                from ... import FP16_TAIL_MAX_SEEN, LOGITS_TOLERANCE, LOGITS_TOLERANCE_RN50, NORTH_STAR_TOLERANCE
                 rn = self.arch.get("kind") == "rn"
                 logging.getLogger(__name__).warning(
                     "CNN_OTAM_CLIPFSAR (HIP): VIDEO.HEAD.PRECISION = 'bf16' (throughput mode) -- logits deviate from the reference's "
                     "fp32 path by rms 2.3-3.9e-3 / up to 1.0e-2 on the BASELINE ViT configurations (standard and high-contrast episodes alike) "
                     "and up to 2.3e-2 on tiny test architectures, argmax flips on near-ties only (1 row of 325) (profiles/r05_parity_table.md; regression bound %g).  "
                     "PRECISION 'fp16' (0.85 x the bf16 rate) is a STATISTICAL 1e-3 mode: rms <= 4e-4 (measured 1.9-3.5e-4) and 99 %% of the logits within %g, "
-                    "an episode's largest deviation up to 1.2e-3 in about one episode of 13-60 (RN50: rms 9.4e-4, max 3.3e-3); PRECISION 'fp32' "
+                    "an episode's largest deviation up to %.3g in about one episode of 13-60 (RN50: rms 9.4e-4, max 3.3e-3); PRECISION 'fp16_strict' (ViT towers) "
+                    "keeps every logit of every reference golden within %g; PRECISION 'fp32' "
                     "(0.1 x) holds every logit of every episode within %g" % (
-                        (LOGITS_TOLERANCE_RN50 if rn else LOGITS_TOLERANCE)["bf16"], NORTH_STAR_TOLERANCE, NORTH_STAR_TOLERANCE))
+                        (LOGITS_TOLERANCE_RN50 if rn else LOGITS_TOLERANCE)["bf16"], NORTH_STAR_TOLERANCE, FP16_TAIL_MAX_SEEN, NORTH_STAR_TOLERANCE,
+                        NORTH_STAR_TOLERANCE))
                 self._warned_bf16 = True
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             self._engine = ClipFsarEngine(self.arch, sd, self.text_features_train, self.text_features_test,

@@ -44,7 +44,7 @@ class DevicePrefetcher:
         keys = [k for k, v in host.items() if isinstance(v, torch.Tensor)]
         for j, h in enumerate(hosts[1:], 1):                        # collated items must agree (a mismatch would fail inside copy_ or drop keys silently)
             hk = [k for k, v in h.items() if isinstance(v, torch.Tensor)]
-            if hk != keys:
+            if sorted(hk) != sorted(keys):                          # (dict insertion order is not part of the contract: ADVICE r5)
                 raise ValueError("DevicePrefetcher: collated item %d has tensor keys %s, item 0 has %s" % (j, hk, keys))
             for k in keys:
                 if h[k].shape[1:] != host[k].shape[1:] or h[k].dtype != host[k].dtype:

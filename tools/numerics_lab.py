@@ -14,6 +14,13 @@ Scheme grammar: comma-separated key=value over
   u      = (as act)              MLP hidden only, overrides act
   o      = (as act)              attention output only
   dr     = 0 | 1                 1: GEMM output rounded to fp16 before the residual add (the round-3 epilogue)
+Round 6 (the per-site budget behind precision "fp16_strict", profiles/r06_strict_budget.md):
+  feed   = f16 | x               what the LN-folded GEMMs read of the stream (x: both words)
+  q, k, v, p                     one attention operand alone (override qkv / act)
+  patch  = f16 | x               the patch embedding's pixels and weights (override act)
+  pre    = same | f16            the two stores of the stream in front of the blocks (patch-embed output, ln_pre output): as `stream`, or one fp16 word
+  wfold  = r, wres = m           the product's per-frame low-word correction of the weights (raw-stream form / token-mean form)
+  clsx=1 | meanx=1               diagnostics: every rounding leaves the class-token row exact / gets the per-frame mean of its error added back
 """
 import math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,7 +32,21 @@ import _cases
 torch.set_grad_enabled(False)
 
 
+CLSX = [False]
+MEANX = [False]
 def rnd(t, kind):
+    if MEANX[0] and kind in ("f16", "bf16") and t.dim() in (3, 4):
+        r = t.half().float() if kind == "f16" else t.bfloat16().float()
+        d = t.dim() - 2
+        return r + (t - r).mean(d, keepdim=True)
+    if CLSX[0] and t.dim() == 3 and kind in ("f16", "bf16"):
+        r = t.half().float() if kind == "f16" else t.bfloat16().float()
+        r[:, 0, :] = t[:, 0, :]
+        return r
+    if CLSX[0] and t.dim() == 4 and kind in ("f16", "bf16"):      # probabilities [F, h, Nq, Nk]: query row 0 exact
+        r = t.half().float() if kind == "f16" else t.bfloat16().float()
+        r[:, :, 0, :] = t[:, :, 0, :]
+        return r
     if kind == "f16":
         return t.half().float()
     if kind == "bf16":
@@ -36,6 +57,8 @@ def rnd(t, kind):
 def make_tower(s):
     stream, wres, wfold = s.get("stream", "f16"), s.get("wres", "f16"), s.get("wfold", "f16")
     act = s.get("act", "f16")
+    CLSX[0] = s.get("clsx", "0") == "1"
+    MEANX[0] = s.get("meanx", "0") == "1"
     ku, ko, kq, kp = s.get("u", act), s.get("o", act), s.get("qkv", act), s.get("p", act)
     wqkv, wfc, wout, wpr = s.get("wqkv", wfold), s.get("wfc", wfold), s.get("wout", wres), s.get("wpr", wres)
     dr = s.get("dr", "0") == "1"       # round-3 kernels: the GEMM output is rounded to fp16 BEFORE the (packed fp16) residual add
@@ -54,8 +77,9 @@ def make_tower(s):
             return hi + (x - hi).half().to(torch.float8_e5m2).float()
         return x
 
+    fk = s.get("feed", "f16")
     def feed(x):             # what a consumer GEMM reads of the stream (16-bit operand)
-        return x.half().float()
+        return rnd(x, fk)
 
     def mm(A, W32, kind):
         """A [F, N, K] @ W^T with the weight precision `kind`: f16 | x (exact) | m (fp16 word + the low word applied to the per-frame
@@ -86,10 +110,12 @@ def make_tower(s):
             p_ = arch["patch"]
             gg = H // p_
             pt = f.reshape(F_, C, gg, p_, gg, p_).permute(0, 2, 4, 1, 3, 5).reshape(F_, gg * gg, C * p_ * p_)
-            tok = rnd(pt, act) @ rnd(g("conv1.weight").reshape(D, -1), act).t()
+            tok = rnd(pt, s.get("patch", act)) @ rnd(g("conv1.weight").reshape(D, -1), s.get("patch", act)).t()
             x = torch.cat([g("class_embedding").reshape(1, 1, D).expand(F_, 1, D), tok], 1) + g("positional_embedding")
-            x = store(x)
-            x = store(orc.layer_norm(x, g("ln_pre.weight"), g("ln_pre.bias")))
+            pre = s.get("pre", "same")
+            st0 = store if pre == "same" else (lambda t: rnd(t, pre))
+            x = st0(x)
+            x = st0(orc.layer_norm(x, g("ln_pre.weight"), g("ln_pre.bias")))
             for i in range(arch["layers"]):
                 b = "transformer.resblocks.%d." % i
                 N = x.shape[1]
@@ -97,8 +123,8 @@ def make_tower(s):
                 gam, bet = g(b + "ln_1.weight"), g(b + "ln_1.bias")
                 mu, var = xi.mean(-1, keepdim=True), xi.var(-1, unbiased=False, keepdim=True)
                 qkv = mm_ln(xi, mu, var, g(b + "attn.in_proj_weight") * gam[None, :], wqkv) + (g(b + "attn.in_proj_weight") @ bet + g(b + "attn.in_proj_bias"))
-                qkv = rnd(qkv, kq)
                 q, k, v = qkv.split(D, -1)
+                q, k, v = rnd(q, s.get("q", kq)), rnd(k, s.get("k", kq)), rnd(v, s.get("v", kq))
                 q = q.reshape(F_, N, heads, hd).transpose(1, 2); k = k.reshape(F_, N, heads, hd).transpose(1, 2)
                 v = v.reshape(F_, N, heads, hd).transpose(1, 2)
                 sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd)

@@ -2,7 +2,7 @@
 13 episodes = 65 logit rows per configuration, at the generator's standard contrast `mc_*` and at high contrast `hc_*`, logits spread 3-4).
 Per (case, mode): rms / p99 / max of |logits - reference| over all elements, the largest per-episode deviation and how many episodes exceed 1e-3,
 the same relative to the episode's logits spread -> gpurun_out/parity_multi.json (profiles/r05_parity_table.md is made from it).
-usage: python tools/parity_multi.py [--modes fp32,fp16,bf16] [case ...]"""
+usage: python tools/parity_multi.py [--modes fp32,fp16,bf16] [case ...]      a mode may carry environment switches: "fp16_strict;CFSAR_FP16_SPLIT=out" """
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,9 +17,13 @@ table = {}
 for name in cases:
     table[name] = {}
     for mode in modes:
-        st = multi_case_stats(name, mode)
+        for k in ("CFSAR_FP16_SPLIT", "CFSAR_FP16_MCORR"):
+            os.environ.pop(k, None)
+        for kv in mode.split(";")[1:]:
+            os.environ[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
+        st = multi_case_stats(name, mode.split(";")[0])
         table[name][mode] = st
-        print("%-26s %-5s rows %3d spread %.2f | rms %.2e p99 %.2e max %.2e | worst episode %.2e, episodes > 1e-3: %d of %d | max / spread %.2e | argmax %d/%d" % (
+        print("%-26s %-40s rows %3d spread %.2f | rms %.2e p99 %.2e max %.2e | worst episode %.2e, episodes > 1e-3: %d of %d | max / spread %.2e | argmax %d/%d" % (
             name, mode, st["rows"], st["mean_spread"], st["rms"], st["p99"], st["max"], st["worst_episode_max"], st["episodes_over_1e-3"], st["episodes"],
             st["max_rel_spread"], st["argmax_equal"], st["rows"]), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
