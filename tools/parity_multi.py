@@ -2,7 +2,8 @@
 13 episodes = 65 logit rows per configuration, at the generator's standard contrast `mc_*` and at high contrast `hc_*`, logits spread 3-4).
 Per (case, mode): rms / p99 / max of |logits - reference| over all elements, the largest per-episode deviation and how many episodes exceed 1e-3,
 the same relative to the episode's logits spread -> gpurun_out/parity_multi.json (profiles/r05_parity_table.md is made from it).
-usage: python tools/parity_multi.py [--modes fp32,fp16,bf16] [case ...]      a mode may carry environment switches: "fp16_strict;CFSAR_FP16_SPLIT=out" """
+usage: python tools/parity_multi.py [--modes fp32,fp16,bf16] [case ...]      a mode may carry environment switches, modes are then separated by "|":
+                                                                                 --modes "fp16_strict|fp16_strict;CFSAR_FP16_SPLIT=out;CFSAR_FP16_MCORR=qkv,fc,pr" """
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,7 +12,7 @@ from _cases import multi_case_stats, MULTI_CASES
 
 modes = ["fp32", "fp16", "bf16"]
 if "--modes" in sys.argv:
-    i = sys.argv.index("--modes"); modes = sys.argv[i + 1].split(","); del sys.argv[i:i + 2]
+    i = sys.argv.index("--modes"); modes = sys.argv[i + 1].split("|" if "|" in sys.argv[i + 1] or ";" in sys.argv[i + 1] else ","); del sys.argv[i:i + 2]
 cases = sys.argv[1:] or [c for c in MULTI_CASES if os.path.exists(os.path.join(ROOT, "tests", "golden", "multi_%s.npz" % c))]
 table = {}
 for name in cases:

@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/r06_s2; mkdir -p $O
-timeout 2400 python tools/parity_multi.py --modes "fp16_strict,fp16_strict;CFSAR_FP16_SPLIT=out;CFSAR_FP16_MCORR=qkv,fc,pr,fp16_strict;CFSAR_FP16_SPLIT=qkv,out,fc,pr;CFSAR_FP16_MCORR=,fp16_strict;CFSAR_FP16_SPLIT=out,pr;CFSAR_FP16_MCORR=qkv,fc" hc_cfg4_L14_5w1s_T16 oc_cfg2_B16_5w1s_T8 mc_cfg4_L14_5w1s_T16 hc_cfg2_B16_5w1s_T8 > $O/parity_multi.log 2>&1; grep -v amdgpu.ids $O/parity_multi.log | tail -18
+timeout 2400 python tools/parity_multi.py --modes "fp16_strict|fp16_strict;CFSAR_FP16_SPLIT=out;CFSAR_FP16_MCORR=qkv,fc,pr|fp16_strict;CFSAR_FP16_SPLIT=qkv,out,fc,pr;CFSAR_FP16_MCORR=|fp16_strict;CFSAR_FP16_SPLIT=out,pr;CFSAR_FP16_MCORR=qkv,fc" hc_cfg4_L14_5w1s_T16 oc_cfg2_B16_5w1s_T8 mc_cfg4_L14_5w1s_T16 hc_cfg2_B16_5w1s_T8 > $O/parity_multi.log 2>&1; grep -v amdgpu.ids $O/parity_multi.log | tail -18
 timeout 900 python - > $O/rn50_batch.log 2>&1 <<'PY'
 import sys, os
 sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
