@@ -26,14 +26,22 @@ __device__ __forceinline__ f32x4 att_mfma(typename Vec2B<T>::v8 a, typename Vec2
 // and g^1 hold the two halves of each 8-wide d chunk.  After one exchange with lane^16 (4 dwords each way) the even-g lane owns
 // the chunks of dt 0,1 and the odd-g lane those of dt 2,3: two dwordx4 stores per lane instead of four dwordx2 (the
 // attention epilogue is store-ISSUE bound: 59 of 273 us at 640 frames were the 8-byte stores).
-template <typename T>
+// LOW (round 6, the two-word output of the fp16_strict mode): the tile of SECOND words, (T)(x - (float)(T)x) of every x = o * inv.
+template <typename T, bool LOW = false>
 __device__ __forceinline__ void pack_o_tile(const f32x4 (&o)[4], float inv, int g, uint4 (&val)[2]) {
     unsigned pk[4][2];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
         typename Vec2B<T>::v4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (T)(o[dt][r] * inv);
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (LOW) {
+                const float x = o[dt][r] * inv;
+                v[r] = (T)(x - (float)(T)x);
+            } else {
+                v[r] = (T)(o[dt][r] * inv);
+            }
+        }
         const uint2 u = __builtin_bit_cast(uint2, v);
         pk[dt][0] = u.x;
         pk[dt][1] = u.y;
@@ -64,10 +72,10 @@ __device__ __forceinline__ void store_o_packed(const uint4 (&val)[2], bool valid
         for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(orow + (odd ? 2 + i : i) * 16 + (g >> 1) * 8) = val[i];
     }
 }
-template <typename T>
+template <typename T, bool LOW = false>
 __device__ __forceinline__ void store_o_tile(const f32x4 (&o)[4], float inv, bool valid, T* orow, int g) {
     uint4 val[2];
-    pack_o_tile<T>(o, inv, g, val);
+    pack_o_tile<T, LOW>(o, inv, g, val);
     store_o_packed(val, valid, orow, g);
 }
 
@@ -252,7 +260,10 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, const 
     inv = __builtin_amdgcn_rcpf(osum[0]);                       // every row of the ones product is the query's sum over all keys
 }
 
-template <typename T, int NKB, int NTV, int NW, int WPS, int KPFK = 0, bool MEANS = false>
+// PAIR (round 6, fp16_strict): the output keeps TWO fp16 words per element, out [F ntok, 2 D] = [o_hi | o_lo] (o_lo = the rounding remainder of o_hi):
+// out_proj reads it as a K = 2 D operand against [W | W] (cfsar_gemm_residual_wide, wsplit = 2) and its result no longer carries the 11-bit rounding of
+// the attention output -- a fifth of the strict mode's remaining error on ViT-L/14 (profiles/r06_strict_budget.md) for one more store pass here.
+template <typename T, int NKB, int NTV, int NW, int WPS, int KPFK = 0, bool MEANS = false, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                                      int ntok, int D, float scale_log2e, int dbg,
                                                                      __bf16* __restrict__ omean = nullptr) {
@@ -350,7 +361,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void vit_attn_bf16_kernel(const T* __
 #endif
         attn_tile<T, NKB, NTV, ((KPFK > 0) ? KPFK : ((NKB >= 9 && WPS > 2) ? 1 : 2))>(sK, sV, L, qf, ntok, scale_log2e, o, inv);
         // O^T[d][q]: lane owns query q16, d = 16 dt + 4 g + r
-        store_o_tile<T>(o, inv, qvalid, out + ((size_t)f * ntok + qrow) * D + h * 64, g);
+        T* const orow = out + ((size_t)f * ntok + qrow) * (PAIR ? 2 * D : D) + h * 64;
+        store_o_tile<T>(o, inv, qvalid, orow, g);
+        if constexpr (PAIR) store_o_tile<T, true>(o, inv, qvalid, orow + D, g);
         if constexpr (MEANS) {
             const float w = qvalid ? inv : 0.f;
 #pragma unroll
@@ -745,11 +758,17 @@ static inline int attn_dbg() {
 }
 
 template <int NKB, int NTV, int NW, int WPS, int KPFK = 0, typename T = __bf16>
-int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s, void* omean = nullptr) {
+int launch_bf16(const void* qkv, void* out, int F, int ntok, int D, int heads, hipStream_t s, void* omean = nullptr, bool pair = false) {
     constexpr int KROWS = (NTV > 0 ? NTV : NKB * 2) * 16;
     constexpr int LDS = 2 * KROWS * 128;
     const float scale_log2e = 0.125f * 1.4426950408889634f;
     if constexpr (std::is_same<T, _Float16>::value) {
+        if (omean != nullptr && pair) {           // fp16_strict: two-word output [o_hi | o_lo] + the per-frame token means
+            if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<T, NKB, NTV, NW, WPS, KPFK, true, true>), LDS, "cfsar_vit_attention")) return rc;
+            hipLaunchKernelGGL((vit_attn_bf16_kernel<T, NKB, NTV, NW, WPS, KPFK, true, true>), dim3(heads, F), dim3(NW * 64), LDS, s,
+                               static_cast<const T*>(qkv), static_cast<T*>(out), ntok, D, scale_log2e, attn_dbg(), static_cast<__bf16*>(omean));
+            return cfsar_check_launch("cfsar_vit_attention_pair");
+        }
         if (omean != nullptr) {                   // the fp16 numerics mode's form that also emits the output's per-frame token means
             if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&vit_attn_bf16_kernel<T, NKB, NTV, NW, WPS, KPFK, true>), LDS, "cfsar_vit_attention")) return rc;
             hipLaunchKernelGGL((vit_attn_bf16_kernel<T, NKB, NTV, NW, WPS, KPFK, true>), dim3(heads, F), dim3(NW * 64), LDS, s,
@@ -795,7 +814,7 @@ static int g_attn_variant = 0;
 extern "C" void cfsar_debug_set_attn_variant(int v) { g_attn_variant = v & 255; g_attn_dbg = v >> 8; }
 #endif
 
-static int vit_attention_impl(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads, void* omean, cfsar_stream_t stream);
+static int vit_attention_impl(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads, void* omean, cfsar_stream_t stream, bool pair = false);
 
 extern "C" int cfsar_vit_attention(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads,
                                    cfsar_stream_t stream) {
@@ -809,7 +828,13 @@ extern "C" int cfsar_vit_attention_means(const void* qkv, void* out, void* omean
     return vit_attention_impl(qkv, out, CFSAR_F16, F, ntok, D, heads, omean, stream);
 }
 
-static int vit_attention_impl(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads, void* omean, cfsar_stream_t stream) {
+// cfsar_vit_attention_means with the output in TWO fp16 words: out_pair [F ntok, 2 D] = [o_hi | o_lo] (see the header).
+extern "C" int cfsar_vit_attention_pair(const void* qkv, void* out_pair, void* omean, int F, int ntok, int D, int heads, cfsar_stream_t stream) {
+    CFSAR_REQUIRE(omean != nullptr, "cfsar_vit_attention_pair: null pointer");
+    return vit_attention_impl(qkv, out_pair, CFSAR_F16, F, ntok, D, heads, omean, stream, true);
+}
+
+static int vit_attention_impl(const void* qkv, void* out, int dtype, int F, int ntok, int D, int heads, void* omean, cfsar_stream_t stream, bool pair) {
     CFSAR_REQUIRE(qkv && out, "cfsar_vit_attention: null pointer");
     CFSAR_REQUIRE(F > 0 && ntok > 0 && heads > 0 && D == heads * 64, "cfsar_vit_attention: need D == heads*64 (D=%d heads=%d)",
                   D, heads);
@@ -870,10 +895,10 @@ static int vit_attention_impl(const void* qkv, void* out, int dtype, int F, int 
     }
     if (dtype == CFSAR_F16) {                    // the fp16 numerics mode: the same kernel on fp16 q / k / v, P rounded to fp16
         CFSAR_REQUIRE(ntok <= 288, "cfsar_vit_attention: ntok=%d > 288", ntok);
-        if (ntok == 197) return launch_bf16<7, 13, 4, 3, 0, _Float16>(qkv, out, F, ntok, D, heads, s, omean);
-        if (ntok == 257) return launch_bf16<9, 17, 4, 2, 5, _Float16>(qkv, out, F, ntok, D, heads, s, omean);
-        if (ntok > 224) return launch_bf16<9, 0, 4, 2, 0, _Float16>(qkv, out, F, ntok, D, heads, s, omean);
-        return launch_bf16<7, 0, 7, 4, 0, _Float16>(qkv, out, F, ntok, D, heads, s, omean);
+        if (ntok == 197) return launch_bf16<7, 13, 4, 3, 0, _Float16>(qkv, out, F, ntok, D, heads, s, omean, pair);
+        if (ntok == 257) return launch_bf16<9, 17, 4, 2, 5, _Float16>(qkv, out, F, ntok, D, heads, s, omean, pair);
+        if (ntok > 224) return launch_bf16<9, 0, 4, 2, 0, _Float16>(qkv, out, F, ntok, D, heads, s, omean, pair);
+        return launch_bf16<7, 0, 7, 4, 0, _Float16>(qkv, out, F, ntok, D, heads, s, omean, pair);
     }
     if (dtype == CFSAR_F32) {
         const int lds = ntok * 64 * 4 * 2;

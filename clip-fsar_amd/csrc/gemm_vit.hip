@@ -707,8 +707,11 @@ int cfsar_gemm_vit_try(const VitGemmCall& c, hipStream_t s) {
     a.res = c.res;
     a.rowstats = c.rowstats;
     const int ka = c.ka > 0 ? c.ka : c.K;           // K of A (split weights: K = 2 ka)
-    if (!(ka == c.K || (2 * ka == c.K && ka % 64 == 0 && ka >= 128 && c.ha_tokens == 0 && c.hb_tokens == 0 && c.in_dtype == CFSAR_F16)))
-        return cfsar_fail("cfsar_gemm (vit): split weights need K = 2 ka, ka %% 64 == 0, fp16 operands, row-major layouts (K=%d, ka=%d)", c.K, ka);
+    // K = 2 ka: split weights [w_hi | w_lo] against A walked twice; 2 K = 3 ka (round 6): A = [a_hi | a_lo] against [w_hi | w_hi | w_lo] -- the K tiles
+    // behind ka wrap to A's first tiles again (kt -> kt - nka): the third segment reads a_hi
+    if (!(ka == c.K || (((2 * ka == c.K && ka % 64 == 0) || (3 * ka == 2 * c.K && c.wide && ka % 128 == 0)) && ka >= 128 && c.ha_tokens == 0 &&
+                        c.hb_tokens == 0 && c.in_dtype == CFSAR_F16)))
+        return cfsar_fail("cfsar_gemm (vit): split operands need K = 2 ka (ka %% 64 == 0) or 2 K = 3 ka (ka %% 128 == 0), fp16 operands, row-major layouts (K=%d, ka=%d)", c.K, ka);
     if (c.wide && !(f16res && c.in_dtype == CFSAR_F16 && c.res == c.out && c.ldr == c.ldo && c.ha_tokens == 0))
         return cfsar_fail("cfsar_gemm_residual_wide: fp16 operands, the residual stream updated in place");
     a.nka = ka / 64;
@@ -878,7 +881,14 @@ static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const floa
     c.part = partial; c.part_slots = slots; c.part_eps = eps;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = 0;
     c.out_dtype = out_dtype; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F32; c.act = act; c.relu = 0;
-    c.opath = vit_policy_opath(K, 0); c.store = vit_policy_store(2); c.group = vit_policy_group(K); c.colfast = vit_policy_colfast(K); c.dbg = 0;
+    // (the policies go by the K the launch WALKS: a split-weight launch of K = 768 is a K = 1 536 launch.  -DCFSAR_SPLIT_POLICY_BY_KA: by the operand's own
+    // K instead -- the LDS-DMA path and the band-fastest walk of the short-K launches; product-build A/B of round 6, tools/r06_runs)
+#ifdef CFSAR_SPLIT_POLICY_BY_KA
+    const int Kp = ka_;
+#else
+    const int Kp = K;
+#endif
+    c.opath = vit_policy_opath(Kp, 0); c.store = vit_policy_store(2); c.group = vit_policy_group(Kp); c.colfast = vit_policy_colfast(Kp); c.dbg = 0;
     c.hb_tokens = hb_tokens; c.hb_heads = hb_heads; c.ha_tokens = 0;
 #ifdef CFSAR_DEV
     c.dbg = g_force_dbg;
@@ -1004,16 +1014,24 @@ extern "C" int cfsar_gemm_residual_wide(const void* A, const void* W, void* x_hi
     CFSAR_REQUIRE(corr == nullptr || corr_tokens >= 128, "cfsar_gemm_residual_wide: the per-frame correction needs >= 128 tokens per frame");
     CFSAR_REQUIRE(A && W && x_hi && bias, "cfsar_gemm_residual_wide: null pointer");
     CFSAR_REQUIRE(M > 0 && N > 0 && K >= 128 && K % 64 == 0 && N % 64 == 0, "cfsar_gemm_residual_wide: bad shape M=%d N=%d K=%d", M, N, K);
-    const int Kt = wsplit ? 2 * K : K;
-    CFSAR_REQUIRE(lda >= K && ldw >= Kt && ldx >= N && lda % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, "cfsar_gemm_residual_wide: bad leading dimension");
+    CFSAR_REQUIRE(wsplit >= 0 && wsplit <= 2, "cfsar_gemm_residual_wide: wsplit must be 0, 1 or 2, got %d", wsplit);
+    CFSAR_REQUIRE(wsplit != 2 || corr == nullptr, "cfsar_gemm_residual_wide: wsplit = 2 carries the weights' second word itself (no per-frame correction)");
+    const int Kt = wsplit == 2 ? 3 * K : (wsplit ? 2 * K : K);
+    const int Ka = wsplit == 2 ? 2 * K : K;                  // columns of A: [a_hi | a_lo] in the two-word form
+    CFSAR_REQUIRE(lda >= Ka && ldw >= Kt && ldx >= N && lda % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0, "cfsar_gemm_residual_wide: bad leading dimension");
     VitGemmCall c;
     c.A = A; c.W = W; c.out = x_hi; c.bias = bias; c.res = x_hi; c.rowstats = nullptr; c.cvec = nullptr; c.stats_out = stats_partial;
     c.part = nullptr; c.part_slots = 0; c.part_eps = 0.f;
     c.M = M; c.N = N; c.K = Kt; c.lda = lda; c.ldw = ldw; c.ldo = ldx; c.ldr = ldx;
     c.out_dtype = CFSAR_F16; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
-    c.opath = vit_policy_opath(Kt, 2); c.store = vit_policy_store(0); c.group = vit_policy_group(Kt); c.colfast = vit_policy_colfast(Kt); c.dbg = 0;
+#ifdef CFSAR_SPLIT_POLICY_BY_KA
+    const int Kp = K;
+#else
+    const int Kp = Kt;
+#endif
+    c.opath = vit_policy_opath(Kp, 2); c.store = vit_policy_store(0); c.group = vit_policy_group(Kp); c.colfast = vit_policy_colfast(Kp); c.dbg = 0;
     c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = 0;
-    c.ka = K; c.wide = 1; c.res_lo = x_lo; c.corr = corr; c.corr_tokens = corr_tokens;
+    c.ka = Ka; c.wide = 1; c.res_lo = x_lo; c.corr = corr; c.corr_tokens = corr_tokens;
 #ifdef CFSAR_DEV
     c.dbg = g_force_dbg & ((1 << 17) | (1 << 18));
 #endif

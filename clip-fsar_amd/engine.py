@@ -44,7 +44,7 @@ class HipViT:
     # statistics fusion.  They are constructor arguments -- the product path reads four environment variables only (CFSAR_LN_FOLD,
     # CFSAR_FULL_LAST_BLOCK, CFSAR_FP16_SPLIT, CFSAR_FP16_MCORR).
     OPTIONS = {"fp16_wide": True, "fp16_lo": True, "fp16_rawmeans": True, "fused_umeans": True, "fused_omeans": True, "fuse_stats": True,
-               "fused_patch": True}
+               "fused_patch": True, "strict_front": True, "strict_o_pair": True}
 
     def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda", stream_dtype=None, fp16_split=None, fp16_mcorr=None,
                  options=None):
@@ -249,14 +249,27 @@ class HipViT:
         if self.strict:
             if not (self.two_word and self.fold and D % 4 == 0 and D <= 1024):
                 raise ValueError("precision 'fp16_strict' needs the two-word stream (options fp16_wide / fp16_lo) and a width <= 1024")
-            self.fused_patch = False
-            w32 = wc
-            w_hi = w32.to(torch.float16)
-            w_lo = (w32 - w_hi.float()).to(torch.float16)
-            self.w_patch3 = torch.cat([w_hi, w_hi, w_lo], 1).contiguous()          # [D, 3 kpad]
+            self.strict_front = bool(opt["strict_front"])                             # (developer ablation of the two strict devices)
+            if self.strict_front:
+                self.fused_patch = False
+                w32 = wc
+                w_hi = w32.to(torch.float16)
+                w_lo = (w32 - w_hi.float()).to(torch.float16)
+                self.w_patch3 = torch.cat([w_hi, w_hi, w_lo], 1).contiguous()      # [D, 3 kpad]
+            # ... and the attention output keeps two fp16 words, out_proj = [o_hi | o_lo] x [W_hi | W_hi | W_lo] (three passes of the smallest block GEMM):
+            # the attention output's rounding is a tenth (ViT-B/16) to a fifth (ViT-L/14) of what is left, out_proj's weight remainder another tenth on
+            # ViT-L/14 (tools/strict_eval.py: cfg4 rms 1.77e-4 -> 1.56e-4 with split out_proj weights alone).  Needs the attention kernel's means form.
+            self.o_pair = bool(opt["strict_o_pair"]) and self.fused_omeans and "out" in self.mcorr and D % 128 == 0
+            if self.o_pair:
+                for i, blk in enumerate(self.blocks):
+                    W = g("transformer.resblocks.%d.attn.out_proj.weight" % i)
+                    Wh = W.to(torch.float16)
+                    blk["w3_out"] = torch.cat([Wh, Wh, (W - Wh.float()).to(torch.float16)], 1).contiguous()
         self._slots = {}
         self.max_frames_32bit = (2 ** 32 - 1) // (self.ntok * 4 * self.D * 2) - 1
-        if self.strict:                                                            # ... and of the three-word patch matrix [F (ntok - 1), 3 kpad]
+        self.strict_front = self.strict and getattr(self, "strict_front", False)
+        self.o_pair = self.strict and getattr(self, "o_pair", False)
+        if self.strict_front:                                                      # ... and of the three-word patch matrix [F (ntok - 1), 3 kpad]
             self.max_frames_32bit = min(self.max_frames_32bit, (2 ** 32 - 1) // ((self.ntok - 1) * 3 * self.kpad * 2) - 1)
 
     # ------------------------------------------------------------------ workspace (caller-owned device buffers)
@@ -270,10 +283,10 @@ class HipViT:
                 x=torch.empty(M, D, device=dev, dtype=self.xd),
                 h=torch.empty(M, D, device=dev, dtype=cd),
                 qkv=torch.empty(M, 3 * D, device=dev, dtype=cd),
-                o=torch.empty(M, D, device=dev, dtype=cd),
+                o=torch.empty(M, 2 * D if self.o_pair else D, device=dev, dtype=cd),
                 u=torch.empty(M, 4 * D, device=dev, dtype=cd),
                 c=torch.empty(F_, D, device=dev, dtype=torch.float32))
-            if self.strict:                                                                  # three-word patch matrix, fp32 patch tokens
+            if self.strict_front:                                                            # three-word patch matrix, fp32 patch tokens
                 ws["patches"] = torch.empty(F_ * (self.ntok - 1), 3 * self.kpad, device=dev, dtype=cd)
                 ws["tok32"] = torch.empty(F_ * (self.ntok - 1), D, device=dev, dtype=torch.float32)
             elif not self.fused_patch:                                                       # the im2col matrix of the unfused patch embedding
@@ -331,12 +344,12 @@ class HipViT:
                 raise RuntimeError("frames must be [F,3,%d,%d], got %s" % (self.arch["res"], self.arch["res"], tuple(fr.shape)))
             if self.fused_patch:
                 hip.patch_embed(fr, self.w_patch, self.pos, self.cls, x[off * N:(off + c) * N], self.P)
-            elif self.strict:
+            elif self.strict_front:
                 hip.im2col_patches_split(fr, ws["patches"][off * npatch:(off + c) * npatch], self.P)
             else:
                 hip.im2col_patches(fr, ws["patches"][off * npatch:(off + c) * npatch], self.P)
             off += c
-        if self.strict:
+        if self.strict_front:
             # fp16_strict: patches [hi | lo | hi] x [W_hi | W_hi | W_lo]^T -> fp32 tokens; class token + pos + ln_pre -> x_hi, x_lo in one pass
             hip.gemm(ws["patches"], self.w_patch3, ws["tok32"], M=F_ * npatch, N=D, K=3 * self.kpad, ldo=D)
             hip.embed_finish_pair(ws["tok32"], self.cls, self.pos, self.ln_pre[0], self.ln_pre[1], x, ws["xlo"], F_, N, D)
@@ -347,7 +360,7 @@ class HipViT:
                 hip.cls_rows(x, self.cls, self.pos, F_, N, D)
             hip.layernorm(x, x, self.ln_pre[0], self.ln_pre[1], M, D)                 # ln_pre (:677), in place
         if taps is not None:
-            taps["ln_pre"] = (x[:M].float() + ws["xlo"][:M].float()) if self.strict else x[:M].clone()
+            taps["ln_pre"] = (x[:M].float() + ws["xlo"][:M].float()) if self.strict_front else x[:M].clone()
         xc_final = None
         es = x.element_size()
 
@@ -358,7 +371,7 @@ class HipViT:
         if self.fold:
             part, rstat, S = ws["part"], ws["rstat"], D // 64
             xlo = ws["xlo"] if self.two_word else None
-            if xlo is not None and not self.strict:
+            if xlo is not None and not self.strict_front:
                 xlo[:M].zero_()                                                       # memset: the stream enters the blocks as ln_pre's fp16 output
             hip.row_stats(x, rstat, M, D)                                             # statistics of ln_pre's output
             prune = self.prune_last and taps is None
@@ -405,7 +418,9 @@ class HipViT:
 
             def resid(A, blk, key, xx, xl, pt, rows, corr=None, cls=False):
                 """xx (+ xl) += A W^T + bias, partial LayerNorm statistics of the new stream -> pt (cls: the last block's class-token rows)"""
-                if self.wide and cls and key in mcorr:
+                if self.o_pair and key == "out" and not cls:                          # fp16_strict: [o_hi | o_lo] x [W_hi | W_hi | W_lo]
+                    hip.gemm_residual_wide(A, blk["w3_out"], xx, xl, blk["b_out"], pt, M=rows, wsplit=2)
+                elif self.wide and cls and key in mcorr:
                     hip.gemm_residual_wide(A, blk["ws_" + key], xx, xl, blk["b_" + key], pt, M=rows, wsplit=True)
                 elif self.wide:
                     hip.gemm_residual_wide(A, blk["w_" + key], xx, xl, blk["b_" + key], pt, M=rows, wsplit=key in split, corr=corr,
@@ -447,13 +462,16 @@ class HipViT:
                     break
                 fold(x, b["wg_qkv"], qkv, b["cx_qkv" if raw else "c_qkv"], b["d_qkv"], part, rstat, from_part=in_part, sp="qkv" in split,
                      corr=mc(b, "qkv", x, rstat), corr_raw=raw)
-                if "out" in mcorr and self.fused_omeans:                           # the attention kernel emits its output's per-frame means
+                if self.o_pair:                                                    # fp16_strict: two-word attention output (+ its per-frame means)
+                    mO = ws["mX"][:F_]
+                    hip.vit_attention_pair(qkv, o, mO, F_, N, D, self.H)
+                elif "out" in mcorr and self.fused_omeans:                         # the attention kernel emits its output's per-frame means
                     mO = ws["mX"][:F_]
                     hip.vit_attention_means(qkv, o, mO, F_, N, D, self.H)
                 else:
                     mO = None
                     hip.vit_attention(qkv, o, F_, N, D, self.H)
-                resid(o, b, "out", x, xlo, part, M, corr=mc(b, "out", o, means=mO))   # x += out_proj(attn); stats of the new x
+                resid(o, b, "out", x, xlo, part, M, corr=None if self.o_pair else mc(b, "out", o, means=mO))   # x += out_proj(attn); stats of the new x
                 if raw:
                     hip.mean_update_gemm(mO, b["wb_out"], b["b_out"], xbar)           # ... and its per-frame mean follows
                 if not fuse:

@@ -60,6 +60,7 @@ SIGNATURES = {
     "cfsar_stem_conv3x3_s2": [_c_p] * 4 + [_c_int] * 6 + [_c_p],
     "cfsar_vit_attention": [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_vit_attention_means": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
+    "cfsar_vit_attention_pair": [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_vit_attention_cls": [_c_p, _c_i64, _c_p, _c_p, _c_int, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_frame_gemm": [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
     "cfsar_class_text_logits": [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p],
@@ -361,17 +362,18 @@ def gemm_lnfold_hp(x, Wg, out, cvec, dvec, rowstats=None, partial=None, slots=0,
 
 
 def gemm_residual_wide(A, W, x, x_lo, bias, stats_partial=None, M=None, wsplit=False, corr=None, corr_tokens=0):
-    """x (+ x_lo) += A @ W.T + bias with the add in fp32 and ONE rounding; W [N, K] or split [N, 2K]; corr: per-frame low-word
-    correction [frames, N] fp32 (cfsar_gemm_residual_wide)."""
+    """x (+ x_lo) += A @ W.T + bias with the add in fp32 and ONE rounding; W [N, K] or split [N, 2K] (wsplit True / 1); wsplit = 2: A [M, 2K] =
+    [a_hi | a_lo] against W [N, 3K] = [w_hi | w_hi | w_lo]; corr: per-frame low-word correction [frames, N] fp32 (cfsar_gemm_residual_wide)."""
     M = A.shape[0] if M is None else M
-    K = A.shape[1]
-    if W.shape[1] != (2 * K if wsplit else K):
-        raise RuntimeError("gemm_residual_wide: W has %d columns, expected %d" % (W.shape[1], 2 * K if wsplit else K))
+    ws = int(wsplit)
+    K = A.shape[1] // 2 if ws == 2 else A.shape[1]
+    if W.shape[1] != (3 * K if ws == 2 else (2 * K if ws else K)) or (ws == 2 and A.shape[1] != 2 * K):
+        raise RuntimeError("gemm_residual_wide: W has %d columns, expected %d" % (W.shape[1], 3 * K if ws == 2 else (2 * K if ws else K)))
     if corr is not None and corr.shape[1] != W.shape[0]:
         raise RuntimeError("gemm_residual_wide: corr must be [frames, N]")
     _check(lib().cfsar_gemm_residual_wide(_dev(A, torch.float16, "A"), _dev(W, torch.float16, "W"), _dev(x, torch.float16, "x"),
                                           _opt(x_lo, torch.float16, "x_lo"), _dev(bias, torch.float32, "bias"),
-                                          _opt(stats_partial, torch.float32, "stats_partial"), M, W.shape[0], K, int(bool(wsplit)),
+                                          _opt(stats_partial, torch.float32, "stats_partial"), M, W.shape[0], K, ws,
                                           A.shape[1], W.shape[1], x.shape[1], _opt(corr, torch.float32, "corr"), int(corr_tokens),
                                           _stream()), "cfsar_gemm_residual_wide")
 
@@ -432,6 +434,14 @@ def vit_attention_means(qkv, out, omean, F_, ntok, D, heads):
     """vit_attention (fp16) + omean [F, D] bf16: the per-frame token means of the attention output (cfsar_vit_attention_means)."""
     _check(lib().cfsar_vit_attention_means(_dev(qkv, torch.float16, "qkv"), _dev(out, torch.float16, "out"), _dev(omean, torch.bfloat16, "omean"),
                                            F_, ntok, D, heads, _stream()), "cfsar_vit_attention_means")
+
+
+def vit_attention_pair(qkv, out_pair, omean, F_, ntok, D, heads):
+    """vit_attention_means with the output in two fp16 words: out_pair [F ntok, 2 D] = [o_hi | o_lo] (cfsar_vit_attention_pair, fp16_strict)."""
+    if out_pair.shape[-1] != 2 * D:
+        raise RuntimeError("vit_attention_pair: out_pair must be [F ntok, 2 D]")
+    _check(lib().cfsar_vit_attention_pair(_dev(qkv, torch.float16, "qkv"), _dev(out_pair, torch.float16, "out_pair"), _dev(omean, torch.bfloat16, "omean"),
+                                          F_, ntok, D, heads, _stream()), "cfsar_vit_attention_pair")
 
 
 def vit_attention_cls(qkv, out, F_, ntok, D, heads, q=None, kv=None):

@@ -295,7 +295,9 @@ int cfsar_gemm_residual_stats_heads(const void* A, const void* W, void* x, const
  * result does not depend on the batch it is served in).
  * cfsar_gemm_residual_wide: x = x + A W^T + bias, A [M, lda] fp16, W [N, ldw] fp16 (wsplit = 0) or [N, ldw >= 2 K] split (wsplit = 1),
  * x_hi [M, ldx] fp16 in place, x_lo [M, ldx] fp16 in place or NULL; stats_partial as in cfsar_gemm_residual_stats (of the new x_hi);
- * corr as above. */
+ * corr as above.  wsplit = 2 (round 6, the fp16_strict mode's out_proj): BOTH operands carry two words -- A [M, lda >= 2 K] = [a_hi | a_lo]
+ * (cfsar_vit_attention_pair's output), W [N, ldw >= 3 K] = [w_hi | w_hi | w_lo]; the kernel accumulates a_hi w_hi + a_lo w_hi + a_hi w_lo in one fp32
+ * chain (A's K tiles wrap behind 2 K: the third segment reads a_hi again), three times the MFMA work of the smallest block GEMM. */
 int cfsar_gemm_lnfold_hp(const void* x, const void* Wg, void* out, const float* cvec, const float* dvec, const float* rowstats,
                          const float* partial, int slots, float eps, float* rowstats_ws, int M, int N, int K, int lda, int ldw, int ldo,
                          int act, int out_dtype, int wsplit, const float* corr, int corr_tokens, void* colmean_out, void* colsum_ws,
@@ -307,6 +309,10 @@ int cfsar_gemm_residual_wide(const void* A, const void* W, void* x_hi, void* x_l
  * mean over the frame's tokens of out[f tokens + t][64 h + d]): what out_proj's per-frame correction needs, from the one workgroup that sees
  * all output rows of a (frame, head) -- no pass over `out`. */
 int cfsar_vit_attention_means(const void* qkv, void* out, void* omean, int F, int ntok, int D, int heads, cfsar_stream_t stream);
+/* Round 6 (fp16_strict): cfsar_vit_attention_means whose output keeps TWO fp16 words per element: out_pair [F ntok, 2 D] = [o_hi | o_lo],
+ * o_hi = fp16(o), o_lo = fp16(o - o_hi) -- the K = 2 D operand of cfsar_gemm_residual_wide (wsplit = 2), so that out_proj (few_shot.py:635) no
+ * longer sees the 11-bit rounding of the attention output.  omean [F, D] bf16 as above (of the unrounded output). */
+int cfsar_vit_attention_pair(const void* qkv, void* out_pair, void* omean, int F, int ntok, int D, int heads, cfsar_stream_t stream);
 /* out[f][k] = mean over the frame's tokens t of w_t (A[f tokens + t][k] - mu_t), (mu_t, w_t) = (mean, 1 / std) of row t from rowstats
  * [frames tokens, 4] (the token mean of LayerNorm(x) before its affine, few_shot.py:605-611) or (0, 1) when rowstats == NULL.
  * A [frames tokens, lda] fp16, out [frames, K] bf16. */

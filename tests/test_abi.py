@@ -24,7 +24,7 @@ def test_header_symbols_exported_and_arity_matches():
     from clip_fsar_amd import hip
     L = hip.lib()
     protos = _header_prototypes()
-    assert len(protos) == 47, protos
+    assert len(protos) == 48, protos
     for name, nargs in protos.items():
         assert hasattr(L, name), "symbol %s declared in the header is not exported" % name
         if name == "cfsar_last_error":

@@ -1265,6 +1265,73 @@ def test_vit_attention_means(hip, F_, ntok, H):
     assert maxdiff(om.float(), ref) < 2.0 ** -8 * max(0.05, float(ref.abs().max())) + 2e-4, maxdiff(om.float(), ref)
 
 
+@pytest.mark.parametrize("F_,ntok,H", [(7, 197, 12), (3, 257, 16), (5, 130, 4), (4, 17, 2)])
+def test_vit_attention_pair(hip, F_, ntok, H):
+    """cfsar_vit_attention_pair (round 6, fp16_strict): out_pair [F ntok, 2 D] = [o_hi | o_lo]; o_hi and the per-frame means are the bits of
+    cfsar_vit_attention_means, o_lo is the rounding remainder of o_hi (at most half an fp16 ulp of it), and o_hi + o_lo is closer to the fp32
+    attention of the same fp16 q / k / v than o_hi alone (what is left is the kernel's fp16 probabilities)."""
+    D = 64 * H
+    g = torch.Generator().manual_seed(17)
+    qkv = (torch.randn(F_ * ntok, 3 * D, generator=g)).to(torch.float16).cuda()
+    o1 = torch.empty(F_ * ntok, D, device="cuda", dtype=torch.float16)
+    om1 = torch.empty(F_, D, device="cuda", dtype=torch.bfloat16)
+    hip.vit_attention_means(qkv, o1, om1, F_, ntok, D, H)
+    op = torch.full((F_ * ntok, 2 * D), float("nan"), device="cuda", dtype=torch.float16)
+    om2 = torch.full((F_, D), float("nan"), device="cuda", dtype=torch.bfloat16)
+    hip.vit_attention_pair(qkv, op, om2, F_, ntok, D, H)
+    hi, lo = op[:, :D], op[:, D:]
+    assert torch.equal(hi.contiguous(), o1) and torch.equal(om1, om2)
+    assert not torch.isnan(lo.float()).any()
+    ulp_hi = torch.pow(2.0, torch.floor(torch.log2(hi.float().abs().clamp_min(2.0 ** -14))) - 10)
+    assert bool((lo.float().abs() <= 0.5 * ulp_hi * 1.001).all())
+    ref = _ref_attention(qkv.cpu(), F_, ntok, D, H)
+    e_hi = float((hi.float().cpu() - ref).pow(2).mean().sqrt())
+    e_pair = float((hi.float().cpu() + lo.float().cpu() - ref).pow(2).mean().sqrt())
+    assert e_pair < 0.9 * e_hi, (e_pair, e_hi)
+
+
+@pytest.mark.parametrize("M,N,K", [(5000, 768, 768), (197 * 40, 1024, 1024), (300, 128, 128), (70000, 768, 768)])
+@pytest.mark.parametrize("two_word", [True, False])
+def test_gemm_residual_wide_two_word_operands(hip, M, N, K, two_word):
+    """cfsar_gemm_residual_wide, wsplit = 2 (round 6, fp16_strict's out_proj): A [M, 2 K] = [a_hi | a_lo] against W [N, 3 K] = [w_hi | w_hi | w_lo] in
+    one fp32 accumulation chain = x + (a_hi + a_lo)(w_hi + w_lo)^T + b up to the a_lo w_lo term (2^-24) and fp32 round-off; the same call on
+    one-word operands (wsplit = 0 on a_hi, w_hi) is measurably farther from the reference on the unrounded operands."""
+    g = torch.Generator().manual_seed(71)
+    A32 = (torch.randn(M, K, generator=g) * 0.7).cuda()
+    Ah = A32.to(torch.float16)
+    Ap = torch.cat([Ah, (A32 - Ah.float()).to(torch.float16)], 1).contiguous()
+    W32 = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    Wh = W32.to(torch.float16)
+    Wl = (W32 - Wh.float()).to(torch.float16)
+    W3 = torch.cat([Wh, Wh, Wl], 1).contiguous()
+    bias = torch.randn(N, generator=g).cuda()
+    x32 = (torch.randn(M, N, generator=g) * 3.0).cuda()
+    xh = x32.to(torch.float16)
+    xl = (x32 - xh.float()).to(torch.float16) if two_word else None
+    x0 = xh.double() + (xl.double() if two_word else 0.0)
+    ref = x0 + (Ap[:, :K].double() + Ap[:, K:].double()) @ (Wh.double() + Wl.double()).t() + bias.double()
+    xh2, xl2 = xh.clone(), (xl.clone() if two_word else None)
+    S = N // 64
+    part = torch.full((M, S, 2), float("nan"), device="cuda")
+    hip.gemm_residual_wide(Ap, W3, xh2, xl2, bias, part, wsplit=2)
+    got = xh2.double() + (xl2.double() if two_word else 0.0)
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    if two_word:
+        assert err < 3e-6 * scale, (err, scale)
+        xh3, xl3 = xh.clone(), xl.clone()
+        hip.gemm_residual_wide(Ah.contiguous(), Wh.contiguous(), xh3, xl3, bias, None)
+        err1 = float((xh3.double() + xl3.double() - ref).abs().max())
+        assert err1 > 20 * err, (err1, err)                        # the one-word operands' 11 bits
+    else:
+        ulp = torch.pow(2.0, torch.floor(torch.log2(torch.maximum(ref.abs(), torch.tensor(2.0 ** -14, dtype=torch.float64, device="cuda")))) - 10)
+        assert bool(((got - ref).abs() <= 0.5 * ulp + 2e-6 * scale).all())
+    hs = xh2.float().reshape(M, S, 64)
+    assert maxdiff(part[:, :, 0], hs.sum(2)) < 1e-4 * max(1.0, float(hs.sum(2).abs().max()))
+    with pytest.raises(RuntimeError, match="no per-frame correction"):
+        hip.gemm_residual_wide(Ap, W3, xh2, xl2, bias, None, wsplit=2, corr=torch.zeros((M + 196) // 197, N, device="cuda"), corr_tokens=197)
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 768, 768), (80, 768, 768), (81, 2304, 768), (200, 768, 3072), (1280, 3072, 768), (1283, 1024, 4096)])
 def test_frame_gemm_matches_fp32_and_is_row_invariant(hip, M, N, K):
     """cfsar_frame_gemm (the fp16 numerics mode's per-frame GEMMs, round 5): fp32 form == the fp32 product of the bf16 operands; bf16 form ==
