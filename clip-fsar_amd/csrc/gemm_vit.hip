@@ -881,12 +881,13 @@ static int gemm_lnfold_impl(const void* x, const void* Wg, void* out, const floa
     c.part = partial; c.part_slots = slots; c.part_eps = eps;
     c.M = M; c.N = N; c.K = K; c.lda = lda; c.ldw = ldw; c.ldo = ldo; c.ldr = 0;
     c.out_dtype = out_dtype; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F32; c.act = act; c.relu = 0;
-    // (the policies go by the K the launch WALKS: a split-weight launch of K = 768 is a K = 1 536 launch.  -DCFSAR_SPLIT_POLICY_BY_KA: by the operand's own
-    // K instead -- the LDS-DMA path and the band-fastest walk of the short-K launches; product-build A/B of round 6, tools/r06_runs)
-#ifdef CFSAR_SPLIT_POLICY_BY_KA
-    const int Kp = ka_;
-#else
+    // The policies go by the OPERAND's K: a split-weight launch of K = 768 walks 1 536 but keeps the short-K launches' LDS-DMA path (no spilled registers;
+    // the register-staged LN-folded instances spill 29-35) and band-fastest walk.  Product-build A/B in separate processes, round 6 (profiles/r06_split_policy.txt):
+    // strict mode with split QKV 234.8 -> 239.1 episodes/s, split QKV + c_fc 202.6 -> 210.5, split all 191.5 -> 198.1.  -DCFSAR_SPLIT_POLICY_BY_WALK: by the walked K.
+#ifdef CFSAR_SPLIT_POLICY_BY_WALK
     const int Kp = K;
+#else
+    const int Kp = ka_;
 #endif
     c.opath = vit_policy_opath(Kp, 0); c.store = vit_policy_store(2); c.group = vit_policy_group(Kp); c.colfast = vit_policy_colfast(Kp); c.dbg = 0;
     c.hb_tokens = hb_tokens; c.hb_heads = hb_heads; c.ha_tokens = 0;
@@ -1024,10 +1025,10 @@ extern "C" int cfsar_gemm_residual_wide(const void* A, const void* W, void* x_hi
     c.part = nullptr; c.part_slots = 0; c.part_eps = 0.f;
     c.M = M; c.N = N; c.K = Kt; c.lda = lda; c.ldw = ldw; c.ldo = ldx; c.ldr = ldx;
     c.out_dtype = CFSAR_F16; c.in_dtype = CFSAR_F16; c.res_dtype = CFSAR_F16; c.act = CFSAR_ACT_NONE; c.relu = 0;
-#ifdef CFSAR_SPLIT_POLICY_BY_KA
-    const int Kp = K;
-#else
+#ifdef CFSAR_SPLIT_POLICY_BY_WALK
     const int Kp = Kt;
+#else
+    const int Kp = K;                // (see gemm_lnfold_impl: the policies go by the operand's K)
 #endif
     c.opath = vit_policy_opath(Kp, 2); c.store = vit_policy_store(0); c.group = vit_policy_group(Kp); c.colfast = vit_policy_colfast(Kp); c.dbg = 0;
     c.hb_tokens = 0; c.hb_heads = 0; c.ha_tokens = 0;

@@ -31,6 +31,12 @@ from . import hip
 # 6.7 / 5.5 / 5.3 at 194;  neither 3.3 / 2.8 / 5.0 and 9.0 / 9.3 / 16.0 at 308.
 FP16_SPLIT_DEFAULT = ""
 FP16_MCORR_DEFAULT = "qkv,out,fc,pr"
+# fp16_strict (round 6; profiles/r06_strict_eval.md): the QKV GEMM carries split weights, the other three keep the per-frame correction.  On high-contrast
+# ViT-L/14 episodes and on outlier-channel weights a frame's tokens differ a lot from their mean, and what the correction leaves of the LN-folded QKV weights'
+# rounding -- it reaches the logits through q k^T, twice -- is then the largest term: 13 reference episodes of hc_cfg4, max |dlogits| 1.06e-3 with the correction,
+# 7.4e-4 with split QKV weights (split c_fc instead: 9.3e-4; both: 5.8e-4 at 0.57 x the bf16 rate).
+FP16_STRICT_SPLIT_DEFAULT = "qkv"
+FP16_STRICT_MCORR_DEFAULT = "out,fc,pr"
 
 
 def _round_up(x, m):
@@ -44,7 +50,7 @@ class HipViT:
     # statistics fusion.  They are constructor arguments -- the product path reads four environment variables only (CFSAR_LN_FOLD,
     # CFSAR_FULL_LAST_BLOCK, CFSAR_FP16_SPLIT, CFSAR_FP16_MCORR).
     OPTIONS = {"fp16_wide": True, "fp16_lo": True, "fp16_rawmeans": True, "fused_umeans": True, "fused_omeans": True, "fuse_stats": True,
-               "fused_patch": True, "strict_front": True, "strict_o_pair": True}
+               "fused_patch": True, "strict_front": True, "strict_o_pair": False}
 
     def __init__(self, arch: dict, sd: dict, prefix: str = "", precision: str = "bf16", device="cuda", stream_dtype=None, fp16_split=None, fp16_mcorr=None,
                  options=None):
@@ -139,7 +145,8 @@ class HipViT:
         # options fp16_wide / fp16_lo and CFSAR_FP16_SPLIT override the defaults (ablation: tools/fp16_variants.py).
         self.wide = precision == "fp16" and opt["fp16_wide"]
         self.two_word = self.wide and opt["fp16_lo"]
-        sp = os.environ.get("CFSAR_FP16_SPLIT", FP16_SPLIT_DEFAULT if fp16_split is None else fp16_split) if precision == "fp16" else ""
+        sp_default, mc_default = (FP16_STRICT_SPLIT_DEFAULT, FP16_STRICT_MCORR_DEFAULT) if self.strict else (FP16_SPLIT_DEFAULT, FP16_MCORR_DEFAULT)
+        sp = os.environ.get("CFSAR_FP16_SPLIT", sp_default if fp16_split is None else fp16_split) if precision == "fp16" else ""
         self.split = set(t for t in sp.split(",") if t)
         #   mcorr  -- which GEMMs get the PER-FRAME LOW-WORD CORRECTION instead: the second weight word multiplies only the per-frame
         #             token mean of the GEMM's operand ([F, K] x W_lo^T, a 1 / tokens-size GEMM) and the [F, N] result is added to every row
@@ -147,7 +154,7 @@ class HipViT:
         #             frame's tokens -- most of what the split buys (tools/numerics_lab.py, scheme "m") -- for one pass over the operand
         #             instead of a second MFMA pass.  Needs >= 128 tokens per frame (tiny test towers fall back to the split); the
         #             last block's class-token rows (one row per frame) use the split form.
-        mc = os.environ.get("CFSAR_FP16_MCORR", FP16_MCORR_DEFAULT if fp16_mcorr is None else fp16_mcorr) if precision == "fp16" else ""
+        mc = os.environ.get("CFSAR_FP16_MCORR", mc_default if fp16_mcorr is None else fp16_mcorr) if precision == "fp16" else ""
         self.mcorr = set(t for t in mc.split(",") if t)
         if not (self.split | self.mcorr) <= {"qkv", "out", "fc", "pr"}:
             raise ValueError("CFSAR_FP16_SPLIT / CFSAR_FP16_MCORR: names out of qkv,out,fc,pr expected, got %r / %r" % (sp, mc))
@@ -233,8 +240,11 @@ class HipViT:
         # The LN-folded GEMMs' correction in its RAW-STREAM form: corr = xbar W_lo^T with xbar the per-frame token mean of the raw stream (the row
         # mean's share rides in cvec = the exact column sums of W gamma).  xbar needs no pass over x: the stream's update x += A W^T + b is linear
         # in the frame's token mean, so xbar += mean_t(A) W^T + b from the operand means the residual GEMMs' own corrections already have.
+        # (needs the residual GEMMs' operand means -- "out" and "pr" corrected -- for the updates; an LN-folded GEMM that is SPLIT instead of corrected simply
+        # takes no correction, and its cvec = the exact column sums serves the split weights as well: they differ from the hi + lo sums by 2^-22)
         self.rawmeans = (opt["fp16_rawmeans"] and self.fused_umeans and self.fused_omeans
-                         and all(k in self.mcorr for k in ("qkv", "out", "fc", "pr")))
+                         and all(k in self.mcorr for k in ("out", "pr")) and all(k in self.mcorr | self.split for k in ("qkv", "fc"))
+                         and bool(self.mcorr & {"qkv", "fc"}))
         if self.rawmeans:
             for i, blk in enumerate(self.blocks):
                 bb = "transformer.resblocks.%d." % i
@@ -256,9 +266,10 @@ class HipViT:
                 w_hi = w32.to(torch.float16)
                 w_lo = (w32 - w_hi.float()).to(torch.float16)
                 self.w_patch3 = torch.cat([w_hi, w_hi, w_lo], 1).contiguous()      # [D, 3 kpad]
-            # ... and the attention output keeps two fp16 words, out_proj = [o_hi | o_lo] x [W_hi | W_hi | W_lo] (three passes of the smallest block GEMM):
-            # the attention output's rounding is a tenth (ViT-B/16) to a fifth (ViT-L/14) of what is left, out_proj's weight remainder another tenth on
-            # ViT-L/14 (tools/strict_eval.py: cfg4 rms 1.77e-4 -> 1.56e-4 with split out_proj weights alone).  Needs the attention kernel's means form.
+            # Option strict_o_pair (built, measured, OFF): the attention output in two fp16 words and out_proj = [o_hi | o_lo] x [W_hi | W_hi | W_lo] (three
+            # passes of the smallest block GEMM).  The CPU budget gave it a tenth (ViT-B/16) to a fifth (ViT-L/14) of what the front end leaves; measured it
+            # moves the six reference sets by -4 ... +7 % in rms (hc_cfg4 3.64e-4 -> 3.61e-4) and fresh cfg4 episodes by -14 %, for 11 % of the step
+            # (303.7 -> 270.8 episodes/s): profiles/r06_strict_eval.md.  Needs the attention kernel's means form.
             self.o_pair = bool(opt["strict_o_pair"]) and self.fused_omeans and "out" in self.mcorr and D % 128 == 0
             if self.o_pair:
                 for i, blk in enumerate(self.blocks):

@@ -484,6 +484,23 @@ def test_strict_mode_is_the_fp16_mode_plus_its_front_end():
     ar, sdr, ttr, ter, _ = case_inputs(gr["meta"])
     with pytest.raises(ValueError, match="fp16_strict"):
         ClipFsarEngine(ar, sdr, ttr, ter, precision="fp16_strict", device="cuda")
+    # the mode's defaults: split QKV weights, the per-frame correction on the other three GEMMs, its raw-stream form kept for c_fc
+    gc = load_golden("cfg2_B16_5w1s_T8")
+    ac, hc_sd, _, _, _ = case_inputs(gc["meta"])
+    vc = HipViT(ac, {k[len("backbone."):]: v for k, v in hc_sd.items() if k.startswith("backbone.")}, precision="fp16_strict")
+    assert vc.split == {"qkv"} and vc.mcorr == {"out", "fc", "pr"} and vc.rawmeans and vc.strict_front and not vc.o_pair
+
+
+def test_strict_option_two_word_attention_output():
+    """Developer option strict_o_pair (built and measured in round 6, off by default: 11 % of the step for -4 ... +7 % in rms on the reference sets,
+    profiles/r06_strict_eval.md): cfsar_vit_attention_pair + cfsar_gemm_residual_wide(wsplit = 2) end to end, inside the mode's bound."""
+    g = load_golden("cfg2_B16_5w1s_T8")
+    m = g["meta"]
+    a, sd, tt, te, ep = case_inputs(m)
+    lp, _ = run_engine(m, a, sd, tt, te, [ep], "fp16_strict", vit_options={"strict_o_pair": True})
+    ls, _ = run_engine(m, a, sd, tt, te, [ep], "fp16_strict", vit_options={})
+    assert maxdiff(lp[0], g["logits"]) < NORTH_STAR_TOLERANCE and maxdiff(ls[0], g["logits"]) < NORTH_STAR_TOLERANCE
+    assert not torch.equal(lp, ls)                                # the option is live
 
 
 def test_fp16_mode_b16_equals_b1():
