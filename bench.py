@@ -638,7 +638,7 @@ def run(args):
                                     kernel_events=not args.no_kernel_events)
     if (not dry and rank == 0 and world == 1 and args.precision == "bf16" and args.config == "cfg2" and not args.no_config_legs
             and B * frames_per_ep > 160):
-        # BASELINE configs[2..3] in front of the driver: 3 timed steps of the harness's batch (12 / 11 episodes), bf16 and fp16, with golden parity
+        # BASELINE configs[2..3] in front of the driver: 3 timed steps of the harness's batch (12 / 11 episodes), bf16, fp16 and fp16_strict, with golden parity
         config_legs = {}
         for cname in ("cfg3", "cfg4"):
             cc = CONFIGS[cname]
@@ -647,7 +647,7 @@ def run(args):
                 aa = synth.ARCHS[cc["arch"]]
                 w = ({k: torch.from_numpy(v) for k, v in synth.head_state_dict(cc["arch"], SEED).items()},
                      synth.text_features(N_TRAIN, aa["embed"], "train", SEED), synth.text_features(N_TEST, aa["embed"], "test", SEED))
-            for prec in ("bf16", "fp16"):
+            for prec in ("bf16", "fp16", "fp16_strict"):
                 config_legs["%s_%s" % (cname, prec)] = timed_leg(cname, prec, default_episodes_per_step(cname), 3, dev, timer, weights=w,
                                                                  kernel_events=not args.no_kernel_events)
             del w

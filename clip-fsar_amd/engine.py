@@ -37,6 +37,11 @@ FP16_MCORR_DEFAULT = "qkv,out,fc,pr"
 # 7.4e-4 with split QKV weights (split c_fc instead: 9.3e-4; both: 5.8e-4 at 0.57 x the bf16 rate).
 FP16_STRICT_SPLIT_DEFAULT = "qkv"
 FP16_STRICT_MCORR_DEFAULT = "out,fc,pr"
+# Towers deeper than 12 blocks (ViT-L/14: 24) also split c_fc: 64 fresh HIGH-CONTRAST cfg4 episodes (logits spread 5.4), max |dlogits| 1.05e-3 / 2 episodes over
+# 1e-3 with split QKV alone, 8.3e-4 / none with c_fc split as well (0.64 x instead of 0.75 x the tower's bf16 rate; profiles/r06_strict_eval.md).
+FP16_STRICT_DEEP_LAYERS = 12
+FP16_STRICT_SPLIT_DEEP_DEFAULT = "qkv,fc"
+FP16_STRICT_MCORR_DEEP_DEFAULT = "out,pr"
 
 
 def _round_up(x, m):
@@ -145,7 +150,11 @@ class HipViT:
         # options fp16_wide / fp16_lo and CFSAR_FP16_SPLIT override the defaults (ablation: tools/fp16_variants.py).
         self.wide = precision == "fp16" and opt["fp16_wide"]
         self.two_word = self.wide and opt["fp16_lo"]
-        sp_default, mc_default = (FP16_STRICT_SPLIT_DEFAULT, FP16_STRICT_MCORR_DEFAULT) if self.strict else (FP16_SPLIT_DEFAULT, FP16_MCORR_DEFAULT)
+        sp_default, mc_default = FP16_SPLIT_DEFAULT, FP16_MCORR_DEFAULT
+        if self.strict:
+            deep = self.L > FP16_STRICT_DEEP_LAYERS
+            sp_default = FP16_STRICT_SPLIT_DEEP_DEFAULT if deep else FP16_STRICT_SPLIT_DEFAULT
+            mc_default = FP16_STRICT_MCORR_DEEP_DEFAULT if deep else FP16_STRICT_MCORR_DEFAULT
         sp = os.environ.get("CFSAR_FP16_SPLIT", sp_default if fp16_split is None else fp16_split) if precision == "fp16" else ""
         self.split = set(t for t in sp.split(",") if t)
         #   mcorr  -- which GEMMs get the PER-FRAME LOW-WORD CORRECTION instead: the second weight word multiplies only the per-frame

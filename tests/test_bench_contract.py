@@ -125,6 +125,9 @@ def test_bench_line_bf16_parity_roofline_rccl_ws1():
     # ratio to the bf16 rate 0.845 (README, head warning): guard at 0.9 x that
     assert f16["parity"]["within_tolerance"] and f16["parity"]["argmax_equal"] and f16["value"] > 0.76 * out["value"], f16
     assert 0 < f16["roofline"]["frac"] <= 1, f16
+    st = out["strict_mode"]                                 # round 6: the 16-bit mode whose contract is a bound, same steps
+    assert st["precision"] == "fp16_strict" and st["parity"]["meets_north_star"] and st["parity"]["argmax_equal"], st
+    assert st["value"] > 0.66 * out["value"] and 0 < st["roofline"]["frac"] <= 1, st          # measured 0.738 x the bf16 rate at 36 episodes per step
     assert out["collective"]["rccl_world_size"] == 1 and out["collective"]["backend"] == "nccl", out["collective"]
     assert out["per_rank_episodes_per_s"]["ranks"] == 1
     r = out["roofline"]
@@ -152,12 +155,12 @@ def test_bench_self_spawn_two_gpus_rccl():
 @needs_gpu
 def test_bench_line_carries_cfg3_cfg4_legs():
     """BASELINE configs[2..3] in front of the driver: the default run's `configs` object holds short cfg3 / cfg4 legs in
-    bf16 and fp16, each with its rate, roofline fractions and golden parity."""
+    bf16, fp16 and fp16_strict, each with its rate, roofline fractions and golden parity."""
     out = _run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fp16-leg"])
     from clip_fsar_amd import LOGITS_TOLERANCE
     legs = out["configs"]
-    assert sorted(legs) == ["cfg3_bf16", "cfg3_fp16", "cfg4_bf16", "cfg4_fp16"]
+    assert sorted(legs) == ["cfg3_bf16", "cfg3_fp16", "cfg3_fp16_strict", "cfg4_bf16", "cfg4_fp16", "cfg4_fp16_strict"]
     for name, leg in legs.items():
-        prec = name.split("_")[1]
+        prec = name.split("_", 1)[1]
         assert leg["value"] > 0 and 0 < leg["roofline"]["frac_end_to_end"] <= leg["roofline"]["frac"] + 0.05, leg
         assert leg["parity"]["checked"] and leg["parity"]["argmax_equal"] and leg["parity"]["max_abs_dlogits"] < LOGITS_TOLERANCE[prec], leg
