@@ -107,7 +107,7 @@ class GemmTimer:
             self.k_div = 3
             return orig_split(*a, **k)
         self.hip.im2col_patches_split = split_marker
-        # the patch-embed GEMM that gathers its rows from the frames (cfsar_patch_embed): 2 x (frames x patches) x D x 768
+        # the patch-embed GEMM that gathers its rows from the frames (cfsar_patch_embed): 2 x (frames x patches) x D x 3 P^2
         orig_pe = self.hip.patch_embed
 
         def timed_pe(frames, w, pos, cls, x, *a, **k):
@@ -118,7 +118,8 @@ class GemmTimer:
             r = orig_pe(frames, w, pos, cls, x, *a, **k)
             e.record()
             self.events.append((s, e))
-            self.flops += 2.0 * frames.shape[0] * (pos.shape[0] - 1) * w.shape[0] * 768
+            patch = k.get("patch", a[0] if a else 16)
+            self.flops += 2.0 * frames.shape[0] * (pos.shape[0] - 1) * w.shape[0] * 3 * patch * patch      # algorithmic K = 3 P^2 (the 14 x 14 form walks 704 padded slots)
             self.launches += 1
             return r
         self.hip.patch_embed = timed_pe

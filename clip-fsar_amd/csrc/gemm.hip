@@ -790,8 +790,13 @@ struct PatchArgs {
     int H, Wd, gw, npatch, F;
 };
 
-template <typename TI, typename TO>
+// P = 14 (ViT-L/14; round 6): 14 pixels are 56 bytes -- a patch row is 8-byte aligned only and 64 K slots do not hold whole rows.  The K axis is
+// therefore laid out in PADDED rows: k' = (c 14 + dy) 16 + dx with dx = 14, 15 zero, 42 rows = 672 slots, padded to 704 = 11 slices of 4 rows; the weight
+// matrix is handed over in the same layout (host side, once).  A lane's chunk is then px 0..7 (four 8-byte loads) or px 8..13 + two zeros (three loads
+// + one re-load of a valid address whose value is discarded: every lane issues the same loads per slice, no divergent control flow in the K loop).
+template <typename TI, typename TO, int P = 16>
 __global__ __launch_bounds__(NTHREADS2) void patch_embed_kernel(PatchArgs q) {
+    static_assert(P == 16 || P == 14, "patch size 16 or 14");
     const GemmArgs& p = q.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -818,7 +823,8 @@ __global__ __launch_bounds__(NTHREADS2) void patch_embed_kernel(PatchArgs q) {
         gm = gm < p.M ? gm : p.M - 1;
         const int f = gm / q.npatch, pp = gm - f * q.npatch;
         const int py = pp / q.gw, px = pp - py * q.gw;
-        srcX[i] = q.frames + ((size_t)f * 3 * q.H + py * 16 + (chunk >> 1)) * q.Wd + px * 16 + (chunk & 1) * 8;
+        if constexpr (P == 16) srcX[i] = q.frames + ((size_t)f * 3 * q.H + py * 16 + (chunk >> 1)) * q.Wd + px * 16 + (chunk & 1) * 8;
+        else srcX[i] = q.frames + ((size_t)f * 3 * q.H + py * 14) * q.Wd + px * 14 + (chunk & 1) * 8;      // + the slice's (channel, row) offset: load_x
     }
     const char* srcW[2];
 #pragma unroll
@@ -838,11 +844,35 @@ __global__ __launch_bounds__(NTHREADS2) void patch_embed_kernel(PatchArgs q) {
     };
     // slice kt = channel kt / 4, image rows 4 (kt % 4) .. + 3 of the patch
     auto load_x = [&](int kt, f32x4 (&xr)[8]) __attribute__((always_inline)) {
-        const size_t off = ((size_t)(kt >> 2) * q.H + (kt & 3) * 4) * q.Wd;
+        if constexpr (P == 16) {
+            const size_t off = ((size_t)(kt >> 2) * q.H + (kt & 3) * 4) * q.Wd;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            xr[2 * i] = *reinterpret_cast<const f32x4*>(srcX[i] + off);
-            xr[2 * i + 1] = *reinterpret_cast<const f32x4*>(srcX[i] + off + 4);
+            for (int i = 0; i < 4; ++i) {
+                xr[2 * i] = *reinterpret_cast<const f32x4*>(srcX[i] + off);
+                xr[2 * i + 1] = *reinterpret_cast<const f32x4*>(srcX[i] + off + 4);
+            }
+        } else {
+            // padded row r = 4 kt + j (j = the lane's row inside the slice): channel r / 14, image row r % 14 of the patch; r >= 42: zeros
+            const int j = chunk >> 1;
+            const bool hi8 = chunk & 1;                    // px 8 .. 13 (+ two zero slots)
+            size_t offj[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int r = 4 * kt + jj;
+                const int rr = r < 42 ? r : 0;             // (a valid address; the values are discarded)
+                offj[jj] = ((size_t)(rr / 14) * q.H + (rr % 14)) * q.Wd;
+            }
+            const size_t off = j == 0 ? offj[0] : (j == 1 ? offj[1] : (j == 2 ? offj[2] : offj[3]));
+            const bool valid = 4 * kt + j < 42;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* src = srcX[i] + off;
+                const f32x2 a0 = *reinterpret_cast<const f32x2*>(src), a1 = *reinterpret_cast<const f32x2*>(src + 2);
+                const f32x2 a2 = *reinterpret_cast<const f32x2*>(src + 4), a3 = *reinterpret_cast<const f32x2*>(hi8 ? src : src + 6);
+                xr[2 * i] = f32x4{valid ? a0[0] : 0.f, valid ? a0[1] : 0.f, valid ? a1[0] : 0.f, valid ? a1[1] : 0.f};
+                xr[2 * i + 1] = f32x4{valid ? a2[0] : 0.f, valid ? a2[1] : 0.f, (valid && !hi8) ? a3[0] : 0.f, (valid && !hi8) ? a3[1] : 0.f};
+            }
         }
     };
     auto write_x = [&](int stage, const f32x4 (&xr)[8]) __attribute__((always_inline)) {
@@ -880,7 +910,10 @@ __global__ __launch_bounds__(NTHREADS2) void patch_embed_kernel(PatchArgs q) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    constexpr int nk = 12;                       // K = 768 (launcher)
+    constexpr int nk = P == 16 ? 12 : 11;        // K = 768 | 704 padded-row slots (launcher)
+    // register-load INSTRUCTIONS of one slice per lane, as a lower bound (the explicit wait below may only name operations that were really issued behind
+    // W(kt)): P = 16 exactly eight 16-byte loads; P = 14 at least eight -- hipcc (ROCm 7.2) emits twelve: one 16-byte + two 8-byte per piece
+    constexpr int NXL = 8;
     f32x4 xa[8], xb[8];                          // even / odd slices
     issue_w(0, 0);
     issue_w(1, 1);
@@ -898,8 +931,8 @@ __global__ __launch_bounds__(NTHREADS2) void patch_embed_kernel(PatchArgs q) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // last slice: its W
         // The barrier publishes W of slice kt (two asm LDS-DMA pieces per wave, issued two iterations ago).  hipcc's own wait in front of write_x
         // (for the registers of slice kt + 1, requested AFTER that DMA) already covers it -- but hipcc does not count the asm DMA, so the
-        // requirement is also stated explicitly: behind W(kt) this wave issued X(kt + 1): 8 loads, W(kt + 1): 2, X(kt + 2): 8.
-        if constexpr (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(10 + (kt + 2 < nk ? 8 : 0)) : "memory");
+        // requirement is also stated explicitly: behind W(kt) this wave issued X(kt + 1): NXL loads, W(kt + 1): 2, X(kt + 2): NXL.
+        if constexpr (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NXL + 2 + (kt + 2 < nk ? NXL : 0)) : "memory");
         __syncthreads();
         if constexpr (kt + 2 < nk) issue_w(st2, kt + 2);
         if constexpr (kt + 3 < nk) load_x(kt + 3, xnext);
@@ -914,11 +947,11 @@ __global__ __launch_bounds__(NTHREADS2) void patch_embed_kernel(PatchArgs q) {
     else epilogue_lds<TO, CFSAR_ACT_NONE, true, true, false>(accp, p, mb, nb, lane, smem + wave * EPI_WAVE_BYTES);
 }
 
-template <typename TI, typename TO>
+template <typename TI, typename TO, int P = 16>
 int launch_patch_embed(const PatchArgs& a, hipStream_t s) {
-    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&patch_embed_kernel<TI, TO>), NSTAGE2 * STAGE2, "cfsar_patch_embed")) return rc;
+    if (int rc = cfsar_ensure_lds(reinterpret_cast<const void*>(&patch_embed_kernel<TI, TO, P>), NSTAGE2 * STAGE2, "cfsar_patch_embed")) return rc;
     const int tiles_m = (a.g.M + BM2 - 1) / BM2;
-    hipLaunchKernelGGL((patch_embed_kernel<TI, TO>), dim3(tiles_m * a.g.tiles_n), dim3(NTHREADS2), NSTAGE2 * STAGE2, s, a);
+    hipLaunchKernelGGL((patch_embed_kernel<TI, TO, P>), dim3(tiles_m * a.g.tiles_n), dim3(NTHREADS2), NSTAGE2 * STAGE2, s, a);
     return cfsar_check_launch("cfsar_patch_embed");
 }
 
@@ -1825,18 +1858,20 @@ extern "C" int cfsar_gemm_ex(const void* A, const void* W, void* out, const floa
 extern "C" int cfsar_patch_embed(const float* frames, const void* W, int w_dtype, const float* pos, const float* cls, void* x, int x_dtype,
                                  int F, int H, int Wd, int P, int D, int ldw, cfsar_stream_t stream) {
     CFSAR_REQUIRE(frames && W && pos && cls && x, "cfsar_patch_embed: null pointer");
-    CFSAR_REQUIRE(P == 16, "cfsar_patch_embed: patch size %d (the fused gather exists for 16 x 16 patches; other sizes: cfsar_im2col_patches + cfsar_gemm_ex)", P);
-    CFSAR_REQUIRE(F > 0 && H > 0 && Wd > 0 && H % 16 == 0 && Wd % 16 == 0, "cfsar_patch_embed: bad geometry F=%d H=%d W=%d", F, H, Wd);
-    CFSAR_REQUIRE(D > 0 && D % 4 == 0 && ldw >= 768 && ldw % 8 == 0, "cfsar_patch_embed: bad D=%d / ldw=%d", D, ldw);
+    CFSAR_REQUIRE(P == 16 || P == 14, "cfsar_patch_embed: patch size %d (the fused gather exists for 16 x 16 and 14 x 14 patches; other sizes: cfsar_im2col_patches + cfsar_gemm_ex)", P);
+    CFSAR_REQUIRE(F > 0 && H > 0 && Wd > 0 && H % P == 0 && Wd % P == 0 && Wd % 2 == 0, "cfsar_patch_embed: bad geometry F=%d H=%d W=%d", F, H, Wd);
+    const int Kslots = P == 16 ? 768 : 704;             // P = 14: padded rows, k' = (c 14 + dy) 16 + dx (see the header)
+    CFSAR_REQUIRE(D > 0 && D % 4 == 0 && ldw >= Kslots && ldw % 8 == 0, "cfsar_patch_embed: bad D=%d / ldw=%d (>= %d)", D, ldw, Kslots);
+    CFSAR_REQUIRE(((size_t)frames & 7) == 0, "cfsar_patch_embed: frames must be 8-byte aligned");
     CFSAR_REQUIRE(w_dtype == CFSAR_BF16 || w_dtype == CFSAR_F16, "cfsar_patch_embed: weights must be bf16 or fp16, got %d", w_dtype);
     CFSAR_REQUIRE(x_dtype == CFSAR_F16, "cfsar_patch_embed: x must be the fp16 residual stream, got dtype %d", x_dtype);
     PatchArgs a;
-    a.frames = frames; a.cls = cls; a.H = H; a.Wd = Wd; a.gw = Wd / 16; a.npatch = (H / 16) * (Wd / 16); a.F = F;
+    a.frames = frames; a.cls = cls; a.H = H; a.Wd = Wd; a.gw = Wd / P; a.npatch = (H / P) * (Wd / P); a.F = F;
     CFSAR_REQUIRE((long long)F * a.npatch < (1ll << 31) / 2 && (long long)F * 3 * H * Wd < (1ll << 40), "cfsar_patch_embed: too many frames");
     GemmArgs& g = a.g;
     g.A = nullptr; g.W = static_cast<const char*>(W); g.out = x; g.bias = nullptr; g.res = pos; g.res_kind = 0; g.relu = 0;
-    g.M = F * a.npatch; g.N = D; g.K = 768;
-    g.lda = 768; g.ldw = ldw; g.ldo = D; g.ldr = D;
+    g.M = F * a.npatch; g.N = D; g.K = Kslots;
+    g.lda = Kslots; g.ldw = ldw; g.ldo = D; g.ldr = D;
     g.act = CFSAR_ACT_NONE;
     g.row_group = a.npatch; g.row_gap = 1; g.row_off = 1; g.res_mod = a.npatch; g.res_off = 1;
     g.tiles_n = (D + BN2 - 1) / BN2; g.ntiles = 0;
@@ -1845,6 +1880,7 @@ extern "C" int cfsar_patch_embed(const float* frames, const void* W, int w_dtype
     g.dbg = 0;
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (P == 14) return w_dtype == CFSAR_F16 ? launch_patch_embed<_Float16, _Float16, 14>(a, s) : launch_patch_embed<__bf16, _Float16, 14>(a, s);
     return w_dtype == CFSAR_F16 ? launch_patch_embed<_Float16, _Float16>(a, s) : launch_patch_embed<__bf16, _Float16>(a, s);
 }
 

@@ -107,10 +107,12 @@ class HipViT:
         wc = torch.zeros(D, self.kpad, device=self.dev, dtype=torch.float32)
         wc[:, :3 * P * P] = g("conv1.weight").reshape(D, -1)
         self.w_patch = wc.to(cd).contiguous()
-        # patch gather inside the patch-embed GEMM (16 x 16 patches, 16-bit operands, 16-bit stream); "fused_patch": False keeps the
-        # three-launch form (the A/B and bit-equality tests)
-        self.fused_patch = bool(opt["fused_patch"] and P == 16 and self.kpad == 768 and cd in (torch.bfloat16, torch.float16)
+        # patch gather inside the patch-embed GEMM (16 x 16 and 14 x 14 patches, 16-bit operands, 16-bit stream); "fused_patch": False keeps
+        # the three-launch form (the A/B and bit-equality tests)
+        self.fused_patch = bool(opt["fused_patch"] and P in hip.PATCH_EMBED_SLOTS and cd in (torch.bfloat16, torch.float16)
                                 and self.xd == torch.float16)
+        if self.fused_patch:             # 14 x 14 patches (ViT-L/14, round 6): the kernel's padded-row column layout, [D, 704]
+            self.w_patch_fused = self.w_patch if P == 16 else hip.patch_embed_weight(g("conv1.weight"), P, cd)
         self.cls = g("class_embedding")
         self.pos = g("positional_embedding")
         self.ln_pre = (g("ln_pre.weight"), g("ln_pre.bias"))
@@ -363,7 +365,7 @@ class HipViT:
             if fr.shape[1:] != (3, self.arch["res"], self.arch["res"]):
                 raise RuntimeError("frames must be [F,3,%d,%d], got %s" % (self.arch["res"], self.arch["res"], tuple(fr.shape)))
             if self.fused_patch:
-                hip.patch_embed(fr, self.w_patch, self.pos, self.cls, x[off * N:(off + c) * N], self.P)
+                hip.patch_embed(fr, self.w_patch_fused, self.pos, self.cls, x[off * N:(off + c) * N], self.P)
             elif self.strict_front:
                 hip.im2col_patches_split(fr, ws["patches"][off * npatch:(off + c) * npatch], self.P)
             else:

@@ -201,9 +201,25 @@ def embed_finish_pair(tok, cls, pos, ln_w, ln_b, x_hi, x_lo, F_, ntok, D, eps=1e
                                          _dev(x_lo, torch.float16, "x_lo"), F_, ntok, D, eps, _stream()), "cfsar_embed_finish_pair")
 
 
+PATCH_EMBED_SLOTS = {16: 768, 14: 704}       # K slots of cfsar_patch_embed's weight matrix (14: padded rows, see patch_embed_weight)
+
+
 def patch_embed_ok(patch, w, x):
-    """cfsar_patch_embed serves 16 x 16 patches with bf16 / fp16 weights [D, >= 768] into the fp16 residual stream."""
-    return patch == 16 and w.dtype in (torch.bfloat16, torch.float16) and w.shape[1] >= 768 and x.dtype == torch.float16
+    """cfsar_patch_embed serves 16 x 16 and 14 x 14 patches with bf16 / fp16 weights [D, >= 768 | 704] into the fp16 residual stream."""
+    return patch in PATCH_EMBED_SLOTS and w.dtype in (torch.bfloat16, torch.float16) and w.shape[1] >= PATCH_EMBED_SLOTS[patch] and x.dtype == torch.float16
+
+
+def patch_embed_weight(conv_w, patch, dtype):
+    """conv1.weight [D, 3, P, P] fp32 -> the weight matrix cfsar_patch_embed reads (layout only, then one rounding to `dtype`): P = 16: [D, 768]
+    = reshape; P = 14: [D, 704] in PADDED ROWS, column (c*14 + dy)*16 + dx, zeros at dx = 14, 15 and behind column 672."""
+    D = conv_w.shape[0]
+    if patch == 16:
+        return conv_w.reshape(D, 768).to(dtype).contiguous()
+    w = torch.zeros(D, 3, 14, 16, device=conv_w.device, dtype=torch.float32)
+    w[..., :14] = conv_w.reshape(D, 3, 14, 14)
+    out = torch.zeros(D, 704, device=conv_w.device, dtype=torch.float32)
+    out[:, :672] = w.reshape(D, 672)
+    return out.to(dtype).contiguous()
 
 
 def patch_embed(frames, w, pos, cls, x, patch=16):
@@ -214,7 +230,7 @@ def patch_embed(frames, w, pos, cls, x, patch=16):
     D = pos.shape[1]
     ntok = (H // patch) * (W // patch) + 1
     if pos.shape[0] != ntok or cls.numel() != D or w.shape[0] != D:
-        raise RuntimeError("patch_embed: pos must be [%d, D], cls [D], w [D, >= 768]; got pos %s, cls %s, w %s" % (ntok, tuple(pos.shape), tuple(cls.shape), tuple(w.shape)))
+        raise RuntimeError("patch_embed: pos must be [%d, D], cls [D], w [D, >= %d]; got pos %s, cls %s, w %s" % (ntok, PATCH_EMBED_SLOTS.get(patch, 768), tuple(pos.shape), tuple(cls.shape), tuple(w.shape)))
     if x.shape[-1] != D or not x.is_contiguous() or x.numel() < F_ * ntok * D:
         raise RuntimeError("patch_embed: x must be contiguous with at least %d rows of %d, got %s" % (F_ * ntok, D, tuple(x.shape)))
     _check(lib().cfsar_patch_embed(_dev(frames, torch.float32, "frames"), _dev(w, None, "w"), _code(w.dtype), _dev(pos, torch.float32, "pos"),

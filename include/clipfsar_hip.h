@@ -70,13 +70,17 @@ int cfsar_im2col_patches(const float* frames, void* out, int out_dtype, int F, i
  * mode's logits error (profiles/r06_strict_budget.md) and 0.7 % of the tower's FLOPs. */
 int cfsar_im2col_patches_split(const float* frames, void* out, int F, int H, int W, int P, int k_pad, cfsar_stream_t stream);
 
-/* ---- A2 in ONE launch (few_shot.py:659, 672-676) for 16 x 16 patches and 16-bit operands: conv1 as a GEMM whose rows are gathered
- * straight from the fp32 NCHW frames (no patch matrix), + pos[1 + p], scattered behind each frame's class-token row, and the class-token rows
- * cls + pos[0] themselves:  x[f*ntok + 1 + p, :] = patch(f, p) @ W.T + pos[1 + p],  x[f*ntok, :] = cls + pos[0],  ntok = (H/16)*(W/16) + 1.
- * frames [F,3,H,W] fp32; W [D, ldw >= 768] (w_dtype CFSAR_BF16 | CFSAR_F16; column k = c*256 + dy*16 + dx = conv1.weight.reshape(D, 768));
- * pos [ntok, D] fp32, cls [D] fp32; x [F*ntok, D] (x_dtype CFSAR_F16: the 16-bit modes' residual stream).  Frames are rounded to w_dtype in
- * registers; every output element is bit-identical to cfsar_im2col_patches + cfsar_gemm_ex (row remap) + cfsar_cls_rows_ex, which remain the
- * path for other patch sizes and for fp32 operands.  Replaces: self.conv1(x) ... x + positional_embedding (few_shot.py:672-676). */
+/* ---- A2 in ONE launch (few_shot.py:659, 672-676) for 16 x 16 and (round 6) 14 x 14 patches and 16-bit operands: conv1 as a GEMM whose rows
+ * are gathered straight from the fp32 NCHW frames (no patch matrix), + pos[1 + p], scattered behind each frame's class-token row, and the class-token rows
+ * cls + pos[0] themselves:  x[f*ntok + 1 + p, :] = patch(f, p) @ W.T + pos[1 + p],  x[f*ntok, :] = cls + pos[0],  ntok = (H/P)*(W/P) + 1.
+ * frames [F,3,H,W] fp32 (8-byte aligned); pos [ntok, D] fp32, cls [D] fp32; x [F*ntok, D] (x_dtype CFSAR_F16: the 16-bit modes' residual stream).
+ * W [D, ldw] (w_dtype CFSAR_BF16 | CFSAR_F16):
+ *   P = 16: ldw >= 768, column k = c*256 + dy*16 + dx = conv1.weight.reshape(D, 768);
+ *   P = 14: ldw >= 704, PADDED ROWS: column k' = (c*14 + dy)*16 + dx for dx < 14, columns with dx in {14, 15} and k' >= 672 zero (a patch row of 14
+ *           pixels is 56 bytes: the 64-slot K slices hold four 16-slot rows each; the caller lays the weights out once).
+ * Frames are rounded to w_dtype in registers; every output element is bit-identical to cfsar_gemm_ex (row remap, pos residual) on a patch matrix in the
+ * same column layout + cfsar_cls_rows_ex (P = 16: cfsar_im2col_patches makes that matrix).  Other patch sizes and fp32 operands keep
+ * cfsar_im2col_patches + cfsar_gemm_ex + cfsar_cls_rows_ex.  Replaces: self.conv1(x) ... x + positional_embedding (few_shot.py:672-676). */
 int cfsar_patch_embed(const float* frames, const void* W, int w_dtype, const float* pos, const float* cls, void* x, int x_dtype,
                       int F, int H, int Wd, int P, int D, int ldw, cfsar_stream_t stream);
 

@@ -228,14 +228,52 @@ def test_strict_patch_embedding_front_end(hip, F_, res, P, D):
     assert float(x_lo.float().abs().max()) <= 2.0 ** -11 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("wd", ["bf16", "f16"])
+@pytest.mark.parametrize("F_,res,D", [(6, 224, 1024), (5, 224, 192), (81, 224, 1024), (40, 56, 128)])
+def test_patch_embed_fused_14x14_equals_the_gemm_on_the_padded_row_matrix_bitwise(hip, wd, F_, res, D):
+    """cfsar_patch_embed for 14 x 14 patches (ViT-L/14; VERDICT r5 item 7): the K axis is laid out in padded rows, k' = (c 14 + dy) 16 + dx, 704 slots;
+    the launch equals cfsar_gemm (row remap, pos residual) on the patch matrix in that layout + cfsar_cls_rows bit for bit (same roundings, same MFMA
+    order), and the fp32 conv1 of the unrounded operands to the operands' 11 / 8 bits."""
+    tw = {"bf16": torch.bfloat16, "f16": torch.float16}[wd]
+    g = res // 14
+    npatch, ntok = g * g, g * g + 1
+    frames = _rand(F_, 3, res, res, seed=41)
+    conv_w = _rand(D, 3, 14, 14, seed=42) * 588 ** -0.5
+    pos, cls = (_rand(ntok, D, seed=43) * 0.3).cuda(), _rand(D, seed=44).cuda()
+    w = hip.patch_embed_weight(conv_w.cuda(), 14, tw)
+    assert tuple(w.shape) == (D, 704) and float(w.float().reshape(D, 44, 16)[:, :42, 14:].abs().max()) == 0.0 and float(w[:, 672:].float().abs().max()) == 0.0
+    x = torch.full((F_ * ntok, D), 7.0, device="cuda", dtype=torch.float16)
+    assert hip.patch_embed_ok(14, w, x)
+    hip.patch_embed(frames.cuda(), w, pos, cls, x, patch=14)
+    # the patch matrix in the kernel's column layout (pure data movement + the one rounding to the operand type)
+    pt = frames.reshape(F_, 3, g, 14, g, 14).permute(0, 2, 4, 1, 3, 5)                                   # [F, gy, gx, c, dy, dx]
+    pm = torch.zeros(F_, g, g, 3, 14, 16)
+    pm[..., :14] = pt
+    patches = torch.zeros(F_ * npatch, 704)
+    patches[:, :672] = pm.reshape(F_ * npatch, 672)
+    patches = patches.to(tw).cuda()
+    y = torch.full((F_ * ntok, D), 7.0, device="cuda", dtype=torch.float16)
+    hip.gemm(patches, w, y, residual=pos, M=F_ * npatch, N=D, K=704, ldo=D, ldr=D, row_group=npatch, row_gap=1, row_off=1, res_mod=npatch, res_off=1)
+    hip.cls_rows(y, cls, pos, F_, ntok, D)
+    torch.cuda.synchronize()
+    if F_ * npatch >= 1024:                        # (the generic small-M GEMM sums K in another order)
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16)), maxdiff(x.float().cpu(), y.float().cpu())
+    else:
+        assert maxdiff(x.float().cpu(), y.float().cpu()) < 2e-3
+    ref = torch.nn.functional.conv2d(frames, conv_w, stride=14).permute(0, 2, 3, 1).reshape(F_, npatch, D) + pos[1:].cpu()
+    ref = torch.cat([(cls + pos[0]).cpu().expand(F_, 1, D), ref], 1).reshape(F_ * ntok, D)
+    assert maxdiff(x.float().cpu(), ref) < (6e-3 if wd == "f16" else 3e-2)
+
+
 def test_patch_embed_rejects_what_it_does_not_serve(hip):
     frames = _rand(2, 3, 28, 28, seed=35).cuda()
     w = _rand(64, 768, seed=36).to(torch.bfloat16).cuda()
     pos, cls = _rand(5, 64, seed=37).cuda(), _rand(64, seed=38).cuda()
     x = torch.empty(2 * 5, 64, device="cuda", dtype=torch.float16)
-    with pytest.raises(RuntimeError, match="patch size 14"):
-        hip.patch_embed(frames, w, pos, cls, x, patch=14)
-    assert not hip.patch_embed_ok(14, w, x) and not hip.patch_embed_ok(16, w.float(), x) and not hip.patch_embed_ok(16, w, x.bfloat16())
+    with pytest.raises(RuntimeError, match="patch size 7"):
+        hip.patch_embed(frames, w, pos.repeat(4, 1)[:17], cls, x.repeat(4, 1)[:34], patch=7)
+    assert not hip.patch_embed_ok(7, w, x) and not hip.patch_embed_ok(16, w.float(), x) and not hip.patch_embed_ok(16, w, x.bfloat16())
+    assert hip.patch_embed_ok(14, w, x) and not hip.patch_embed_ok(14, w[:, :640].contiguous(), x)          # 14 x 14: 704 padded-row slots
     with pytest.raises(RuntimeError, match="at least 10 rows"):                     # a stream too short for the frames: refused before the launch
         hip.patch_embed(_rand(2, 3, 32, 32, seed=39).cuda(), w, pos, cls, x[:9])
     with pytest.raises(RuntimeError, match="pos must be"):
