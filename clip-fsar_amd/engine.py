@@ -1,13 +1,17 @@
 """Host-side orchestration of the HIP kernels: the CLIP ViT image tower (A1-A8) and the few-shot tail (A9-A15).
 
 PyTorch is used only for device memory and the stream; every arithmetic step is a call into
-libclipfsar_hip.so (clip_fsar_amd.hip).  Two numeric modes:
+libclipfsar_hip.so (clip_fsar_amd.hip).  Numerics modes (DESIGN.md (c) has what each guarantees, measured):
 
   * ``precision="bf16"``  -- throughput mode: bf16 MFMA GEMMs / attention with fp32 accumulation, residual
     stream in IEEE fp16 (as CLIP's own GPU path), fp32 LayerNorm / softmax statistics, the two LayerNorms of a block folded
     into the QKV / c_fc GEMMs (fp16 MFMA operands there, bf16 elsewhere); the tail (features -> logits) is always fp32;
+  * ``precision="fp16"``  -- the fast 16-bit mode: fp16 operands everywhere, residual add in fp32 with a two-word fp16 stream, the weights' second fp16
+    word applied to the per-frame token mean of each GEMM's operand; inside 1e-3 as a statistic;
+  * ``precision="fp16_strict"`` (round 6, ViT towers) -- the fp16 mode + an exact patch-embedding front end + split QKV weights: every logit row of every
+    reference golden inside 1e-3 (a bound on everything measured);
   * ``precision="fp32"``  -- validation mode: fp32-input MFMA GEMMs (exact fp32 FMA chains) and an fp32 VALU
-    attention kernel; meets the 1e-3 logits tolerance against the reference's fp32 PyTorch path.
+    attention kernel; meets the 1e-3 logits tolerance against the reference's fp32 PyTorch path on any input.
 
 Layout in HBM (row-major): tokens x [F*N, D] (fp32 in the validation mode, fp16 in the bf16 mode; frame-major, token-minor;
 token 0 = class token),
@@ -357,9 +361,9 @@ class HipViT:
         N, D, npatch = self.ntok, self.D, self.ntok - 1
         M = F_ * N
         x, h, qkv, o, u = ws["x"], ws["h"], ws["qkv"], ws["o"], ws["u"]
-        # A2 (few_shot.py:672-676).  16 x 16 patches, 16-bit operands: ONE launch per frame set -- the GEMM gathers its rows from the fp32 frames,
-        # adds pos[1 + p], scatters them behind each class token and writes the class-token rows (cfsar_patch_embed).  Otherwise
-        # (ViT-L/14, the fp32 mode): patch gather -> GEMM with the scattering epilogue -> class-token rows; the results are bit-identical.
+        # A2 (few_shot.py:672-676).  16 x 16 / 14 x 14 patches, 16-bit operands: ONE launch per frame set -- the GEMM gathers its rows from the fp32
+        # frames, adds pos[1 + p], scatters them behind each class token and writes the class-token rows (cfsar_patch_embed).  Otherwise
+        # (the fp32 mode, other patch sizes): patch gather -> GEMM with the scattering epilogue -> class-token rows.  fp16_strict: its own front end below.
         off = 0
         for fr, c in zip(frame_sets, counts):
             if fr.shape[1:] != (3, self.arch["res"], self.arch["res"]):

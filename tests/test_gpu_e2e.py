@@ -115,6 +115,18 @@ def test_small_cases_fp16_bounded(name):
     assert torch.equal(logits[0].argmax(1), ref.argmax(1))
 
 
+@pytest.mark.parametrize("name", ["t_5w1s_T8", "t_5w3s_T16_mb_d2", "t197_5w1s_T2", "t257_5w1s_T2"])
+def test_small_cases_fp16_strict_bounded(name):
+    """precision "fp16_strict" on the tiny architectures (17 tokens per frame: every block GEMM falls back to split weights; 197 / 257 tokens: the
+    product's split-QKV + per-frame-correction form; 14 x 14 patches): inside the fp16 mode's per-case bound, same argmax as the reference."""
+    g = load_golden(name)
+    m = g["meta"]
+    a, sd, tt, te, ep = case_inputs(m)
+    logits, _ = run_engine(m, a, sd, tt, te, [ep], "fp16_strict")
+    assert maxdiff(logits[0], g["logits"]) < bound(name, "fp16"), maxdiff(logits[0], g["logits"])
+    assert torch.equal(logits[0].argmax(1), torch.from_numpy(g["logits"]).argmax(1))
+
+
 @pytest.mark.parametrize("name", OUTLIER_CASES)
 def test_outlier_channel_statistics(name, monkeypatch):
     """Reference-generated goldens whose residual stream carries two channels at |x| ~ 100 and a non-zero row mean (trained-CLIP-like

@@ -136,3 +136,22 @@ def test_install_as_reference_modules():
         for k, v in saved.items():
             if v is not None:
                 sys.modules[k] = v
+
+
+def test_patch_embed_weight_layouts():
+    """hip.patch_embed_weight (pure layout + one rounding): 16 x 16 patches = conv1.weight.reshape(D, 768); 14 x 14 = padded rows, column
+    (c 14 + dy) 16 + dx, zeros at dx = 14, 15 and behind column 672 (include/clipfsar_hip.h: cfsar_patch_embed)."""
+    import torch
+    from clip_fsar_amd import hip
+    g = torch.Generator().manual_seed(3)
+    w16 = torch.randn(8, 3, 16, 16, generator=g)
+    assert torch.equal(hip.patch_embed_weight(w16, 16, torch.float16), w16.reshape(8, 768).half())
+    w14 = torch.randn(8, 3, 14, 14, generator=g)
+    out = hip.patch_embed_weight(w14, 14, torch.bfloat16)
+    assert tuple(out.shape) == (8, 704) and out.dtype == torch.bfloat16
+    for (c, dy, dx) in ((0, 0, 0), (1, 5, 13), (2, 13, 7)):
+        assert torch.equal(out[:, (c * 14 + dy) * 16 + dx], w14[:, c, dy, dx].bfloat16())
+    pad = out.float().reshape(8, 44, 16)
+    assert float(pad[:, :42, 14:].abs().max()) == 0.0 and float(pad[:, 42:].abs().max()) == 0.0
+    assert hip.PATCH_EMBED_SLOTS == {16: 768, 14: 704}
+
