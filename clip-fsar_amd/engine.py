@@ -271,6 +271,7 @@ class HipViT:
         # a third enters BEFORE the first block: the patch embedding's 11-bit pixels and weights (0.7 % of the tower's FLOPs) and the two one-word
         # stores of the stream in front of the blocks.  Strict: the patch-embed GEMM runs three fp16 passes [hi | lo | hi] x [W_hi | W_hi | W_lo]
         # into an fp32 token matrix, and class token + pos + ln_pre write the two-word stream directly (cfsar_embed_finish_pair).
+        self.strict_front = self.o_pair = False
         if self.strict:
             if not (self.two_word and self.fold and D % 4 == 0 and D <= 1024):
                 raise ValueError("precision 'fp16_strict' needs the two-word stream (options fp16_wide / fp16_lo) and a width <= 1024")
@@ -293,8 +294,6 @@ class HipViT:
                     blk["w3_out"] = torch.cat([Wh, Wh, (W - Wh.float()).to(torch.float16)], 1).contiguous()
         self._slots = {}
         self.max_frames_32bit = (2 ** 32 - 1) // (self.ntok * 4 * self.D * 2) - 1
-        self.strict_front = self.strict and getattr(self, "strict_front", False)
-        self.o_pair = self.strict and getattr(self, "o_pair", False)
         if self.strict_front:                                                      # ... and of the three-word patch matrix [F (ntok - 1), 3 kpad]
             self.max_frames_32bit = min(self.max_frames_32bit, (2 ** 32 - 1) // ((self.ntok - 1) * 3 * self.kpad * 2) - 1)
 
