@@ -84,6 +84,28 @@ def test_test_few_shot_real_head_matches_oracle(eps_per_step):
 
 @gpu
 @needs_gpu
+def test_test_few_shot_precision_fp16_strict_through_the_config():
+    """VIDEO.HEAD.PRECISION: "fp16_strict" is a config value like the other modes: build_model -> the head -> the engine in that mode (split QKV weights,
+    exact front end), the harness's statistics equal the oracle's (same top-1 on clearly separated queries; loss within the tiny tower's 16-bit noise)."""
+    from clip_fsar_amd.models.base.builder import build_model
+    from clip_fsar_amd.runs.test_net_few_shot import test_few_shot
+    n = 8
+    cfg = _cfg(n, 4, precision="fp16_strict")
+    res = test_few_shot(cfg)
+    acc, loss = _oracle_stats(n, 18)
+    assert res["episodes"] == n
+    assert abs(res["top1_acc"] - acc) <= 100.0 / (n * 5) + 1e-4, (res["top1_acc"], acc)            # at most one near-tie of 40 queries
+    assert abs(res["loss"] - loss) < 5e-3, (res["loss"], loss)
+    model, _ = build_model(cfg)
+    task = {k: torch.from_numpy(v).cuda() for k, v in synth.make_episode(5, 1, 1, T, synth.ARCHS[ARCH]["res"], N_TEST, 0, 18).items()}
+    with torch.no_grad():
+        model.eval()(task)
+    vit = model.head._engine.vit
+    assert vit.strict and vit.strict_front and vit.precision == "fp16"
+
+
+@gpu
+@needs_gpu
 def test_eval_epoch_and_ragged_last_step():
     """7 episodes in steps of 4: the loader's last batch holds 3; eval_epoch == test_epoch statistics."""
     from clip_fsar_amd.datasets.base.builder import build_loader
